@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (build container only).
+
+    python tools/make_goldens.py            # needs /root/reference (read-only)
+
+The reference is imported from ``/root/reference`` with the shims of SURVEY.md
+section 8(c); nothing of it is copied: only its numeric OUTPUTS on seeded inputs
+(``tests/golden_inputs.py``) are stored.  The GPU box never sees the reference.
+
+Shims (none touch /root/reference):
+  * ``cv2`` is absent -> stub module (imported at top level by MFT.utils.io /
+    geom_utils, never called on the hot path);
+  * no GPU here and 'cuda' is hard-coded (MFT/MFT.py:20, MFT/raft.py:17,45) ->
+    ``Tensor.cuda`` / ``.to('cuda')`` become no-ops, ``identity(device='cuda')``
+    is redirected to cpu;
+  * the trained checkpoint is missing -> ``RAFT.load_state_dict`` from the
+    build's seeded generator (``mft_amd.weights.make_weights``).
+"""
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parents[1]
+REF = Path("/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(REPO / "tests"))
+sys.path.insert(1, str(REF))
+
+cv2 = types.ModuleType("cv2")
+cv2.INTER_NEAREST = 0
+sys.modules["cv2"] = cv2
+
+import torch  # noqa: E402
+
+torch.set_num_threads(8)
+_orig_to = torch.Tensor.to
+
+
+def _to(self, *a, **k):
+    a = tuple("cpu" if (isinstance(x, str) and x.startswith("cuda")) else x for x in a)
+    if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+        k["device"] = "cpu"
+    return _orig_to(self, *a, **k)
+
+
+torch.Tensor.to = _to
+torch.Tensor.cuda = lambda self, *a, **k: self
+_orig_zeros = torch.zeros
+
+
+def _zeros(*a, **k):
+    if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+        k["device"] = "cpu"
+    return _orig_zeros(*a, **k)
+
+
+torch.zeros = _zeros
+
+from MFT.MFT import MFT, chain_results  # noqa: E402
+from MFT.raft import RAFTWrapper  # noqa: E402
+from MFT.results import FlowOUTrackingResult  # noqa: E402
+from MFT.config import Config  # noqa: E402
+from MFT.RAFT.core.raft import RAFT  # noqa: E402
+from MFT.RAFT.core.corr import CorrBlock  # noqa: E402
+
+import golden_inputs as gi  # noqa: E402
+from mft_amd.weights import make_weights  # noqa: E402
+from mft_amd.synth import SyntheticVideo  # noqa: E402
+
+OUT = REPO / "tests" / "golden"
+OUT.mkdir(parents=True, exist_ok=True)
+
+
+class AttrDict(dict):
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.__dict__.update(k)
+
+
+def build_reference_model():
+    args = AttrDict(occlusion_module="separate_with_uncertainty", small=False, mixed_precision=False)
+    model = RAFT(args)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in make_weights(gi.WEIGHT_SEED).items()}
+    missing = model.load_state_dict(sd, strict=True)
+    print("load_state_dict:", missing)
+    model.requires_grad_(False)
+    model.eval()
+    return model
+
+
+def build_reference_flower(model, iters):
+    fl = object.__new__(RAFTWrapper)
+    fl.C = Config()
+    fl.C.flow_iters = iters
+    fl.model = model
+    return fl
+
+
+def build_reference_tracker(flower, deltas=(np.inf, 1, 2, 4, 8, 16, 32), thr=0.02):
+    tr = object.__new__(MFT)
+    tr.C = Config()
+    tr.C.deltas = list(deltas)
+    tr.C.occlusion_threshold = thr
+    tr.flower = flower
+    tr.device = "cpu"
+    return tr
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def N(x):
+    return x.detach().cpu().numpy().astype(np.float32)
+
+
+def gen_ops(model):
+    d = {k: T(v) for k, v in gi.ops_inputs().items()}
+    out = {}
+    with torch.no_grad():
+        cb = CorrBlock(d["fmap1"], d["fmap2"], radius=4)
+        for l, lvl in enumerate(cb.corr_pyramid):
+            out[f"pyr{l}_checksum"] = gi.checksum(N(lvl))
+            out[f"pyr{l}_shape"] = np.array(lvl.shape)
+        rows = [0, 5, 100, 383]
+        for l, lvl in enumerate(cb.corr_pyramid):
+            out[f"pyr{l}_rows"] = N(lvl[rows])
+        out["pyr_rows_idx"] = np.array(rows)
+        out["lookup"] = N(cb(d["coords1"]))
+        ub = model.update_block
+        net, mask, delta, motion = ub(d["net"], d["inp"], d["corr"], d["flow"])
+        out["ub_net"], out["ub_mask"], out["ub_delta"], out["ub_motion"] = map(N, (net, mask, delta, motion))
+        occl, unc = model.occlusion_block(d["net"], d["inp"], d["corr"], d["flow"], d["delta_flow"], d["motion"])
+        out["ou_occl"], out["ou_unc"] = N(occl), N(unc)
+        out["up_flow"] = N(model.upsample_flow(d["flow"], d["mask"]))
+        out["up_occl"] = N(model.upsample_flow(d["occl_lr"], d["mask"], mult_coef=1.0))
+        out["up_unc"] = N(model.upsample_flow(d["unc_lr"], d["mask"], mult_coef=1.0, n_channels=1))
+        # encoders on a small image pair
+        vid = SyntheticVideo(128, 192, n_frames=4, seed=3)
+        img = T(vid[0][:, :, ::-1].copy()).permute(2, 0, 1)[None].float()
+        x = 2 * (img / 255.0) - 1.0
+        out["fnet"] = N(model.fnet(x))
+        out["cnet"] = N(model.cnet(x))
+    np.savez_compressed(OUT / "ops.npz", **out)
+    print("ops.npz", sum(v.nbytes for v in out.values()) / 1e6, "MB")
+
+
+def gen_compute_flow(model):
+    out = {}
+    with torch.no_grad():
+        for tag, (H, W, iters, fa, fb) in {"a": (128, 192, 12, 0, 3), "b": (125, 187, 4, 1, 2)}.items():
+            vid = SyntheticVideo(H, W, n_frames=8, seed=5)
+            fl = build_reference_flower(model, iters)
+            flow, extra = fl.compute_flow(vid[fa], vid[fb], mode="flow")
+            out[f"{tag}_flow"], out[f"{tag}_occl"], out[f"{tag}_sigma"] = N(flow), N(extra["occlusion"]), N(extra["sigma"])
+            out[f"{tag}_meta"] = np.array([H, W, iters, fa, fb])
+            print(tag, "flow mean abs", float(flow.abs().mean()), "occl>thr", float((extra["occlusion"] > 0.02).float().mean()),
+                  "sigma mean", float(extra["sigma"].mean()))
+    np.savez_compressed(OUT / "compute_flow.npz", **out)
+
+
+class StubFlower:
+    """compute_flow() that returns tests/golden_inputs.stub_flowou for the pair
+    encoded in the two images."""
+
+    def compute_flow(self, src_img, dst_img, mode="flow", init_flow=None, **kw):
+        l, r = gi.decode_id(src_img), gi.decode_id(dst_img)
+        flow, occl, sigma = gi.stub_flowou(l, r)
+        return T(flow), {"occlusion": T(occl), "sigma": T(sigma), "debug": None}
+
+
+def gen_chain_and_sequence():
+    out = {}
+    # (1) bare chain_results on two stub results
+    L = FlowOUTrackingResult(*map(T, gi.stub_flowou(0, 7)))
+    R = FlowOUTrackingResult(*map(T, gi.stub_flowou(7, 9)))
+    c = chain_results(L, R)
+    out["chain_flow"], out["chain_occl"], out["chain_sigma"] = N(c.flow), N(c.occlusion), N(c.sigma)
+    out["chain_invalid"] = c.invalid_mask().numpy()
+    # (2) full init/track sequences with the stub flower: forward and backward
+    keep = [1, 2, 3, 5, 9, 17, 33, 34, 43]
+    for tag, (start, direction) in {"fwd": (0, +1), "bwd": (gi.SEQ_FRAMES - 1, -1)}.items():
+        tr = build_reference_tracker(StubFlower())
+        tr.init(gi.id_image(start), start_frame_i=start, time_direction=direction)
+        sums, keys = [], []
+        for step in range(1, gi.SEQ_FRAMES):
+            fid = start + direction * step
+            meta = tr.track(gi.id_image(fid))
+            res = meta.result
+            sums.append(np.concatenate([gi.checksum(N(res.flow)), gi.checksum(N(res.occlusion)), gi.checksum(N(res.sigma))]))
+            keys.append(np.array(sorted(tr.memory.keys()) + [-1] * (40 - len(tr.memory))))
+            if step in keep:
+                out[f"{tag}_{step}_flow"], out[f"{tag}_{step}_occl"], out[f"{tag}_{step}_sigma"] = \
+                    N(res.flow), N(res.occlusion), N(res.sigma)
+        out[f"{tag}_checksums"] = np.stack(sums)
+        out[f"{tag}_memory_keys"] = np.stack(keys)
+        out[f"{tag}_keep"] = np.array(keep)
+    np.savez_compressed(OUT / "sequence_stub.npz", **out)
+    print("sequence_stub.npz", sum(v.nbytes for v in out.values()) / 1e6, "MB")
+
+
+def gen_e2e(model):
+    out = {}
+    vid = SyntheticVideo(gi.E2E_H, gi.E2E_W, n_frames=gi.E2E_FRAMES, seed=11)
+    fl = build_reference_flower(model, gi.E2E_ITERS)
+    requested = []
+    orig = fl.compute_flow
+
+    tr = build_reference_tracker(fl)
+    keep = [1, 3, 9, 33, 41]
+    with torch.no_grad():
+        tr.init(vid[0])
+        sums = []
+        for i in range(1, gi.E2E_FRAMES):
+            meta = tr.track(vid[i])
+            res = meta.result
+            sums.append(np.concatenate([gi.checksum(N(res.flow)), gi.checksum(N(res.occlusion)), gi.checksum(N(res.sigma))]))
+            if i in keep:
+                out[f"f{i}_flow"], out[f"f{i}_occl"], out[f"f{i}_sigma"] = N(res.flow), N(res.occlusion), N(res.sigma)
+            if i % 10 == 0:
+                print("e2e frame", i, "occl frac", float((res.occlusion > 0.5).float().mean()),
+                      "flow mean abs", float(res.flow.abs().mean()))
+    out["checksums"] = np.stack(sums)
+    out["keep"] = np.array(keep)
+    np.savez_compressed(OUT / "sequence_raft.npz", **out)
+    print("sequence_raft.npz", sum(v.nbytes for v in out.values()) / 1e6, "MB")
+
+
+if __name__ == "__main__":
+    assert REF.exists(), "the reference is only mounted in the build container"
+    model = build_reference_model()
+    which = sys.argv[1:] or ["ops", "flow", "seq", "e2e"]
+    if "ops" in which:
+        gen_ops(model)
+    if "flow" in which:
+        gen_compute_flow(model)
+    if "seq" in which:
+        gen_chain_and_sequence()
+    if "e2e" in which:
+        gen_e2e(model)
