@@ -1,0 +1,152 @@
+/*
+ * mftx.h -- C ABI of libmftx.so: MI355X (gfx950) kernels for the MFT hot path.
+ *
+ * Drop-in boundary.  The reference has no FFI for this
+ * path -- it calls torch ops from Python -- so each entry point replaces a
+ * Python-level function of the reference, cited below, and is what a
+ * maintainer would bind from Python with ctypes.  The one
+ * native precedent is the optional pybind op
+ * MFT/RAFT/alt_cuda_corr/correlation.cpp:19-54 (contiguous device tensors in,
+ * RuntimeError on bad input); the conventions here follow it.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm
+ *    allocations); nothing is allocated, freed or retained past the call,
+ *    except by mftx_raft_create, which keeps the weight POINTERS it is given;
+ *  - all tensors are contiguous fp32 unless stated otherwise;
+ *  - `stream` is a hipStream_t passed as void* (0 = the null stream); calls only
+ *    enqueue work, they never synchronise;
+ *  - return 0 on success, a negative MFTX_E_* for argument errors, a positive
+ *    hipError_t for runtime errors; mftx_last_error_string() describes the last
+ *    failure on the calling thread;
+ *  - re-entrant; one host thread per device.
+ *
+ * Layouts ("pixel-major" = NHWC): a map with C channels over P images of h x w
+ * cells is stored [P*h*w][ld] with ld >= C floats per cell.
+ */
+#ifndef MFTX_H
+#define MFTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFTX_VERSION 100
+
+#define MFTX_E_ARG (-1)      /* null pointer / non-positive size / unsupported shape */
+#define MFTX_E_ALIGN (-2)    /* pointer or leading dimension not 16-byte aligned */
+#define MFTX_E_WORKSPACE (-3) /* workspace too small */
+#define MFTX_E_STATE (-4)    /* bad handle */
+
+#define MFTX_MAX_CANDIDATES 16
+
+int mftx_version(void);
+const char *mftx_last_error_string(void);
+
+/* ---- a4 + a5: all-pairs correlation volume and its pyramid ---------------
+ * Replaces CorrBlock.corr + CorrBlock.__init__ (MFT/RAFT/core/corr.py:14-28,
+ * 53-69).  f1, f2: pixel-major feature maps [P][h*w][C] (C % 32 == 0).
+ * lvl0..3: [P][h*w][h_l*w_l] with h_l = h >> l, w_l = w >> l (floor).
+ * lvl0[p][i][j] = sum_c f1[p][i][c] * f2[p][j][c] / sqrt(C) on fp32 MFMA; levels
+ * 1..3 are 2x2 means of the level below over the TARGET dims. */
+int mftx_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, int w,
+                      float *lvl0, float *lvl1, float *lvl2, float *lvl3, void *stream);
+
+/* ---- a6: multi-scale 9x9 correlation lookup --------------------------------
+ * Replaces CorrBlock.__call__ + bilinear_sampler (core/corr.py:30-51,
+ * core/utils/utils.py:98-112).  coords: [P*h*w][2] (x, y) interleaved.
+ * out: pixel-major [P*h*w][ld_out], channel l*81 + a*9 + b = level l sampled at
+ * (x/2^l + a - 4, y/2^l + b - 4), bilinear, zeros outside. r must be 4. */
+int mftx_corr_lookup(const float *lvl0, const float *lvl1, const float *lvl2, const float *lvl3,
+                     const float *coords, int P, int h, int w, int r,
+                     float *out, int ld_out, void *stream);
+
+/* ---- a7-a9, a11: one convolution as an fp32-MFMA implicit GEMM -------------
+ * Replaces the nn.Conv2d calls of core/update.py (zero "same" padding, bias,
+ * optional activation).  Input = up to two pixel-major segments concatenated on
+ * the channel axis (c0 % 32 == 0 when c1 > 0).  wpk: weights packed
+ * [n_pad][kh*kw][cin_pad] (cin_pad = round_up(c0+c1, 32), n_pad =
+ * round_up(N, 128), zero filled), tap index = ky*kw + kx.
+ * out[m][n] = out_scale * act(conv + bias).  act: 0 none, 1 relu, 2 sigmoid,
+ * 3 tanh. */
+typedef struct mftx_conv_desc {
+    const float *a0; int lda0; int c0;
+    const float *a1; int lda1; int c1;
+    const float *wpk; const float *bias;
+    float *out; int ldo;
+    int P, h, w;         /* M = P*h*w output cells */
+    int N;               /* output channels */
+    int kh, kw;
+    int act;
+    float out_scale;
+} mftx_conv_desc;
+int mftx_conv2d(const mftx_conv_desc *d, void *stream);
+
+/* ---- a2, a7-a12: the whole RAFT refinement loop ----------------------------
+ * Replaces RAFT.forward from the correlation volume on (core/raft.py:141-226)
+ * plus RAFTWrapper's post-processing (MFT/raft.py:57-62), for P image pairs at
+ * once.  mftx_raft_create keeps pointers to packed weights (see
+ * mft_amd/raft.py:pack_weights for the order). */
+typedef struct mftx_raft mftx_raft;
+#define MFTX_RAFT_NUM_WEIGHTS 30
+int mftx_raft_create(const float *const *weights, int n_weights, mftx_raft **out);
+void mftx_raft_destroy(mftx_raft *r);
+size_t mftx_raft_workspace_bytes(int P, int h, int w);
+/* Byte offsets (19 of them) of the workspace regions lvl0..3, coords1, corr,
+ * cor1, corflo, flo1, hx, z, rh, fh, delta, mask, ouin, ouh, ou, flow_lr: after
+ * mftx_raft_refine they hold the intermediates of the last iteration (tests). */
+int mftx_raft_workspace_layout(int P, int h, int w, size_t *offsets, int n);
+/* fmap1/fmap2: [P][h*w][256]; net, inp: [P][h*w][128] (tanh / relu already
+ * applied).  Outputs are planar and UNPADDED: flow [P][2][H0][W0], occl
+ * [P][1][H0][W0] (softmax channel 1), sigma [P][1][H0][W0] (sqrt(exp(u))), with
+ * H0 = 8h - pad_top - pad_bottom etc.  flow_lr (optional) [P*h*w][2]. */
+int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters,
+                     const float *fmap1, const float *fmap2, const float *net, const float *inp,
+                     int pad_left, int pad_right, int pad_top, int pad_bottom,
+                     float *flow, float *occl, float *sigma, float *flow_lr,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- a10 + a12: convex 8x upsampling + post-processing ---------------------
+ * Replaces RAFT.upsample_flow (core/raft.py:83-94) for the three heads and
+ * MFT/raft.py:57-62.  flow_lr [M][2], ou [M][ld_ou] (occl logit0, logit1,
+ * log-variance), mask pixel-major [M][576] (channel k*64 + sy*8 + sx). */
+int mftx_convex_upsample(const float *flow_lr, const float *ou, int ld_ou, const float *mask,
+                         int P, int h, int w,
+                         int pad_left, int pad_right, int pad_top, int pad_bottom,
+                         float *flow, float *occl, float *sigma, void *stream);
+
+/* ---- a14: chain_results -----------------------------------------------------
+ * Replaces chain_results (MFT/MFT.py:233-239) = FlowOUTrackingResult.chain +
+ * 2x warp_backward (MFT/results.py:87-136).  Planar [2|1][H][W] inputs. */
+int mftx_chain(const float *flowL, const float *occlL, const float *sigmaL,
+               const float *flowR, const float *occlR, const float *sigmaR,
+               int H, int W, float *flowO, float *occlO, float *sigmaO, void *stream);
+
+/* ---- a14 (part): FlowOUTrackingResult.warp_backward (MFT/results.py:116-136)
+ * out[c] = bilinear sample of img[c] ([C][H][W]) at pixel grid + flow ([2][H][W]),
+ * zeros outside, same normalise / un-normalise round trip as the reference. */
+int mftx_warp_backward(const float *flow, const float *img, int C, int H, int W, float *out, void *stream);
+
+/* ---- a15: per-pixel best-chain selection -----------------------------------
+ * Replaces MFT/MFT.py:112-143 + invalid_mask (MFT/results.py:250-265).
+ * Candidates must be ordered [inf, 1, 2, ...]; first arg-max of -sigma with
+ * occl > thr scored -inf; occl := 1 where the selected flow leaves the image.
+ * chosen (optional) [H][W] int8 candidate index. */
+int mftx_select(int K, const float *const *flow, const float *const *occl, const float *const *sigma,
+                float thr, int H, int W,
+                float *flowO, float *occlO, float *sigmaO, int8_t *chosen, void *stream);
+
+/* ---- a14 + a15 fused: chain every candidate and select in one pass --------- */
+int mftx_chain_select(int K,
+                      const float *const *flowL, const float *const *occlL, const float *const *sigmaL,
+                      const float *const *flowR, const float *const *occlR, const float *const *sigmaR,
+                      float thr, int H, int W,
+                      float *flowO, float *occlO, float *sigmaO, int8_t *chosen, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFTX_H */

@@ -1,0 +1,219 @@
+"""MFT tracker -- drop-in for ``MFT/MFT.py:13-239``.
+
+Same public surface: ``MFT(config)``, ``.init(img, start_frame_i=0,
+time_direction=1, flow_cache=None) -> meta``, ``.track(img) -> meta`` with
+``meta.result`` a ``FlowOUTrackingResult`` on the CPU, ``tracker.C`` (monkey-
+patched by runners), ``tracker.memory[frame_i] = {'img', 'result'}`` on the
+device, plus the module-level ``get_flowou_with_cache`` and ``chain_results``.
+
+What changed underneath (same results):
+  * the <= 7 (left -> current) flow pairs of a frame are gathered first and run
+    as ONE batched pass through the native RAFT engine (``compute_flow_many``)
+    instead of 7 separate forward passes; frames are encoded once and cached;
+  * the 7 x ``chain_results`` + stack / max / gather selection is one fused HIP
+    kernel (``mftx_chain_select``);
+  * with ``torch.distributed`` initialised and ``C.delta_sharding`` set, the
+    pairs are sharded over ranks and reassembled with one all-gather
+    (``mft_amd/dist.py``).
+Python remains the owner of the delta bookkeeping, the memory ring and the cache.
+"""
+from __future__ import annotations
+
+import logging
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import ops
+from .results import FlowOUTrackingResult
+
+logger = logging.getLogger(__name__)
+
+
+class HipBackend:
+    """chain / select on libmftx (the only product backend)."""
+
+    @staticmethod
+    def chain(L, R):
+        return ops.chain(L, R)
+
+    @staticmethod
+    def select(cands, thr):
+        return ops.select(cands, thr, want_chosen=True)
+
+    @staticmethod
+    def chain_select(Ls, Rs, thr):
+        return ops.chain_select(Ls, Rs, thr, want_chosen=True)
+
+
+class MFT():
+    def __init__(self, config, backend=None, device='cuda'):
+        """config: a mft_amd.config.Config, e.g. from configs/MFT_cfg.py."""
+        self.C = config   # must be named self.C, runners monkey-patch it
+        self.flower = config.flow_config.of_class(config.flow_config)
+        self.device = device
+        self.backend = backend if backend is not None else HipBackend()
+        self.sharder = None
+
+    # ------------------------------------------------------------------ init
+    def init(self, img, start_frame_i=0, time_direction=1, flow_cache=None, **kwargs):
+        """Initialise on the first frame (MFT/MFT.py:22-53)."""
+        self.img_H, self.img_W = img.shape[:2]
+        self.start_frame_i = start_frame_i
+        self.current_frame_i = self.start_frame_i
+        assert time_direction in [+1, -1]
+        self.time_direction = time_direction
+        self.flow_cache = flow_cache
+        if hasattr(self.flower, "reset_cache"):
+            self.flower.reset_cache()
+        self.memory = {
+            self.start_frame_i: {
+                'img': img,
+                'result': FlowOUTrackingResult.identity((self.img_H, self.img_W), device=self.device)
+            }
+        }
+        self.template_img = img.copy() if hasattr(img, "copy") else img.clone()
+        self.last_pairs = []
+        self.last_chosen = None
+        if self.C.delta_sharding:
+            from .dist import DeltaSharder
+            self.sharder = DeltaSharder.from_environment()
+        meta = SimpleNamespace()
+        meta.result = self.memory[self.start_frame_i]['result'].clone().cpu()
+        return meta
+
+    # ----------------------------------------------------------------- track
+    def _plan(self):
+        """Delta bookkeeping of MFT/MFT.py:74-91: [(delta, left_id, use_cache)]."""
+        plan, used = [], []
+        for delta in self.C.deltas:
+            left_id = self.current_frame_i - delta * self.time_direction
+            if self.is_before_start(left_id):
+                if np.isinf(delta):
+                    left_id = self.start_frame_i
+                else:
+                    continue
+            left_id = int(left_id)
+            if left_id in used:
+                continue
+            used.append(left_id)
+            use_cache = bool(np.isfinite(delta) or self.C.cache_delta_infinity)
+            plan.append((delta, left_id, use_cache))
+        # selection order: inf first, then ascending delta (MFT/MFT.py:114)
+        plan.sort(key=lambda e: 0 if np.isinf(e[0]) else e[0])
+        return plan
+
+    def track(self, input_img, debug=False, **kwargs):
+        """Track one frame (MFT/MFT.py:55-154)."""
+        meta = SimpleNamespace()
+        self.current_frame_i += self.time_direction
+        right_id = self.current_frame_i
+        plan = self._plan()
+        self.last_pairs = [(left_id, right_id) for _, left_id, _ in plan]
+
+        if self.sharder is not None and self.sharder.world_size > 1:
+            flow, occl, sigma, chosen = self.sharder.track_step(self, plan, input_img)
+        else:
+            rights = self._flows_for(plan, input_img, range(len(plan)))
+            lefts = [self.memory[left_id]['result'].planes() for _, left_id, _ in plan]
+            flow, occl, sigma, chosen = self.backend.chain_select(lefts, [r.planes() for r in rights],
+                                                                  self.C.occlusion_threshold)
+        # invalid flows are already marked occluded inside the selection kernel
+        result = FlowOUTrackingResult(flow, occl, sigma, validate=False)
+        self.last_chosen = chosen
+
+        if self.C.keep_result_on_device:
+            meta.result = result
+        else:
+            meta.result = result.clone().cpu()
+
+        self.memory[self.current_frame_i] = {'img': input_img, 'result': result}
+        self.cleanup_memory()
+        return meta
+
+    def _flows_for(self, plan, input_img, indices):
+        """FlowOU (left -> current) for plan[i], i in indices: cache first, then
+        one batched flow computation for everything that is missing."""
+        right_id = self.current_frame_i
+        out, missing = {}, []
+        for i in indices:
+            _, left_id, use_cache = plan[i]
+            got = None
+            if use_cache and self.flow_cache is not None:
+                try:
+                    f, o, s = self.flow_cache.read(left_id, right_id)
+                    assert f is not None
+                    got = FlowOUTrackingResult(f, o, s)
+                except Exception:
+                    got = None
+            if got is None:
+                missing.append(i)
+            else:
+                out[i] = got
+        if missing:
+            if hasattr(self.flower, "compute_flow_many"):
+                res = self.flower.compute_flow_many(
+                    [(plan[i][1], self.memory[plan[i][1]]['img']) for i in missing], (right_id, input_img))
+            else:  # any reference-style plugin
+                res = []
+                for i in missing:
+                    f, extra = self.flower.compute_flow(self.memory[plan[i][1]]['img'], input_img, mode='flow',
+                                                        init_flow=None)
+                    res.append((f, extra['occlusion'], extra['sigma']))
+            for i, (f, o, s) in zip(missing, res):
+                _, left_id, use_cache = plan[i]
+                if self.flow_cache is not None and use_cache:
+                    self.flow_cache.write(left_id, right_id, f, o, s)
+                out[i] = FlowOUTrackingResult(f, o, s, validate=False)
+        return [out[i] for i in indices]
+
+    # --------------------------------------------------------------- memory
+    def cleanup_memory(self):
+        """Keep the start frame (iff inf in deltas) and every frame still within
+        the largest finite delta of the current one (MFT/MFT.py:157-181)."""
+        finite = [d for d in self.C.deltas if np.isfinite(d)]
+        max_delta = max(finite) if finite else 0
+        has_direct_flow = any(np.isinf(d) for d in self.C.deltas)
+        for mem_frame_i in list(self.memory.keys()):
+            if mem_frame_i == self.start_frame_i and has_direct_flow:
+                continue
+            if self.time_direction > 0 and mem_frame_i + max_delta > self.current_frame_i:
+                continue
+            if self.time_direction < 0 and mem_frame_i - max_delta < self.current_frame_i:
+                continue
+            del self.memory[mem_frame_i]
+        if hasattr(self.flower, "retain"):
+            self.flower.retain(self.memory.keys())
+
+    def is_before_start(self, frame_i):
+        return ((self.time_direction > 0 and frame_i < self.start_frame_i) or
+                (self.time_direction < 0 and frame_i > self.start_frame_i))
+
+
+def get_flowou_with_cache(flower, left_img, right_img, flow_init=None,
+                          cache=None, left_id=None, right_id=None,
+                          read_cache=False, write_cache=False):
+    """Flow left -> right, possibly cached (MFT/MFT.py:189-230); any cache read
+    error means recompute."""
+    must_compute = not read_cache
+    if read_cache and flow_init is None:
+        assert left_id is not None
+        assert right_id is not None
+        try:
+            assert cache is not None
+            flow_left_to_right, occlusions, sigmas = cache.read(left_id, right_id)
+            assert flow_left_to_right is not None
+        except Exception:
+            must_compute = True
+    if must_compute:
+        flow_left_to_right, extra = flower.compute_flow(left_img, right_img, mode='flow', init_flow=flow_init)
+        occlusions, sigmas = extra['occlusion'], extra['sigma']
+    if (cache is not None) and write_cache and must_compute and (flow_init is None):
+        cache.write(left_id, right_id, flow_left_to_right, occlusions, sigmas)
+    return FlowOUTrackingResult(flow_left_to_right, occlusions, sigmas)
+
+
+def chain_results(left_result, right_result):
+    """(template -> left) o (left -> right) in one HIP kernel (MFT/MFT.py:233-239)."""
+    return left_result.chain_result(right_result)

@@ -1,0 +1,86 @@
+"""ctypes binding of libmftx.so (include/mftx.h).  There is no CPU fallback: if
+the HIP library is missing or a call fails, this raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libmftx.so"
+
+MAX_CANDIDATES = 16
+NUM_RAFT_WEIGHTS = 30
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("a0", C.c_void_p), ("lda0", C.c_int), ("c0", C.c_int),
+                ("a1", C.c_void_p), ("lda1", C.c_int), ("c1", C.c_int),
+                ("wpk", C.c_void_p), ("bias", C.c_void_p),
+                ("out", C.c_void_p), ("ldo", C.c_int),
+                ("P", C.c_int), ("h", C.c_int), ("w", C.c_int),
+                ("N", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
+                ("act", C.c_int), ("out_scale", C.c_float)]
+
+
+_PP = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/mftx.h one to one
+SIGNATURES = {
+    "mftx_version": (C.c_int, []),
+    "mftx_last_error_string": (C.c_char_p, []),
+    "mftx_corr_pyramid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mftx_corr_lookup": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p]),
+    "mftx_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "mftx_raft_create": (C.c_int, [_PP, C.c_int, C.POINTER(C.c_void_p)]),
+    "mftx_raft_destroy": (None, [C.c_void_p]),
+    "mftx_raft_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "mftx_raft_workspace_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.c_int]),
+    "mftx_raft_refine": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mftx_convex_upsample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 7
+                             + [C.c_void_p] * 4),
+    "mftx_chain": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int] + [C.c_void_p] * 4),
+    "mftx_warp_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mftx_select": (C.c_int, [C.c_int, _PP, _PP, _PP, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "mftx_chain_select": (C.c_int, [C.c_int] + [_PP] * 6 + [C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 5),
+}
+
+_lib = None
+
+
+class MftxError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmftx.so (built by ``__graft_entry__.build()`` / ``make -C mft_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("MFTX_LIB", LIB_PATH))
+    if not path.exists():
+        raise MftxError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(there is no CPU fallback for the MFT hot path)")
+    lib = C.CDLL(str(path))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().mftx_last_error_string().decode(errors="replace")
+        raise MftxError(f"{what} failed ({code}): {msg}")
+
+
+def ptr_array(ptrs):
+    arr = (C.c_void_p * len(ptrs))(*ptrs)
+    return C.cast(arr, _PP), arr

@@ -1,0 +1,240 @@
+// MFT flow chaining and per-pixel best-chain selection (HBM-bound).
+//
+// chain (MFT/MFT.py:233-239, MFT/results.py:87-136), per pixel g = (x, y):
+//   p     = g + flowL
+//   B(X)  = bilinear sample of X at p, zeros outside, align_corners=True, after
+//           the reference's normalise (MFT/utils/interpolation.py:69-72) /
+//           un-normalise round trip, reproduced here in fp32
+//   flow  = (p + B(flowR)) - g ;  occl = max(occlL, B(occlR)) ;
+//   sigma = sqrt(sigmaL^2 + B(sigmaR)^2)
+// select (MFT/MFT.py:112-143, MFT/results.py:250-265): first arg-max over the
+// candidates of -sigma, with -inf where occl > thr; then occl = 1 where the
+// selected flow leaves the image.
+//
+// The reference does 3 grid_samples + ~25 launches per candidate and a
+// stack/max/gather pass; here one thread owns a pixel, walks the K candidates,
+// and keeps the running best in registers: (32 K + 16) B/pixel of traffic.
+// `chain_px` is shared by all three kernels so that chain -> all-gather ->
+// select (multi-GPU) is bitwise identical to the fused single-GPU kernel.
+// Compiled with -ffp-contract=off: no FMA contraction, products and sums round
+// exactly as written.
+#include "common.h"
+
+namespace mftx {
+
+struct Planes { const float *flow, *occl, *sigma; };
+struct Chained { float fx, fy, occ, sig; };
+
+__device__ __forceinline__ float tap(const float *pl, int H, int W, int yy, int xx) {
+    return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? pl[(long long)yy * W + xx] : 0.f;
+}
+
+// NaN handling follows torch: a NaN sampled occlusion propagates through
+// maximum(); fmaxf would drop it, so patch it up explicitly.
+__device__ __forceinline__ float max_nanprop(float a, float b) {
+    return (a != a || b != b) ? NAN : fmaxf(a, b);
+}
+
+__device__ __forceinline__ Chained chain_px(const Planes &L, const Planes &R, int H, int W, int x, int y,
+                                           float sx, float sy) {
+    const long long pix = (long long)y * W + x;
+    const long long plane = (long long)H * W;
+    const float gx = (float)x, gy = (float)y;
+    const float px = gx + L.flow[pix];
+    const float py = gy + L.flow[plane + pix];
+    // normalise: p * float32(2/(W-1)) - 1 ; un-normalise: ((g + 1) / 2) * (W - 1)
+    const float ix = ((px * sx - 1.f) + 1.f) / 2.f * (float)(W - 1);
+    const float iy = ((py * sy - 1.f) + 1.f) / 2.f * (float)(H - 1);
+    const float flx = floorf(ix), fly = floorf(iy);
+    const float wx = ix - flx, wy = iy - fly;
+    const int x0 = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
+    const int y0 = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
+    const float w00 = (1.f - wx) * (1.f - wy), w01 = wx * (1.f - wy), w10 = (1.f - wx) * wy, w11 = wx * wy;
+    auto samp = [&](const float *pl) {
+        return tap(pl, H, W, y0, x0) * w00 + tap(pl, H, W, y0, x0 + 1) * w01 +
+               tap(pl, H, W, y0 + 1, x0) * w10 + tap(pl, H, W, y0 + 1, x0 + 1) * w11;
+    };
+    Chained c;
+    c.fx = (px + samp(R.flow)) - gx;
+    c.fy = (py + samp(R.flow + plane)) - gy;
+    c.occ = max_nanprop(L.occl[pix], samp(R.occl));
+    const float sl = L.sigma[pix], sr = samp(R.sigma);
+    c.sig = sqrtf(sl * sl + sr * sr);
+    return c;
+}
+
+__global__ __launch_bounds__(256) void chain_kernel(Planes L, Planes R, int H, int W, float sx, float sy,
+                                                    float *flowO, float *occlO, float *sigmaO) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    const Chained c = chain_px(L, R, H, W, x, y, sx, sy);
+    const long long pix = (long long)y * W + x, plane = (long long)H * W;
+    flowO[pix] = c.fx; flowO[plane + pix] = c.fy; occlO[pix] = c.occ; sigmaO[pix] = c.sig;
+}
+
+// warp_backward (MFT/results.py:116-136): out[c] = B(img[c]) at p = g + flow
+__global__ __launch_bounds__(256) void warp_backward_kernel(const float *__restrict__ flow,
+                                                            const float *__restrict__ img, int C, int H, int W,
+                                                            float sx, float sy, float *__restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    const long long pix = (long long)y * W + x, plane = (long long)H * W;
+    const float px = (float)x + flow[pix];
+    const float py = (float)y + flow[plane + pix];
+    const float ix = ((px * sx - 1.f) + 1.f) / 2.f * (float)(W - 1);
+    const float iy = ((py * sy - 1.f) + 1.f) / 2.f * (float)(H - 1);
+    const float flx = floorf(ix), fly = floorf(iy);
+    const float wx = ix - flx, wy = iy - fly;
+    const int x0 = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
+    const int y0 = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
+    const float w00 = (1.f - wx) * (1.f - wy), w01 = wx * (1.f - wy), w10 = (1.f - wx) * wy, w11 = wx * wy;
+    for (int c = 0; c < C; ++c) {
+        const float *pl = img + c * plane;
+        out[c * plane + pix] = tap(pl, H, W, y0, x0) * w00 + tap(pl, H, W, y0, x0 + 1) * w01 +
+                               tap(pl, H, W, y0 + 1, x0) * w10 + tap(pl, H, W, y0 + 1, x0 + 1) * w11;
+    }
+}
+
+struct CandSet {
+    int K;
+    Planes L[MFTX_MAX_CANDIDATES];
+    Planes R[MFTX_MAX_CANDIDATES];
+};
+
+struct Best { float score; Chained c; int k; };
+
+__device__ __forceinline__ void consider(Best &b, const Chained &c, int k, float thr) {
+    // torch: scores = -sigma; scores[occl > thr] = -inf; max(dim=0) keeps the
+    // first maximal index (a NaN score wins over everything, first NaN kept).
+    const float score = (c.occ > thr) ? -INFINITY : -c.sig;
+    bool take;
+    if (k == 0) take = true;
+    else if (b.score != b.score) take = false;          // current best is NaN
+    else if (score != score) take = true;               // NaN beats numbers
+    else take = score > b.score;                        // strict: first max wins
+    if (take) { b.score = score; b.c = c; b.k = k; }
+}
+
+__device__ __forceinline__ void write_selected(const Best &b, int H, int W, int x, int y, float *flowO,
+                                               float *occlO, float *sigmaO, int8_t *chosen) {
+    const long long pix = (long long)y * W + x, plane = (long long)H * W;
+    const float qx = (float)x + b.c.fx, qy = (float)y + b.c.fy;
+    const bool invalid = (qx < 0.f) | (qy < 0.f) | (qx >= (float)W) | (qy >= (float)H);
+    flowO[pix] = b.c.fx;
+    flowO[plane + pix] = b.c.fy;
+    occlO[pix] = invalid ? 1.f : b.c.occ;
+    sigmaO[pix] = b.c.sig;
+    if (chosen) chosen[pix] = (int8_t)b.k;
+}
+
+__global__ __launch_bounds__(256) void chain_select_kernel(CandSet cs, float thr, int H, int W, float sx,
+                                                           float sy, float *flowO, float *occlO, float *sigmaO,
+                                                           int8_t *chosen) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    Best b;
+    b.score = 0.f; b.k = 0; b.c = Chained{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < cs.K; ++k) consider(b, chain_px(cs.L[k], cs.R[k], H, W, x, y, sx, sy), k, thr);
+    write_selected(b, H, W, x, y, flowO, occlO, sigmaO, chosen);
+}
+
+struct SelSet {
+    int K;
+    Planes C[MFTX_MAX_CANDIDATES];
+};
+
+__global__ __launch_bounds__(256) void select_kernel(SelSet ss, float thr, int H, int W, float *flowO,
+                                                     float *occlO, float *sigmaO, int8_t *chosen) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    const long long pix = (long long)y * W + x, plane = (long long)H * W;
+    Best b;
+    b.score = 0.f; b.k = 0; b.c = Chained{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < ss.K; ++k) {
+        Chained c;
+        c.fx = ss.C[k].flow[pix]; c.fy = ss.C[k].flow[plane + pix];
+        c.occ = ss.C[k].occl[pix]; c.sig = ss.C[k].sigma[pix];
+        consider(b, c, k, thr);
+    }
+    write_selected(b, H, W, x, y, flowO, occlO, sigmaO, chosen);
+}
+
+}  // namespace mftx
+
+using namespace mftx;
+
+static void scales(int H, int W, float &sx, float &sy) {
+    // np.array([2/(W-1), 2/(H-1)]).astype(np.float32)  (double division, then rounded)
+    sx = (float)(2.0 / (double)(W - 1));
+    sy = (float)(2.0 / (double)(H - 1));
+}
+
+extern "C" int mftx_chain(const float *flowL, const float *occlL, const float *sigmaL, const float *flowR,
+                          const float *occlR, const float *sigmaR, int H, int W, float *flowO, float *occlO,
+                          float *sigmaO, void *stream) {
+    if (!flowL || !occlL || !sigmaL || !flowR || !occlR || !sigmaR || !flowO || !occlO || !sigmaO)
+        return fail(MFTX_E_ARG, "chain: null pointer");
+    if (H < 2 || W < 2) return fail(MFTX_E_ARG, "chain: H and W must be >= 2");
+    float sx, sy;
+    scales(H, W, sx, sy);
+    Planes L{flowL, occlL, sigmaL}, R{flowR, occlR, sigmaR};
+    hipLaunchKernelGGL(chain_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, L, R, H, W, sx, sy,
+                       flowO, occlO, sigmaO);
+    return check_launch("chain");
+}
+
+extern "C" int mftx_warp_backward(const float *flow, const float *img, int C, int H, int W, float *out,
+                                  void *stream) {
+    if (!flow || !img || !out) return fail(MFTX_E_ARG, "warp_backward: null pointer");
+    if (C < 1 || H < 2 || W < 2) return fail(MFTX_E_ARG, "warp_backward: need C >= 1, H, W >= 2");
+    float sx, sy;
+    scales(H, W, sx, sy);
+    hipLaunchKernelGGL(warp_backward_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, flow, img,
+                       C, H, W, sx, sy, out);
+    return check_launch("warp_backward");
+}
+
+extern "C" int mftx_select(int K, const float *const *flow, const float *const *occl, const float *const *sigma,
+                           float thr, int H, int W, float *flowO, float *occlO, float *sigmaO, int8_t *chosen,
+                           void *stream) {
+    if (K < 1 || K > MFTX_MAX_CANDIDATES) return fail(MFTX_E_ARG, "select: K must be in 1..%d", MFTX_MAX_CANDIDATES);
+    if (!flow || !occl || !sigma || !flowO || !occlO || !sigmaO) return fail(MFTX_E_ARG, "select: null pointer");
+    if (H < 1 || W < 1) return fail(MFTX_E_ARG, "select: bad size");
+    SelSet ss;
+    ss.K = K;
+    for (int k = 0; k < K; ++k) {
+        if (!flow[k] || !occl[k] || !sigma[k]) return fail(MFTX_E_ARG, "select: null candidate %d", k);
+        ss.C[k] = Planes{flow[k], occl[k], sigma[k]};
+    }
+    hipLaunchKernelGGL(select_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, ss, thr, H, W,
+                       flowO, occlO, sigmaO, chosen);
+    return check_launch("select");
+}
+
+extern "C" int mftx_chain_select(int K, const float *const *flowL, const float *const *occlL,
+                                 const float *const *sigmaL, const float *const *flowR,
+                                 const float *const *occlR, const float *const *sigmaR, float thr, int H, int W,
+                                 float *flowO, float *occlO, float *sigmaO, int8_t *chosen, void *stream) {
+    if (K < 1 || K > MFTX_MAX_CANDIDATES)
+        return fail(MFTX_E_ARG, "chain_select: K must be in 1..%d", MFTX_MAX_CANDIDATES);
+    if (!flowL || !occlL || !sigmaL || !flowR || !occlR || !sigmaR || !flowO || !occlO || !sigmaO)
+        return fail(MFTX_E_ARG, "chain_select: null pointer");
+    if (H < 2 || W < 2) return fail(MFTX_E_ARG, "chain_select: H and W must be >= 2");
+    CandSet cs;
+    cs.K = K;
+    for (int k = 0; k < K; ++k) {
+        if (!flowL[k] || !occlL[k] || !sigmaL[k] || !flowR[k] || !occlR[k] || !sigmaR[k])
+            return fail(MFTX_E_ARG, "chain_select: null candidate %d", k);
+        cs.L[k] = Planes{flowL[k], occlL[k], sigmaL[k]};
+        cs.R[k] = Planes{flowR[k], occlR[k], sigmaR[k]};
+    }
+    float sx, sy;
+    scales(H, W, sx, sy);
+    hipLaunchKernelGGL(chain_select_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, cs, thr, H,
+                       W, sx, sy, flowO, occlO, sigmaO, chosen);
+    return check_launch("chain_select");
+}

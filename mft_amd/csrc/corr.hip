@@ -1,0 +1,169 @@
+// Correlation pyramid pooling and the multi-scale 9x9 lookup (HBM-bound).
+#include "common.h"
+
+namespace mftx {
+
+// ---------------------------------------------------------------------------
+// Pyramid: levels 1..3 from level 0, one workgroup per query row.
+// core/corr.py:26-28: 3x avg_pool2d(2, stride 2) over the target dims (floor
+// sizes).  Sum order ((v00 + v01) + v10) + v11, then * 0.25 -- the order ATen's
+// avg_pool2d uses -- so the result is bit-identical to the CPU reference.
+// The row of level 0 is read once from HBM; levels 1 and 2 stay in LDS while
+// the next level is formed.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void corr_pool_kernel(const float *__restrict__ lvl0, int h, int w,
+                                                        float *__restrict__ lvl1, float *__restrict__ lvl2,
+                                                        float *__restrict__ lvl3) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int h1 = h >> 1, w1 = w >> 1, h2 = h >> 2, w2 = w >> 2, h3 = h >> 3, w3 = w >> 3;
+    float *s1 = sm;                 // h1*w1
+    float *s2 = sm + h1 * w1;       // h2*w2
+    const long long row = blockIdx.x;
+    const float *src = lvl0 + row * (long long)h * w;
+    float *d1 = lvl1 + row * (long long)h1 * w1;
+    float *d2 = lvl2 + row * (long long)h2 * w2;
+    float *d3 = lvl3 + row * (long long)h3 * w3;
+    for (int i = threadIdx.x; i < h1 * w1; i += blockDim.x) {
+        const int y = i / w1, x = i - y * w1;
+        const float *p = src + (2 * y) * w + 2 * x;
+        const float v = (((p[0] + p[1]) + p[w]) + p[w + 1]) * 0.25f;
+        s1[i] = v;
+        d1[i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < h2 * w2; i += blockDim.x) {
+        const int y = i / w2, x = i - y * w2;
+        const float *p = s1 + (2 * y) * w1 + 2 * x;
+        const float v = (((p[0] + p[1]) + p[w1]) + p[w1 + 1]) * 0.25f;
+        s2[i] = v;
+        d2[i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < h3 * w3; i += blockDim.x) {
+        const int y = i / w3, x = i - y * w3;
+        const float *p = s2 + (2 * y) * w2 + 2 * x;
+        d3[i] = (((p[0] + p[1]) + p[w2]) + p[w2 + 1]) * 0.25f;
+    }
+}
+
+int launch_corr_pool(const float *lvl0, int rows, int h, int w, float *lvl1, float *lvl2, float *lvl3,
+                     hipStream_t s) {
+    const size_t lds = ((size_t)(h >> 1) * (w >> 1) + (size_t)(h >> 2) * (w >> 2)) * sizeof(float);
+    if (lds > 150 * 1024) return fail(MFTX_E_ARG, "corr_pool: feature map too large for the LDS tile");
+    static size_t attr = 0;
+    if (lds > attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(corr_pool_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr = lds;
+    }
+    hipLaunchKernelGGL(corr_pool_kernel, dim3(rows), dim3(256), lds, s, lvl0, h, w, lvl1, lvl2, lvl3);
+    return check_launch("corr_pool");
+}
+
+// ---------------------------------------------------------------------------
+// Lookup (core/corr.py:30-51, core/utils/utils.py:98-112).
+//
+// One wave per query cell.  For each of the 4 levels the 81 window samples
+// share one fractional offset, so the cell needs only the 10x10 integer taps
+// around floor(c / 2^l) - 4: the wave pulls those 400 taps (zero outside the
+// level, matching grid_sample's zero padding tap by tap) into its private LDS
+// slab, then every lane blends 4 neighbours for its output channels and writes
+// them pixel-major, 256 contiguous bytes per store.  Algorithmic traffic per
+// cell: 4*100*4 B read + 8 B coords + 324*4 B written.
+//
+// Coordinates: the reference normalises to [-1,1] and grid_sample maps back;
+// that round trip moves a coordinate by O(1e-6) px, and zero-padded bilinear
+// sampling is continuous in the coordinate, so sampling directly at
+// c/2^l + (a-4) agrees to O(1e-6 * |grad V|).
+// ---------------------------------------------------------------------------
+constexpr int LK_WAVES = 4;
+constexpr int LK_TAPS = 400;   // 4 levels x 10 x 10
+
+struct LookupArgs {
+    const float *lvl[4];
+    const float *coords;
+    float *out;
+    int ld_out;
+    int cells;      // P*h*w
+    int n_per_img;  // h*w
+    int hl[4], wl[4];
+};
+
+__global__ __launch_bounds__(64 * LK_WAVES) void corr_lookup_kernel(LookupArgs p) {
+    __shared__ float taps[LK_WAVES][LK_TAPS + 16];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    float *tp = taps[wv];
+
+    // lane-constant decode: tap slots (2 per level per lane) and output slots (6 per lane)
+    const int tr0 = lane / 10, tc0 = lane - tr0 * 10;                   // taps 0..63
+    const int tr1 = (lane + 64) / 10, tc1 = (lane + 64) - tr1 * 10;     // taps 64..99 (lanes 0..35)
+    int o_lvl[6], o_off[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int o = lane + 64 * j;
+        const int l = o / 81;
+        const int rem = o - l * 81;
+        const int a = rem / 9, b = rem - a * 9;   // a offsets x, b offsets y
+        o_lvl[j] = l;
+        o_off[j] = l * 100 + b * 10 + a;          // tap (row b, col a) of level l
+    }
+
+    for (int cell = blockIdx.x * LK_WAVES + wv; cell < p.cells; cell += gridDim.x * LK_WAVES) {
+        const float2 c = reinterpret_cast<const float2 *>(p.coords)[cell];
+        float fx[4], fy[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const float sx = c.x / (float)(1 << l), sy = c.y / (float)(1 << l);
+            const float flx = floorf(sx), fly = floorf(sy);
+            fx[l] = sx - flx; fy[l] = sy - fly;
+            // clamp so that the int conversion is defined for wild coordinates
+            const int x0 = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f) - 4;
+            const int y0 = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f) - 4;
+            const int H = p.hl[l], W = p.wl[l];
+            const float *base = p.lvl[l] + (long long)cell * H * W;
+            {
+                const int yy = y0 + tr0, xx = x0 + tc0;
+                float v = 0.f;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = base[yy * W + xx];
+                tp[l * 100 + lane] = v;
+            }
+            if (lane < 36) {
+                const int yy = y0 + tr1, xx = x0 + tc1;
+                float v = 0.f;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = base[yy * W + xx];
+                tp[l * 100 + 64 + lane] = v;
+            }
+        }
+        // LDS operations of one wave complete in issue order, so the wave can
+        // read back what its other lanes just wrote without a barrier.
+        float *dst = p.out + (long long)cell * p.ld_out;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int o = lane + 64 * j;
+            if (o < 324) {
+                const int l = o_lvl[j];
+                const float wx = (l == 0) ? fx[0] : (l == 1) ? fx[1] : (l == 2) ? fx[2] : fx[3];
+                const float wy = (l == 0) ? fy[0] : (l == 1) ? fy[1] : (l == 2) ? fy[2] : fy[3];
+                const float *t4 = tp + o_off[j];
+                const float v00 = t4[0], v01 = t4[1], v10 = t4[10], v11 = t4[11];
+                dst[o] = v00 * ((1.f - wx) * (1.f - wy)) + v01 * (wx * (1.f - wy)) +
+                         v10 * ((1.f - wx) * wy) + v11 * (wx * wy);
+            }
+        }
+    }
+}
+
+int launch_corr_lookup(const float *const lvl[4], const float *coords, int P, int h, int w, float *out,
+                       int ld_out, hipStream_t s) {
+    LookupArgs a;
+    for (int l = 0; l < 4; ++l) { a.lvl[l] = lvl[l]; a.hl[l] = h >> l; a.wl[l] = w >> l; }
+    a.coords = coords; a.out = out; a.ld_out = ld_out;
+    a.cells = P * h * w; a.n_per_img = h * w;
+    const int blocks = cdiv(a.cells, LK_WAVES);
+    hipLaunchKernelGGL(corr_lookup_kernel, dim3(blocks), dim3(64 * LK_WAVES), 0, s, a);
+    return check_launch("corr_lookup");
+}
+
+}  // namespace mftx

@@ -1,0 +1,333 @@
+// Native runtime for the RAFT refinement loop: owns the packed-weight table,
+// carves the caller's workspace, and enqueues the whole iteration sequence
+// (core/raft.py:141-226) on one HIP stream -- ~14 launches per iteration, no
+// host round trips, batched over P image pairs (M = P*h*w cells).
+#include "common.h"
+#include <new>
+
+namespace mftx {
+
+// ---------------------------------------------------------------------------
+// small glue kernels
+// ---------------------------------------------------------------------------
+
+// hx[m] = [net | inp | (motion: filled later)], coords1 = pixel grid
+// (core/raft.py:146-151; coords_grid core/utils/utils.py:115-118)
+__global__ void init_state_kernel(const float *__restrict__ net, const float *__restrict__ inp, float *hx,
+                                  float *coords1, int M, int h, int w) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over M*64 float4 slots
+    if (i >= (long long)M * 64) return;
+    const int m = (int)(i >> 6), q = (int)(i & 63);
+    const float4 v = (q < 32) ? reinterpret_cast<const float4 *>(net)[(long long)m * 32 + q]
+                              : reinterpret_cast<const float4 *>(inp)[(long long)m * 32 + (q - 32)];
+    reinterpret_cast<float4 *>(hx + (long long)m * 384)[q] = v;
+    if (q == 0) {
+        const int rem = m % (h * w);
+        coords1[2 * (long long)m] = (float)(rem % w);
+        coords1[2 * (long long)m + 1] = (float)(rem / w);
+    }
+}
+
+// convf1: 7x7 conv over the 2-channel flow (= coords1 - grid), 2 -> 128, ReLU
+// (core/update.py:147,154).  K = 98 is too thin for MFMA: direct VALU kernel,
+// one thread per output channel, 16 cells of one row per block, flow patch in LDS.
+// Also drops flow into channels 382..383 of hx (motion_features' tail,
+// core/update.py:160).
+constexpr int F1_CELLS = 16;
+__global__ __launch_bounds__(128) void convf1_kernel(const float *__restrict__ coords1,
+                                                     const float *__restrict__ w98,   // [98][128]
+                                                     const float *__restrict__ bias, float *__restrict__ flo1,
+                                                     float *__restrict__ hx, int h, int w, int strips_per_row) {
+    __shared__ float patch[7][F1_CELLS + 6][2];
+    const int strip = blockIdx.x % strips_per_row;
+    const int rowid = blockIdx.x / strips_per_row;   // img*h + y
+    const int y = rowid % h;
+    const long long img_base = (long long)(rowid / h) * h * w;
+    const int x0 = strip * F1_CELLS;
+    for (int i = threadIdx.x; i < 7 * (F1_CELLS + 6); i += blockDim.x) {
+        const int r = i / (F1_CELLS + 6), c = i - r * (F1_CELLS + 6);
+        const int yy = y + r - 3, xx = x0 + c - 3;
+        float fx = 0.f, fy = 0.f;
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+            const long long cell = img_base + (long long)yy * w + xx;
+            fx = coords1[2 * cell] - (float)xx;
+            fy = coords1[2 * cell + 1] - (float)yy;
+        }
+        patch[r][c][0] = fx;
+        patch[r][c][1] = fy;
+    }
+    __syncthreads();
+    const int co = threadIdx.x;
+    float acc[F1_CELLS];
+    const float b = bias[co];
+#pragma unroll
+    for (int t = 0; t < F1_CELLS; ++t) acc[t] = b;
+    for (int ky = 0; ky < 7; ++ky)
+        for (int kx = 0; kx < 7; ++kx) {
+            const float w0 = w98[((ky * 7 + kx) * 2 + 0) * 128 + co];
+            const float w1 = w98[((ky * 7 + kx) * 2 + 1) * 128 + co];
+#pragma unroll
+            for (int t = 0; t < F1_CELLS; ++t)
+                acc[t] += w0 * patch[ky][t + kx][0] + w1 * patch[ky][t + kx][1];
+        }
+#pragma unroll
+    for (int t = 0; t < F1_CELLS; ++t) {
+        const int x = x0 + t;
+        if (x < w) {
+            const long long cell = img_base + (long long)y * w + x;
+            flo1[cell * 128 + co] = fmaxf(acc[t], 0.f);
+            if (co < 2) hx[cell * 384 + 382 + co] = patch[3][t + 3][co];
+        }
+    }
+}
+
+// coords1 += delta_flow (core/raft.py:184)
+__global__ void add_delta_kernel(float *coords1, const float *__restrict__ delta, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) coords1[i] += delta[i];
+}
+
+// OU input [net128 | inp128 | corr324 | flow2 | delta2 | motion128] = 712
+// (core/update.py:197), flow = coords1 - grid AFTER the last update
+// (core/raft.py:199-206); also emits flow_lr for the upsampler.
+__global__ void ou_gather_kernel(const float *__restrict__ hx, const float *__restrict__ corr,
+                                 const float *__restrict__ coords1, const float *__restrict__ delta,
+                                 float *__restrict__ ouin, float *__restrict__ flow_lr, int M, int h, int w) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over M*178 float4 slots
+    if (i >= (long long)M * 178) return;
+    const int m = (int)(i / 178), q = (int)(i - (long long)m * 178);
+    float4 v;
+    if (q < 64) v = reinterpret_cast<const float4 *>(hx + (long long)m * 384)[q];                 // net, inp
+    else if (q < 145) v = reinterpret_cast<const float4 *>(corr + (long long)m * 324)[q - 64];    // corr
+    else if (q == 145) {
+        const int rem = m % (h * w);
+        const float fx = coords1[2 * (long long)m] - (float)(rem % w);
+        const float fy = coords1[2 * (long long)m + 1] - (float)(rem / w);
+        v = make_float4(fx, fy, delta[2 * (long long)m], delta[2 * (long long)m + 1]);
+        flow_lr[2 * (long long)m] = fx;
+        flow_lr[2 * (long long)m + 1] = fy;
+    } else v = reinterpret_cast<const float4 *>(hx + (long long)m * 384 + 256)[q - 146];         // motion
+    reinterpret_cast<float4 *>(ouin + (long long)m * 712)[q] = v;
+}
+
+// ---------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------
+enum WeightSlot {
+    W_CONVC1, B_CONVC1, W_CONVC2, B_CONVC2, W_CONVF1, B_CONVF1, W_CONVF2, B_CONVF2, W_CONV, B_CONV,
+    W_ZR1, B_ZR1, W_Q1, B_Q1, W_ZR2, B_ZR2, W_Q2, B_Q2,
+    W_FH1, B_FH1, W_FH2, B_FH2, W_MASK0, B_MASK0, W_MASK2, B_MASK2,
+    W_OU1, B_OU1, W_OU2, B_OU2, W_COUNT
+};
+
+struct Workspace {
+    float *lvl[4];
+    float *coords1, *corr, *cor1, *corflo, *flo1, *hx, *z, *rh, *fh, *delta, *mask, *ouin, *ouh, *ou, *flow_lr;
+    size_t bytes;
+};
+
+static Workspace carve(void *base, int P, int h, int w) {
+    Workspace ws{};
+    const size_t N = (size_t)h * w, M = (size_t)P * N;
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        float *p = base ? reinterpret_cast<float *>(static_cast<char *>(base) + off) : nullptr;
+        off += (floats * sizeof(float) + 255) & ~size_t(255);
+        return p;
+    };
+    for (int l = 0; l < 4; ++l) ws.lvl[l] = take(M * (size_t)(h >> l) * (size_t)(w >> l));
+    ws.coords1 = take(M * 2);
+    ws.corr = take(M * 324);
+    ws.cor1 = take(M * 256);
+    ws.corflo = take(M * 256);
+    ws.flo1 = take(M * 128);
+    ws.hx = take(M * 384);
+    ws.z = take(M * 128);
+    ws.rh = take(M * 128);
+    ws.fh = take(M * 256);
+    ws.delta = take(M * 2);
+    ws.mask = take(M * 576);
+    ws.ouin = take(M * 712);
+    ws.ouh = take(M * 256);
+    ws.ou = take(M * 4);
+    ws.flow_lr = take(M * 2);
+    ws.bytes = off;
+    return ws;
+}
+
+}  // namespace mftx
+
+using namespace mftx;
+
+struct mftx_raft {
+    uint32_t magic;
+    const float *w[W_COUNT];
+};
+static constexpr uint32_t RAFT_MAGIC = 0x4d465458;  // "MFTX"
+
+extern "C" int mftx_raft_create(const float *const *weights, int n_weights, mftx_raft **out) {
+    if (!weights || !out) return fail(MFTX_E_ARG, "raft_create: null pointer");
+    if (n_weights != W_COUNT) return fail(MFTX_E_ARG, "raft_create: expected %d weight tensors, got %d", (int)W_COUNT, n_weights);
+    for (int i = 0; i < W_COUNT; ++i) {
+        if (!weights[i]) return fail(MFTX_E_ARG, "raft_create: weight %d is null", i);
+        if (!aligned16(weights[i])) return fail(MFTX_E_ALIGN, "raft_create: weight %d not 16-byte aligned", i);
+    }
+    mftx_raft *r = new (std::nothrow) mftx_raft;
+    if (!r) return fail(MFTX_E_ARG, "raft_create: out of host memory");
+    r->magic = RAFT_MAGIC;
+    for (int i = 0; i < W_COUNT; ++i) r->w[i] = weights[i];
+    *out = r;
+    return 0;
+}
+
+extern "C" void mftx_raft_destroy(mftx_raft *r) {
+    if (r && r->magic == RAFT_MAGIC) { r->magic = 0; delete r; }
+}
+
+extern "C" size_t mftx_raft_workspace_bytes(int P, int h, int w) {
+    if (P <= 0 || h <= 0 || w <= 0) return 0;
+    return carve(nullptr, P, h, w).bytes;
+}
+
+// Byte offsets of the workspace regions, in the order lvl0..3, coords1, corr,
+// cor1, corflo, flo1, hx, z, rh, fh, delta, mask, ouin, ouh, ou, flow_lr -- lets
+// the parity tests inspect the intermediates of the last iteration.
+extern "C" int mftx_raft_workspace_layout(int P, int h, int w, size_t *offsets, int n) {
+    if (P <= 0 || h <= 0 || w <= 0 || !offsets || n != 19) return fail(MFTX_E_ARG, "workspace_layout: need 19 slots");
+    char *base = reinterpret_cast<char *>(uintptr_t(1) << 40);
+    Workspace ws = carve(base, P, h, w);
+    float *ptrs[19] = {ws.lvl[0], ws.lvl[1], ws.lvl[2], ws.lvl[3], ws.coords1, ws.corr, ws.cor1, ws.corflo, ws.flo1,
+                       ws.hx, ws.z, ws.rh, ws.fh, ws.delta, ws.mask, ws.ouin, ws.ouh, ws.ou, ws.flow_lr};
+    for (int i = 0; i < 19; ++i) offsets[i] = (size_t)(reinterpret_cast<char *>(ptrs[i]) - base);
+    return 0;
+}
+
+#define TRY(expr) do { int _e = (expr); if (_e) return _e; } while (0)
+
+static mftx_conv_desc conv_desc(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
+                                const float *w, const float *b, float *out, int ldo, int P, int h, int wd, int N,
+                                int kh, int kw, int act, float scale = 1.f) {
+    mftx_conv_desc d{};
+    d.a0 = a0; d.lda0 = lda0; d.c0 = c0; d.a1 = a1; d.lda1 = lda1; d.c1 = c1;
+    d.wpk = w; d.bias = b; d.out = out; d.ldo = ldo; d.P = P; d.h = h; d.w = wd; d.N = N;
+    d.kh = kh; d.kw = kw; d.act = act; d.out_scale = scale;
+    return d;
+}
+
+extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, const float *fmap1,
+                                const float *fmap2, const float *net, const float *inp, int pad_left,
+                                int pad_right, int pad_top, int pad_bottom, float *flow, float *occl,
+                                float *sigma, float *flow_lr_out, void *workspace, size_t workspace_bytes,
+                                void *stream) {
+    if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_refine: bad handle");
+    if (!fmap1 || !fmap2 || !net || !inp || !flow || !occl || !sigma || !workspace)
+        return fail(MFTX_E_ARG, "raft_refine: null pointer");
+    if (P <= 0 || h < 16 || w < 16 || iters < 1)
+        return fail(MFTX_E_ARG, "raft_refine: need P >= 1, h, w >= 16 (level 3 of the pyramid needs >= 2 cells), iters >= 1");
+    if ((long long)P * h * w > (1ll << 24)) return fail(MFTX_E_ARG, "raft_refine: batch too large");
+    if (!aligned16(fmap1) || !aligned16(fmap2) || !aligned16(net) || !aligned16(inp) ||
+        (reinterpret_cast<uintptr_t>(workspace) & 255))
+        return fail(MFTX_E_ALIGN, "raft_refine: inputs must be 16-byte and the workspace 256-byte aligned");
+    if (pad_left < 0 || pad_right < 0 || pad_top < 0 || pad_bottom < 0 || pad_left + pad_right >= 8 ||
+        pad_top + pad_bottom >= 8)
+        return fail(MFTX_E_ARG, "raft_refine: bad padding");
+    Workspace ws = carve(workspace, P, h, w);
+    if (ws.bytes > workspace_bytes)
+        return fail(MFTX_E_WORKSPACE, "raft_refine: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const int N = h * w, M = P * N;
+    const float *const *W = r->w;
+
+    // correlation volume + pyramid (core/corr.py:14-28)
+    TRY(launch_corr_volume(fmap1, fmap2, P, 256, N, ws.lvl[0], s));
+    TRY(launch_corr_pool(ws.lvl[0], M, h, w, ws.lvl[1], ws.lvl[2], ws.lvl[3], s));
+    {
+        const long long slots = (long long)M * 64;
+        hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, net, inp,
+                           ws.hx, ws.coords1, M, h, w);
+        TRY(check_launch("init_state"));
+    }
+    const float *lv[4] = {ws.lvl[0], ws.lvl[1], ws.lvl[2], ws.lvl[3]};
+    const int strips = cdiv(w, F1_CELLS);
+    for (int it = 0; it < iters; ++it) {
+        const bool last = (it == iters - 1);
+        TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, 324, s));
+        // motion encoder (core/update.py:152-160)
+        TRY(launch_conv(conv_desc(ws.corr, 324, 324, nullptr, 0, 0, W[W_CONVC1], W[B_CONVC1], ws.cor1, 256, P, h, w, 256, 1, 1, 1), s));
+        TRY(launch_conv(conv_desc(ws.cor1, 256, 256, nullptr, 0, 0, W[W_CONVC2], W[B_CONVC2], ws.corflo, 256, P, h, w, 192, 3, 3, 1), s));
+        hipLaunchKernelGGL(convf1_kernel, dim3(P * h * strips), dim3(128), 0, s, ws.coords1, W[W_CONVF1],
+                           W[B_CONVF1], ws.flo1, ws.hx, h, w, strips);
+        TRY(check_launch("convf1"));
+        TRY(launch_conv(conv_desc(ws.flo1, 128, 128, nullptr, 0, 0, W[W_CONVF2], W[B_CONVF2], ws.corflo + 192, 256, P, h, w, 64, 3, 3, 1), s));
+        TRY(launch_conv(conv_desc(ws.corflo, 256, 256, nullptr, 0, 0, W[W_CONV], W[B_CONV], ws.hx + 256, 384, P, h, w, 126, 3, 3, 1), s));
+        // SepConvGRU (core/update.py:108-123): horizontal 1x5 then vertical 5x1
+        for (int pass = 0; pass < 2; ++pass) {
+            const int kh = pass ? 5 : 1, kw = pass ? 1 : 5;
+            GruEpilogue g1{1, ws.hx, 384, ws.z, ws.rh};
+            TRY(launch_conv_gru(conv_desc(ws.hx, 384, 384, nullptr, 0, 0, W[pass ? W_ZR2 : W_ZR1], W[pass ? B_ZR2 : B_ZR1], ws.z, 128, P, h, w, 256, kh, kw, 2), g1, s));
+            GruEpilogue g2{2, ws.hx, 384, ws.z, ws.rh};
+            TRY(launch_conv_gru(conv_desc(ws.rh, 128, 128, ws.hx + 128, 384, 256, W[pass ? W_Q2 : W_Q1], W[pass ? B_Q2 : B_Q1], ws.hx, 384, P, h, w, 128, kh, kw, 3), g2, s));
+        }
+        // flow head (core/update.py:6-14) and coordinate update (core/raft.py:184)
+        TRY(launch_conv(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, W[W_FH1], W[B_FH1], ws.fh, 256, P, h, w, 256, 3, 3, 1), s));
+        TRY(launch_conv(conv_desc(ws.fh, 256, 256, nullptr, 0, 0, W[W_FH2], W[B_FH2], ws.delta, 2, P, h, w, 2, 3, 3, 0), s));
+        hipLaunchKernelGGL(add_delta_kernel, dim3((unsigned)((2ll * M + 255) / 256)), dim3(256), 0, s, ws.coords1,
+                           ws.delta, 2ll * M);
+        TRY(check_launch("add_delta"));
+        if (!last) continue;
+        // The upsampling mask is consumed only after the last iteration in test
+        // mode (core/raft.py:190-196,234-239), so it is computed once.
+        TRY(launch_conv(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, W[W_MASK0], W[B_MASK0], ws.fh, 256, P, h, w, 256, 3, 3, 1), s));
+        TRY(launch_conv(conv_desc(ws.fh, 256, 256, nullptr, 0, 0, W[W_MASK2], W[B_MASK2], ws.mask, 576, P, h, w, 576, 1, 1, 0, 0.25f), s));
+        // occlusion + uncertainty heads (core/update.py:196-214)
+        float *flow_lr = flow_lr_out ? flow_lr_out : ws.flow_lr;
+        {
+            const long long slots = (long long)M * 178;
+            hipLaunchKernelGGL(ou_gather_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, ws.hx,
+                               ws.corr, ws.coords1, ws.delta, ws.ouin, flow_lr, M, h, w);
+            TRY(check_launch("ou_gather"));
+        }
+        TRY(launch_conv(conv_desc(ws.ouin, 712, 712, nullptr, 0, 0, W[W_OU1], W[B_OU1], ws.ouh, 256, P, h, w, 256, 3, 3, 1), s));
+        TRY(launch_conv(conv_desc(ws.ouh, 256, 256, nullptr, 0, 0, W[W_OU2], W[B_OU2], ws.ou, 4, P, h, w, 3, 3, 3, 0), s));
+        TRY(launch_convex_upsample(flow_lr, ws.ou, 4, ws.mask, P, h, w, pad_left, pad_right, pad_top, pad_bottom,
+                                   flow, occl, sigma, s));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// per-op exports
+// ---------------------------------------------------------------------------
+extern "C" int mftx_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, int w, float *lvl0,
+                                 float *lvl1, float *lvl2, float *lvl3, void *stream) {
+    if (!f1 || !f2 || !lvl0 || !lvl1 || !lvl2 || !lvl3) return fail(MFTX_E_ARG, "corr_pyramid: null pointer");
+    if (P <= 0 || C <= 0 || C % 32 || h < 8 || w < 8) return fail(MFTX_E_ARG, "corr_pyramid: need C %% 32 == 0, h, w >= 8");
+    if (!aligned16(f1) || !aligned16(f2)) return fail(MFTX_E_ALIGN, "corr_pyramid: features must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    TRY(launch_corr_volume(f1, f2, P, C, h * w, lvl0, s));
+    return launch_corr_pool(lvl0, P * h * w, h, w, lvl1, lvl2, lvl3, s);
+}
+
+extern "C" int mftx_corr_lookup(const float *lvl0, const float *lvl1, const float *lvl2, const float *lvl3,
+                                const float *coords, int P, int h, int w, int r, float *out, int ld_out,
+                                void *stream) {
+    if (!lvl0 || !lvl1 || !lvl2 || !lvl3 || !coords || !out) return fail(MFTX_E_ARG, "corr_lookup: null pointer");
+    if (r != 4) return fail(MFTX_E_ARG, "corr_lookup: only radius 4 (RAFT basic) is built");
+    if (P <= 0 || h < 8 || w < 8 || ld_out < 324) return fail(MFTX_E_ARG, "corr_lookup: bad sizes");
+    const float *lv[4] = {lvl0, lvl1, lvl2, lvl3};
+    return launch_corr_lookup(lv, coords, P, h, w, out, ld_out, (hipStream_t)stream);
+}
+
+extern "C" int mftx_conv2d(const mftx_conv_desc *d, void *stream) {
+    if (!d) return fail(MFTX_E_ARG, "conv2d: null descriptor");
+    return launch_conv(*d, (hipStream_t)stream);
+}
+
+extern "C" int mftx_convex_upsample(const float *flow_lr, const float *ou, int ld_ou, const float *mask, int P,
+                                    int h, int w, int pad_left, int pad_right, int pad_top, int pad_bottom,
+                                    float *flow, float *occl, float *sigma, void *stream) {
+    if (!flow_lr || !ou || !mask || !flow || !occl || !sigma) return fail(MFTX_E_ARG, "convex_upsample: null pointer");
+    if (P <= 0 || h <= 0 || w <= 0 || ld_ou < 3) return fail(MFTX_E_ARG, "convex_upsample: bad sizes");
+    return launch_convex_upsample(flow_lr, ou, ld_ou, mask, P, h, w, pad_left, pad_right, pad_top, pad_bottom, flow,
+                                  occl, sigma, (hipStream_t)stream);
+}

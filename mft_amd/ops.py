@@ -1,0 +1,274 @@
+"""Torch-tensor front end of the C ABI (device memory + streams are PyTorch's;
+all arithmetic happens in libmftx's HIP kernels).
+
+Every function checks device / dtype / contiguity, passes raw device pointers
+and the current HIP stream, and raises ``MftxError`` on a non-zero return --
+same contract as the reference's one native op
+(``MFT/RAFT/alt_cuda_corr/correlation.cpp:19-33``: CHECK_CUDA, CHECK_CONTIGUOUS,
+RuntimeError).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, MftxError, check
+
+ACT = {None: 0, "none": 0, "relu": 1, "sigmoid": 2, "tanh": 3}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise MftxError(f"{name} must be a CUDA(HIP) tensor")
+    if t.dtype != dtype:
+        raise MftxError(f"{name} must be {dtype}")
+    if not t.is_contiguous():
+        raise MftxError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+# ---------------------------------------------------------------------------
+# weight packing (host plumbing, once per checkpoint)
+# ---------------------------------------------------------------------------
+
+def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, kh, kw] -> [round_up(Cout,128), kh*kw, round_up(Cin,32)], zero
+    padded: the K axis (tap, cin) is contiguous per output channel, which is what
+    the NT implicit-GEMM kernel streams (csrc/conv_gemm.hip)."""
+    cout, cin, kh, kw = w.shape
+    n_pad = -(-cout // 128) * 128
+    c_pad = -(-cin // 32) * 32
+    out = torch.zeros(n_pad, kh * kw, c_pad, dtype=torch.float32, device=w.device)
+    out[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+    return out.contiguous()
+
+
+def pack_raft_weights(sd: dict, device) -> list:
+    """The 30 tensors ``mftx_raft_create`` expects, in WeightSlot order
+    (csrc/raft_engine.hip).  z|r gates and the two OU heads are fused into single
+    GEMMs by stacking / block-placing their weights (exact: the extra terms are
+    multiplications by zero weights)."""
+    g = lambda k: sd[k].to(device=device, dtype=torch.float32)  # noqa: E731
+    u, o = "update_block.", "occlusion_block."
+    out = []
+
+    def conv(name):
+        out.append(pack_conv_weight(g(name + ".weight")))
+        out.append(g(name + ".bias").contiguous())
+
+    conv(u + "encoder.convc1")
+    conv(u + "encoder.convc2")
+    # convf1: [128, 2, 7, 7] -> [(ky, kx, c), co] for the direct kernel
+    out.append(g(u + "encoder.convf1.weight").permute(2, 3, 1, 0).reshape(98, 128).contiguous())
+    out.append(g(u + "encoder.convf1.bias").contiguous())
+    conv(u + "encoder.convf2")
+    conv(u + "encoder.conv")
+    for sfx in ("1", "2"):
+        wz, wr = g(u + f"gru.convz{sfx}.weight"), g(u + f"gru.convr{sfx}.weight")
+        out.append(pack_conv_weight(torch.cat([wz, wr], 0)))
+        out.append(torch.cat([g(u + f"gru.convz{sfx}.bias"), g(u + f"gru.convr{sfx}.bias")]).contiguous())
+        conv(u + f"gru.convq{sfx}")
+    conv(u + "flow_head.conv1")
+    conv(u + "flow_head.conv2")
+    conv(u + "mask.0")
+    conv(u + "mask.2")
+    w1 = torch.cat([g(o + "occl_head.conv1.weight"), g(o + "uncertainty_head.conv1.weight")], 0)
+    out.append(pack_conv_weight(w1))
+    out.append(torch.cat([g(o + "occl_head.conv1.bias"), g(o + "uncertainty_head.conv1.bias")]).contiguous())
+    w2 = torch.zeros(3, 256, 3, 3, dtype=torch.float32, device=device)
+    w2[0:2, 0:128] = g(o + "occl_head.conv2.weight")
+    w2[2:3, 128:256] = g(o + "uncertainty_head.conv2.weight")
+    out.append(pack_conv_weight(w2))
+    out.append(torch.cat([g(o + "occl_head.conv2.bias"), g(o + "uncertainty_head.conv2.bias")]).contiguous())
+    assert len(out) == _lib.NUM_RAFT_WEIGHTS
+    return out
+
+
+# ---------------------------------------------------------------------------
+# per-op wrappers
+# ---------------------------------------------------------------------------
+
+def corr_pyramid(f1: torch.Tensor, f2: torch.Tensor, h: int, w: int):
+    """f1, f2: pixel-major [P, h*w, C] -> 4 levels [P, h*w, (h>>l)*(w>>l)]."""
+    lib = _lib.load()
+    P, N, Cc = f1.shape
+    assert N == h * w and f2.shape == f1.shape
+    lv = [torch.empty(P, N, (h >> l) * (w >> l), dtype=torch.float32, device=f1.device) for l in range(4)]
+    check(lib.mftx_corr_pyramid(_chk(f1, "f1"), _chk(f2, "f2"), P, Cc, h, w,
+                                *[t.data_ptr() for t in lv], _stream()), "mftx_corr_pyramid")
+    return lv
+
+
+def corr_lookup(lv, coords: torch.Tensor, h: int, w: int, r: int = 4):
+    """coords pixel-major [P, h*w, 2] (x, y) -> [P, h*w, 324]."""
+    lib = _lib.load()
+    P = coords.shape[0]
+    out = torch.empty(P, h * w, 324, dtype=torch.float32, device=coords.device)
+    check(lib.mftx_corr_lookup(*[_chk(t, "level") for t in lv], _chk(coords, "coords"), P, h, w, r,
+                               out.data_ptr(), 324, _stream()), "mftx_corr_lookup")
+    return out
+
+
+def conv2d(x: torch.Tensor, wpk: torch.Tensor, bias, P, h, w, N, kh, kw, act=None, out_scale=1.0, x2=None):
+    """x: pixel-major [P*h*w, C0] (optionally concatenated with x2 [P*h*w, C1]) ->
+    [P*h*w, N]."""
+    lib = _lib.load()
+    out = torch.empty(P * h * w, N, dtype=torch.float32, device=x.device)
+    d = ConvDesc()
+    d.a0, d.lda0, d.c0 = _chk(x, "x"), x.shape[1], x.shape[1]
+    if x2 is not None:
+        d.a1, d.lda1, d.c1 = _chk(x2, "x2"), x2.shape[1], x2.shape[1]
+    else:
+        d.a1, d.lda1, d.c1 = None, 0, 0
+    d.wpk = _chk(wpk, "wpk")
+    d.bias = _chk(bias, "bias") if bias is not None else None
+    d.out, d.ldo = out.data_ptr(), N
+    d.P, d.h, d.w, d.N, d.kh, d.kw = P, h, w, N, kh, kw
+    d.act, d.out_scale = ACT[act], out_scale
+    check(lib.mftx_conv2d(C.byref(d), _stream()), "mftx_conv2d")
+    return out
+
+
+def convex_upsample(flow_lr, ou, mask, P, h, w, pads=(0, 0, 0, 0)):
+    """flow_lr [M,2], ou [M,ld>=3], mask [M,576] -> flow [P,2,H0,W0], occl, sigma [P,1,H0,W0]."""
+    lib = _lib.load()
+    pl, pr, pt, pb = pads
+    H0, W0 = 8 * h - pt - pb, 8 * w - pl - pr
+    dev = flow_lr.device
+    flow = torch.empty(P, 2, H0, W0, dtype=torch.float32, device=dev)
+    occl = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev)
+    sigma = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev)
+    check(lib.mftx_convex_upsample(_chk(flow_lr, "flow_lr"), _chk(ou, "ou"), ou.shape[1], _chk(mask, "mask"),
+                                   P, h, w, pl, pr, pt, pb, flow.data_ptr(), occl.data_ptr(), sigma.data_ptr(),
+                                   _stream()), "mftx_convex_upsample")
+    return flow, occl, sigma
+
+
+def _planes(res, H, W):
+    flow, occl, sigma = res
+    if flow.shape != (2, H, W) or occl.shape != (1, H, W) or sigma.shape != (1, H, W):
+        raise MftxError("FlowOU planes must be [2,H,W], [1,H,W], [1,H,W]")
+    return _chk(flow, "flow"), _chk(occl, "occlusion"), _chk(sigma, "sigma")
+
+
+def _new_result(H, W, device):
+    return (torch.empty(2, H, W, dtype=torch.float32, device=device),
+            torch.empty(1, H, W, dtype=torch.float32, device=device),
+            torch.empty(1, H, W, dtype=torch.float32, device=device))
+
+
+def chain(L, R):
+    """chain_results: L, R = (flow[2,H,W], occl[1,H,W], sigma[1,H,W]) -> same triple."""
+    lib = _lib.load()
+    _, H, W = L[0].shape
+    out = _new_result(H, W, L[0].device)
+    check(lib.mftx_chain(*_planes(L, H, W), *_planes(R, H, W), H, W, *[t.data_ptr() for t in out], _stream()),
+          "mftx_chain")
+    return out
+
+
+def warp_backward(flow, img):
+    """flow [2,H,W], img [C,H,W] -> img sampled at grid + flow, [C,H,W]."""
+    lib = _lib.load()
+    Cc, H, W = img.shape
+    if flow.shape != (2, H, W):
+        raise MftxError("warp_backward: flow must be [2,H,W] matching img")
+    out = torch.empty_like(img)
+    check(lib.mftx_warp_backward(_chk(flow, "flow"), _chk(img, "img"), Cc, H, W, out.data_ptr(), _stream()),
+          "mftx_warp_backward")
+    return out
+
+
+def select(cands, thr, want_chosen=False):
+    """cands: list of chained triples ordered [inf, 1, 2, ...]."""
+    lib = _lib.load()
+    K = len(cands)
+    _, H, W = cands[0][0].shape
+    cols = list(zip(*[_planes(c, H, W) for c in cands]))
+    arrs = [_lib.ptr_array(list(c)) for c in cols]
+    out = _new_result(H, W, cands[0][0].device)
+    chosen = torch.empty(H, W, dtype=torch.int8, device=out[0].device) if want_chosen else None
+    check(lib.mftx_select(K, arrs[0][0], arrs[1][0], arrs[2][0], float(thr), H, W, *[t.data_ptr() for t in out],
+                          chosen.data_ptr() if want_chosen else None, _stream()), "mftx_select")
+    return out + (chosen,)
+
+
+def chain_select(Ls, Rs, thr, want_chosen=False):
+    """Fused chain + select over K (L, R) pairs ordered [inf, 1, 2, ...]."""
+    lib = _lib.load()
+    K = len(Ls)
+    assert len(Rs) == K
+    _, H, W = Ls[0][0].shape
+    lcols = list(zip(*[_planes(c, H, W) for c in Ls]))
+    rcols = list(zip(*[_planes(c, H, W) for c in Rs]))
+    arrs = [_lib.ptr_array(list(c)) for c in lcols + rcols]
+    out = _new_result(H, W, Ls[0][0].device)
+    chosen = torch.empty(H, W, dtype=torch.int8, device=out[0].device) if want_chosen else None
+    check(lib.mftx_chain_select(K, *[a[0] for a in arrs], float(thr), H, W, *[t.data_ptr() for t in out],
+                                chosen.data_ptr() if want_chosen else None, _stream()), "mftx_chain_select")
+    return out + (chosen,)
+
+
+class RaftEngine:
+    """Handle on the native refinement runtime (``mftx_raft_*``)."""
+
+    def __init__(self, state_dict: dict, device):
+        lib = _lib.load()
+        self.device = torch.device(device)
+        self.weights = pack_raft_weights(state_dict, self.device)   # keep alive: the engine holds raw pointers
+        arr, self._keep = _lib.ptr_array([_chk(t, "weight") for t in self.weights])
+        handle = C.c_void_p()
+        check(lib.mftx_raft_create(arr, len(self.weights), C.byref(handle)), "mftx_raft_create")
+        self._h = handle
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.load().mftx_raft_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def workspace(self, P, h, w):
+        need = _lib.load().mftx_raft_workspace_bytes(P, h, w)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    REGIONS = ("lvl0", "lvl1", "lvl2", "lvl3", "coords1", "corr", "cor1", "corflo", "flo1", "hx", "z", "rh", "fh",
+               "delta", "mask", "ouin", "ouh", "ou", "flow_lr")
+
+    def region(self, name, P, h, w, cols):
+        """View of a workspace region as [P*h*w, cols] fp32 (parity tests)."""
+        offs = (C.c_size_t * 19)()
+        check(_lib.load().mftx_raft_workspace_layout(P, h, w, offs, 19), "mftx_raft_workspace_layout")
+        off = offs[self.REGIONS.index(name)]
+        n = P * h * w * cols
+        return self._ws[off: off + 4 * n].view(torch.float32).reshape(P * h * w, cols)
+
+    def refine(self, fmap1, fmap2, net, inp, h, w, iters, pads=(0, 0, 0, 0), want_flow_lr=False):
+        """fmap1/fmap2 [P, h*w, 256], net/inp [P, h*w, 128] pixel-major ->
+        flow [P,2,H0,W0], occl [P,1,H0,W0], sigma [P,1,H0,W0] (+ flow_lr [P,h*w,2])."""
+        lib = _lib.load()
+        P = fmap1.shape[0]
+        pl, pr, pt, pb = pads
+        H0, W0 = 8 * h - pt - pb, 8 * w - pl - pr
+        dev = self.device
+        flow = torch.empty(P, 2, H0, W0, dtype=torch.float32, device=dev)
+        occl = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev)
+        sigma = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev)
+        flow_lr = torch.empty(P, h * w, 2, dtype=torch.float32, device=dev) if want_flow_lr else None
+        ws = self.workspace(P, h, w)
+        check(lib.mftx_raft_refine(self._h, P, h, w, iters, _chk(fmap1, "fmap1"), _chk(fmap2, "fmap2"),
+                                   _chk(net, "net"), _chk(inp, "inp"), pl, pr, pt, pb,
+                                   flow.data_ptr(), occl.data_ptr(), sigma.data_ptr(),
+                                   flow_lr.data_ptr() if want_flow_lr else None,
+                                   ws.data_ptr(), ws.numel(), _stream()), "mftx_raft_refine")
+        return (flow, occl, sigma, flow_lr) if want_flow_lr else (flow, occl, sigma)

@@ -1,0 +1,154 @@
+"""FlowOUTrackingResult -- drop-in for ``MFT/results.py:11-265``.
+
+Same constructor (with the reference's assertions), same attributes
+(``flow [2,H,W]``, ``occlusion [1,H,W]``, ``sigma [1,H,W]``, ``H``, ``W``) and
+the same public methods.  On device tensors ``chain`` / ``warp_backward`` run
+on libmftx's HIP kernels (one fused launch instead of three ``grid_sample``
+pipelines); the host-side, few-hundred-point helpers (``sample``,
+``warp_forward_points``) stay torch plumbing.
+"""
+from __future__ import annotations
+
+import pickle
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _grid(H, W, device):
+    """x,y pixel grid [2,H,W] (MFT/utils/geom_utils.py:429-452)."""
+    idx = torch.arange(H * W, device=device)
+    return torch.stack([idx % W, torch.div(idx, W, rounding_mode="floor")], 0).reshape(2, H, W).to(torch.float32)
+
+
+def _normalize_coords(coords, H, W):
+    """(N H W xy) pixel coords -> [-1,1] (MFT/utils/interpolation.py:63-73)."""
+    scales = torch.from_numpy(np.array([2 / (W - 1), 2 / (H - 1)]).astype(np.float32)).to(coords.device)
+    return coords * scales.reshape(1, 1, 1, 2) - 1
+
+
+class FlowOUTrackingResult(object):
+    def __init__(self, flow, occlusion=None, sigma=None, validate=True):
+        """Stores optical flow, occlusion map and flow sigma map.
+
+        flow: (xy-delta, H, W) tensor; occlusion, sigma: (1, H, W) tensors.
+        ``validate=False`` skips the three range assertions (each is a host
+        sync); the tracker uses it for tensors its own kernels just produced.
+        """
+        assert len(flow.shape) == 3
+        assert flow.shape[0] == 2
+        self.H, self.W = flow.shape[1:]
+        if occlusion is None:
+            occlusion = torch.zeros((1, self.H, self.W), dtype=torch.float32)
+        if sigma is None:
+            sigma = torch.zeros((1, self.H, self.W), dtype=torch.float32)
+
+        assert flow.shape == (2, self.H, self.W)
+        assert occlusion.shape == (1, self.H, self.W)
+        assert sigma.shape == (1, self.H, self.W)
+
+        if validate:
+            assert torch.all(occlusion >= 0)
+            assert torch.all(occlusion <= 1.000001)
+            assert torch.all(sigma >= 0)
+
+        self.flow = flow
+        self.occlusion = occlusion
+        self.sigma = sigma
+
+    def __repr__(self):
+        return f'<{self.__class__.__name__} ({self.H} x {self.W}) has flow, occlusion, sigma>'
+
+    # ---- placement -------------------------------------------------------
+    def cpu(self):
+        self.flow, self.occlusion, self.sigma = self.flow.cpu(), self.occlusion.cpu(), self.sigma.cpu()
+        return self
+
+    def cuda(self):
+        self.flow, self.occlusion, self.sigma = self.flow.cuda(), self.occlusion.cuda(), self.sigma.cuda()
+        return self
+
+    def clone(self):
+        return FlowOUTrackingResult(self.flow.clone(), self.occlusion.clone(), self.sigma.clone(), validate=False)
+
+    def planes(self):
+        return self.flow, self.occlusion, self.sigma
+
+    # ---- IO (plain pickle of the three arrays; the reference's .flowouX16
+    # codec, MFT/utils/io.py:495-563, is outside this tier's scope) ---------
+    def write(self, path):
+        with open(path, "wb") as f:
+            pickle.dump({k: getattr(self, k).detach().cpu().numpy() for k in ("flow", "occlusion", "sigma")}, f)
+
+    @classmethod
+    def read(cls, path):
+        with open(path, "rb") as f:
+            d = pickle.load(f)
+        return FlowOUTrackingResult(torch.from_numpy(d["flow"]), torch.from_numpy(d["occlusion"]),
+                                    torch.from_numpy(d["sigma"]))
+
+    @classmethod
+    def identity(cls, flow_shape, device=None):
+        """Zero-flow, zero-sigma, zero-occlusion result; flow_shape = (H, W)."""
+        H, W = flow_shape
+        return FlowOUTrackingResult(torch.zeros((2, H, W), dtype=torch.float32, device=device),
+                                    torch.zeros((1, H, W), dtype=torch.float32, device=device),
+                                    torch.zeros((1, H, W), dtype=torch.float32, device=device), validate=False)
+
+    # ---- chaining (hot path) ---------------------------------------------
+    def chain(self, flow):
+        """With self.flow A->B and ``flow`` B->C, the flow A->C by bilinear
+        interpolation (MFT/results.py:87-114)."""
+        assert flow.shape == (2, self.H, self.W)
+        flow = flow.to(torch.float32).contiguous()
+        zeros = torch.zeros((1, self.H, self.W), dtype=torch.float32, device=flow.device)
+        out = ops.chain((self.flow.to(flow.device).to(torch.float32).contiguous(), zeros, zeros),
+                        (flow, zeros, zeros))
+        return out[0]
+
+    def warp_backward(self, img):
+        """Sample img (C,H,W) at the right end of self.flow (MFT/results.py:116-136)."""
+        assert len(img.shape) == 3
+        assert img.shape[1:] == (self.H, self.W)
+        return ops.warp_backward(self.flow.to(img.device).to(torch.float32).contiguous(),
+                                 img.to(torch.float32).contiguous())
+
+    def chain_result(self, right):
+        """chain_results(self, right) (MFT/MFT.py:233-239) in one kernel."""
+        flow, occl, sigma = ops.chain(self.planes(), right.planes())
+        return FlowOUTrackingResult(flow, occl, sigma, validate=False)
+
+    # ---- point queries (N ~ hundreds; torch plumbing) ----------------------
+    def _points_normed(self, points):
+        if not isinstance(points, torch.Tensor):
+            points = torch.from_numpy(np.asarray(points))
+        points = points.to(torch.float32)
+        return points, _normalize_coords(points.reshape(1, 1, -1, 2), self.H, self.W)
+
+    def warp_forward_points(self, points):
+        """(N xy) source coords -> (N xy) warped coords (MFT/results.py:138-157)."""
+        points, normed = self._points_normed(points)
+        flow = self.flow.to(points.device).to(torch.float32)
+        s = F.grid_sample(flow[None], normed, align_corners=True)
+        return points + s[0, :, 0, :].t()
+
+    def sample(self, points):
+        """-> sampled flow (xy N), occlusion (1 N), sigma (1 N) (MFT/results.py:159-188)."""
+        points, normed = self._points_normed(points)
+        dev = points.device
+        out = []
+        for t in (self.flow, self.occlusion, self.sigma):
+            out.append(F.grid_sample(t.to(dev).to(torch.float32)[None], normed, align_corners=True)[0, :, 0, :])
+        return tuple(out)
+
+    def invalid_mask(self):
+        """(H, W) bool, True where the flow points outside the image
+        (MFT/results.py:250-265)."""
+        q = _grid(self.H, self.W, self.flow.device) + self.flow.to(torch.float32)
+        return (q[0] < 0) | (q[1] < 0) | (q[0] >= self.W) | (q[1] >= self.H)
+
+
+FlowOUResult = FlowOUTrackingResult  # the name BASELINE.json uses

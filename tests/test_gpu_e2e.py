@@ -1,0 +1,183 @@
+"""End-to-end parity of the HIP path (flow plugin + tracker, through the C ABI)
+against the reference-generated goldens and the CPU oracle.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from oracle import mft_oracle as O
+from mft_amd.synth import SyntheticVideo
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def epe(a, b):
+    return (a.double() - b.double()).pow(2).sum(0).sqrt()
+
+
+@pytest.fixture(scope="module")
+def flower(weights_np):
+    from mft_amd.config import Config
+    from mft_amd.raft import RAFTWrapper
+    c = Config()
+    c.flow_iters = 12
+    return RAFTWrapper(c, state_dict=weights_np)
+
+
+def make_tracker(flower, deltas=(np.inf, 1, 2, 4, 8, 16, 32)):
+    from mft_amd.config import Config
+    from mft_amd.MFT import MFT
+    c = Config()
+    c.deltas = list(deltas)
+    c.occlusion_threshold = 0.02
+    c.flow_config = Config()
+    c.flow_config.of_class = lambda cfg: flower
+    return MFT(c)
+
+
+def test_first_iteration_intermediates(flower, weights_cpu):
+    """Stage-by-stage check of one refinement iteration against the oracle
+    (workspace regions hold the intermediates of the last iteration)."""
+    vid = SyntheticVideo(128, 192, n_frames=8, seed=5)
+    a, b = vid[0], vid[3]
+    f1, f2 = flower.encode(a), flower.encode(b, want_context=False)
+    h, w = f1.h, f1.w
+    out = flower.engine.refine(f1.fmap[None], f2.fmap[None], f1.net[None], f1.inp[None], h, w, 1, pads=f1.pads,
+                               want_flow_lr=True)
+    im1, im2 = O.preprocess(a), O.preprocess(b)
+    of1, of2 = O.features(weights_cpu, im1), O.features(weights_cpu, im2)
+    onet, oinp = O.context(weights_cpu, im1)
+
+    def pmaj(x):
+        return x[0].permute(1, 2, 0).reshape(h * w, -1)
+
+    assert (f1.fmap.cpu() - pmaj(of1)).abs().max() < 2e-4, "fnet"
+    assert (f1.net.cpu() - pmaj(onet)).abs().max() < 2e-4, "cnet"
+    trace = []
+    pred = O.raft_refine(weights_cpu, of1, of2, onet, oinp, 1, trace=trace)
+    eng = flower.engine
+    corr = eng.region("corr", 1, h, w, 324).cpu()
+    assert (corr - pmaj(trace[0]["corr"])).abs().max() < 5e-4, "lookup"
+    hx = eng.region("hx", 1, h, w, 384).cpu()
+    assert (hx[:, :128] - pmaj(trace[0]["net"])).abs().max() < 5e-4, "gru"
+    delta = eng.region("delta", 1, h, w, 2).cpu()
+    assert (delta - pmaj(trace[0]["delta"])).abs().max() < 5e-4, "flow head"
+    flow_lr = out[3][0].cpu()
+    assert (flow_lr - pmaj(pred["coords"])).abs().max() < 5e-4, "coords"
+    oflow, ooccl, osig = O.postprocess(pred, 128, 192)
+    assert epe(out[0][0].cpu(), oflow).mean() < 1e-3
+    assert (out[1][0].cpu() - ooccl).abs().max() < 1e-3
+    assert ((out[2][0].cpu() - osig).abs() / osig).max() < 1e-3
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_compute_flow_vs_golden(golden_dir, flower, tag):
+    g = np.load(golden_dir / "compute_flow.npz")
+    H, W, iters, fa, fb = (int(v) for v in g[f"{tag}_meta"])
+    vid = SyntheticVideo(H, W, n_frames=8, seed=5)
+    flower.C.flow_iters = iters
+    flow, extra = flower.compute_flow(vid[fa], vid[fb], mode="flow")
+    flower.C.flow_iters = 12
+    assert flow.shape == (2, H, W) and extra["occlusion"].shape == (1, H, W)
+    e = epe(flow.cpu(), T(g[f"{tag}_flow"]))
+    assert e.mean() < 1e-3, float(e.mean())             # north-star tolerance: 1e-3 px EPE
+    assert e.max() < 1e-2
+    assert (extra["occlusion"].cpu() - T(g[f"{tag}_occl"])).abs().max() < 2e-3
+    rel = (extra["sigma"].cpu() - T(g[f"{tag}_sigma"])).abs() / T(g[f"{tag}_sigma"])
+    assert rel.max() < 2e-3
+
+
+def test_batch_invariance_bitwise(flower):
+    """A pair's FlowOU must not depend on what it is batched with (the 1-vs-N
+    GPU equality of the delta-sharded path relies on it)."""
+    vid = SyntheticVideo(128, 160, n_frames=6, seed=9)
+    lefts = [(None, vid[i]) for i in (0, 2, 3)]
+    many = flower.compute_flow_many(lefts, (None, vid[5]))
+    for (k, img), m in zip(lefts, many):
+        (single,) = flower.compute_flow_many([(None, img)], (None, vid[5]))
+        for a, b in zip(m, single):
+            assert torch.equal(a, b)
+
+
+class StubFlower:
+    def compute_flow(self, src_img, dst_img, mode="flow", init_flow=None, **kw):
+        l, r = gi.decode_id(src_img), gi.decode_id(dst_img)
+        flow, occl, sigma = gi.stub_flowou(l, r)
+        return T(flow).to(DEV), {"occlusion": T(occl).to(DEV), "sigma": T(sigma).to(DEV), "debug": None}
+
+
+@pytest.mark.parametrize("tag,start,direction", [("fwd", 0, 1), ("bwd", gi.SEQ_FRAMES - 1, -1)])
+def test_tracker_stub_sequence_vs_golden(golden_dir, tag, start, direction):
+    """MFT.init/track on the HIP chain+select kernels, driven by the same stub
+    flows the reference's own MFT.track was driven with."""
+    g = np.load(golden_dir / "sequence_stub.npz")
+    tr = make_tracker(StubFlower())
+    meta = tr.init(gi.id_image(start), start_frame_i=start, time_direction=direction)
+    assert not meta.result.flow.is_cuda and float(meta.result.flow.abs().sum()) == 0.0
+    keep = set(g[f"{tag}_keep"].tolist())
+    for step in range(1, gi.SEQ_FRAMES):
+        meta = tr.track(gi.id_image(start + direction * step))
+        res = meta.result
+        assert not res.flow.is_cuda
+        keys = [k for k in g[f"{tag}_memory_keys"][step - 1].tolist() if k >= 0]
+        assert sorted(tr.memory.keys()) == keys
+        if step in keep:
+            d = (res.flow - T(g[f"{tag}_{step}_flow"])).abs().max(0).values
+            ok = d < 1e-3
+            assert ok.float().mean() > 0.999, (step, float(ok.float().mean()))
+            assert (res.occlusion - T(g[f"{tag}_{step}_occl"])).abs()[0][ok].max() < 1e-4
+            assert (res.sigma - T(g[f"{tag}_{step}_sigma"])).abs()[0][ok].max() < 1e-4
+        cs = np.concatenate([gi.checksum(res.flow.numpy()), gi.checksum(res.occlusion.numpy()),
+                             gi.checksum(res.sigma.numpy())])
+        assert np.allclose(cs, g[f"{tag}_checksums"][step - 1], rtol=2e-3, atol=1.0), step
+
+
+def test_tracker_raft_sequence_vs_golden(golden_dir, flower):
+    """The whole path (encoders -> native RAFT engine -> chain+select) over 41
+    frames so that all seven deltas fire, against the reference's outputs."""
+    g = np.load(golden_dir / "sequence_raft.npz")
+    vid = SyntheticVideo(gi.E2E_H, gi.E2E_W, n_frames=gi.E2E_FRAMES, seed=11)
+    flower.C.flow_iters = gi.E2E_ITERS
+    try:
+        tr = make_tracker(flower)
+        tr.init(vid[0])
+        seen = 0
+        for i in range(1, gi.E2E_FRAMES):
+            res = tr.track(vid[i]).result
+            if i == 40:
+                assert len(tr.last_pairs) == 7
+            if f"f{i}_flow" in g.files:
+                e = epe(res.flow, T(g[f"f{i}_flow"]))
+                # selection can flip between near-tied candidates; those pixels
+                # are few and everything else must sit within the 1e-3 budget
+                assert np.median(e.numpy()) < 1e-3, (i, float(e.median()))
+                assert (e < 1e-2).float().mean() > 0.99, (i, float((e < 1e-2).float().mean()))
+                ok = e < 1e-2
+                assert (res.occlusion[0] - T(g[f"f{i}_occl"])[0]).abs()[ok].max() < 5e-2
+                seen += 1
+        assert seen == 5
+    finally:
+        flower.C.flow_iters = 12
+
+
+def test_result_api(flower):
+    from mft_amd.results import FlowOUTrackingResult, FlowOUResult
+    assert FlowOUResult is FlowOUTrackingResult
+    with pytest.raises(AssertionError):
+        FlowOUTrackingResult(torch.zeros(3, 4, 4))
+    with pytest.raises(AssertionError):
+        FlowOUTrackingResult(torch.zeros(2, 4, 4), torch.full((1, 4, 4), 1.5), torch.zeros(1, 4, 4))
+    with pytest.raises(AssertionError):
+        FlowOUTrackingResult(torch.zeros(2, 4, 4), torch.zeros(1, 4, 4), -torch.ones(1, 4, 4))
+    r = FlowOUTrackingResult.identity((16, 24), device=DEV)
+    assert r.flow.is_cuda and r.clone().cpu().flow.device.type == "cpu"
+    pts = torch.tensor([[3.0, 4.0], [10.5, 2.25]])
+    r2 = FlowOUTrackingResult(torch.ones(2, 16, 24), torch.zeros(1, 16, 24), torch.zeros(1, 16, 24))
+    assert torch.allclose(r2.warp_forward_points(pts), pts + 1)
+    f, o, s = r2.sample(pts)
+    assert f.shape == (2, 2) and o.shape == (1, 2)

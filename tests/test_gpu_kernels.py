@@ -1,0 +1,304 @@
+"""Parity of every libmftx kernel (called through the C ABI) against the CPU
+oracle and the reference-generated golden vectors.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_inputs as gi
+from oracle import mft_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def pm(x):
+    """[1,C,h,w] (cpu) -> pixel-major [h*w, C] on the GPU."""
+    return x[0].permute(1, 2, 0).reshape(-1, x.shape[1]).contiguous().to(DEV)
+
+
+def from_pm(x, h, w):
+    """pixel-major [h*w, C] (gpu) -> [1,C,h,w] cpu."""
+    return x.reshape(h, w, -1).permute(2, 0, 1)[None].cpu()
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+@pytest.fixture(scope="module")
+def ops_mod():
+    from mft_amd import ops
+    return ops
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return dict(np.load(golden_dir / "ops.npz"))
+
+
+@pytest.fixture(scope="module")
+def inp():
+    return {k: T(v) for k, v in gi.ops_inputs().items()}
+
+
+def maxerr(a, b):
+    return float((a.double() - b.double()).abs().max())
+
+
+# ---------------------------------------------------------------------------
+# a4/a5/a6
+# ---------------------------------------------------------------------------
+
+def test_corr_pyramid_vs_golden(ops_mod, gold, inp):
+    h, w = gi.OPS_H, gi.OPS_W
+    lv = ops_mod.corr_pyramid(pm(inp["fmap1"])[None], pm(inp["fmap2"])[None], h, w)
+    rows = gold["pyr_rows_idx"]
+    for l, t in enumerate(lv):
+        got = t[0].cpu()[rows].reshape(gold[f"pyr{l}_rows"].shape)
+        assert maxerr(got, T(gold[f"pyr{l}_rows"])) < 3e-5, l
+        cs = gi.checksum(t.cpu().numpy())
+        assert np.allclose(cs, gold[f"pyr{l}_checksum"], rtol=1e-5, atol=1e-2)
+
+
+def test_corr_pool_bit_exact_vs_oracle(ops_mod, inp):
+    """Pooling uses ATen's summation order: levels 1..3 must equal avg-pooling
+    the kernel's own level 0 on the CPU bit for bit."""
+    h, w = gi.OPS_H, gi.OPS_W
+    lv = ops_mod.corr_pyramid(pm(inp["fmap1"])[None], pm(inp["fmap2"])[None], h, w)
+    v = lv[0][0].cpu().reshape(h * w, 1, h, w)
+    for l in range(1, 4):
+        v = F.avg_pool2d(v, 2, stride=2)
+        assert torch.equal(v.reshape(h * w, -1), lv[l][0].cpu()), l
+
+
+def test_corr_lookup_vs_golden(ops_mod, gold, inp):
+    h, w = gi.OPS_H, gi.OPS_W
+    lv = ops_mod.corr_pyramid(pm(inp["fmap1"])[None], pm(inp["fmap2"])[None], h, w)
+    coords = pm(inp["coords1"])[None]
+    out = ops_mod.corr_lookup(lv, coords, h, w)
+    assert maxerr(from_pm(out[0], h, w), T(gold["lookup"])) < 5e-5
+
+
+def test_corr_lookup_batched_and_odd_size(ops_mod):
+    """P=3 pairs at an odd 1/8 grid (17x23: pyramid sizes floor), vs the oracle."""
+    g = torch.Generator().manual_seed(3)
+    h, w, P = 17, 23, 3
+    f1 = torch.randn(P, 256, h, w, generator=g)
+    f2 = torch.randn(P, 256, h, w, generator=g)
+    coords = O.pixel_grid(h, w)[None] + 3 * torch.randn(P, 2, h, w, generator=g)
+    a = torch.stack([pm(f1[i:i + 1]) for i in range(P)])
+    b = torch.stack([pm(f2[i:i + 1]) for i in range(P)])
+    lv = ops_mod.corr_pyramid(a, b, h, w)
+    out = ops_mod.corr_lookup(lv, torch.stack([pm(coords[i:i + 1]) for i in range(P)]), h, w)
+    for i in range(P):
+        pyr = O.corr_pyramid(O.corr_volume(f1[i:i + 1], f2[i:i + 1]))
+        for l in range(4):
+            assert maxerr(lv[l][i].cpu(), pyr[l].reshape(h * w, -1)) < 5e-5
+        ref = O.corr_lookup(pyr, coords[i:i + 1])
+        assert maxerr(from_pm(out[i], h, w), ref) < 1e-4
+
+
+# ---------------------------------------------------------------------------
+# a7-a9/a11: conv kernel
+# ---------------------------------------------------------------------------
+
+CONV_CASES = [
+    # cin, cout, kh, kw, act, scale, P, h, w
+    (324, 256, 1, 1, "relu", 1.0, 1, 16, 24),
+    (256, 192, 3, 3, "relu", 1.0, 2, 16, 24),
+    (256, 126, 3, 3, "relu", 1.0, 1, 17, 23),
+    (384, 256, 1, 5, "sigmoid", 1.0, 1, 16, 24),
+    (384, 128, 5, 1, "tanh", 1.0, 3, 16, 24),
+    (256, 2, 3, 3, None, 1.0, 1, 16, 24),
+    (256, 576, 1, 1, None, 0.25, 1, 16, 24),
+    (712, 256, 3, 3, "relu", 1.0, 1, 16, 24),
+    (128, 64, 3, 3, "relu", 1.0, 7, 32, 32),   # large-M tile path
+]
+
+
+@pytest.mark.parametrize("cin,cout,kh,kw,act,scale,P,h,w", CONV_CASES)
+def test_conv2d_vs_torch(ops_mod, cin, cout, kh, kw, act, scale, P, h, w):
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(P, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, kh, kw, generator=g) * (2.0 / (cin * kh * kw)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x, wt, b, padding=(kh // 2, kw // 2))
+    ref = {None: lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}[act](ref) * scale
+    xp = x.permute(0, 2, 3, 1).reshape(P * h * w, cin).contiguous().to(DEV)
+    out = ops_mod.conv2d(xp, ops_mod.pack_conv_weight(wt.to(DEV)), b.to(DEV), P, h, w, cout, kh, kw, act=act,
+                         out_scale=scale)
+    got = out.reshape(P, h, w, cout).permute(0, 3, 1, 2).cpu()
+    assert maxerr(got, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_conv2d_two_segments(ops_mod):
+    g = torch.Generator().manual_seed(5)
+    P, h, w = 2, 16, 24
+    a = torch.randn(P, 128, h, w, generator=g)
+    bb = torch.randn(P, 256, h, w, generator=g)
+    wt = torch.randn(128, 384, 1, 5, generator=g) * 0.03
+    bias = torch.randn(128, generator=g) * 0.1
+    ref = torch.tanh(F.conv2d(torch.cat([a, bb], 1), wt, bias, padding=(0, 2)))
+    ap = a.permute(0, 2, 3, 1).reshape(-1, 128).contiguous().to(DEV)
+    bp = bb.permute(0, 2, 3, 1).reshape(-1, 256).contiguous().to(DEV)
+    out = ops_mod.conv2d(ap, ops_mod.pack_conv_weight(wt.to(DEV)), bias.to(DEV), P, h, w, 128, 1, 5, act="tanh",
+                         x2=bp)
+    assert maxerr(out.reshape(P, h, w, 128).permute(0, 3, 1, 2).cpu(), ref) < 2e-5
+
+
+def test_conv2d_argument_errors(ops_mod):
+    from mft_amd._lib import MftxError
+    x = torch.zeros(16 * 24, 130, device=DEV)
+    wt = ops_mod.pack_conv_weight(torch.zeros(8, 130, 3, 3, device=DEV))
+    with pytest.raises(MftxError):
+        ops_mod.conv2d(x, wt, None, 1, 16, 24, 8, 3, 3)          # 130 channels: not a multiple of 4
+    with pytest.raises(MftxError):
+        ops_mod.conv2d(torch.zeros(16 * 24, 128), wt, None, 1, 16, 24, 8, 3, 3)   # CPU tensor
+
+
+# ---------------------------------------------------------------------------
+# a10 + a12
+# ---------------------------------------------------------------------------
+
+def test_convex_upsample_vs_golden(ops_mod, gold, inp):
+    h, w = gi.OPS_H, gi.OPS_W
+    ou = torch.cat([pm(inp["occl_lr"]), pm(inp["unc_lr"]), torch.zeros(h * w, 1, device=DEV)], 1).contiguous()
+    flow, occl, sigma = ops_mod.convex_upsample(pm(inp["flow"]), ou, pm(inp["mask"]), 1, h, w)
+    assert maxerr(flow.cpu(), T(gold["up_flow"])) < 2e-5
+    ref_occl = torch.softmax(T(gold["up_occl"]), dim=1)[:, 1:2]
+    ref_sigma = torch.sqrt(torch.exp(T(gold["up_unc"])))
+    assert maxerr(occl.cpu(), ref_occl) < 1e-5
+    assert maxerr(sigma.cpu(), ref_sigma) < 1e-5 * float(ref_sigma.max())
+    # cropped output == crop of the full output (InputPadder.unpad)
+    f2, o2, s2 = ops_mod.convex_upsample(pm(inp["flow"]), ou, pm(inp["mask"]), 1, h, w, pads=(2, 3, 1, 2))
+    assert torch.equal(f2, flow[..., 1:8 * h - 2, 2:8 * w - 3])
+    assert torch.equal(o2, occl[..., 1:8 * h - 2, 2:8 * w - 3])
+
+
+# ---------------------------------------------------------------------------
+# a14 / a15
+# ---------------------------------------------------------------------------
+
+def dev3(t):
+    return tuple(T(x).to(DEV) for x in t)
+
+
+def test_chain_vs_golden(ops_mod, golden_dir):
+    g = np.load(golden_dir / "sequence_stub.npz")
+    flow, occ, sig = ops_mod.chain(dev3(gi.stub_flowou(0, 7)), dev3(gi.stub_flowou(7, 9)))
+    assert maxerr(flow.cpu(), T(g["chain_flow"])) < 2e-5
+    assert maxerr(occ.cpu(), T(g["chain_occl"])) < 1e-5
+    assert maxerr(sig.cpu(), T(g["chain_sigma"])) < 1e-5
+
+
+def test_warp_backward_and_chain_method(ops_mod):
+    from mft_amd.results import FlowOUTrackingResult
+    L = FlowOUTrackingResult(*dev3(gi.stub_flowou(0, 7)))
+    R = dev3(gi.stub_flowou(7, 9))
+    ref = O.chain(tuple(T(x) for x in gi.stub_flowou(0, 7)), tuple(T(x) for x in gi.stub_flowou(7, 9)))
+    assert maxerr(L.chain(R[0]).cpu(), ref[0]) < 2e-5
+    warped = L.warp_backward(torch.cat([R[1], R[2]], 0))
+    occ = torch.maximum(L.occlusion, warped[0:1])
+    assert maxerr(occ.cpu(), ref[1]) < 1e-5
+    assert bool(L.invalid_mask().any())
+
+
+def _candidates():
+    pairs = [(0, 9), (8, 9), (7, 9), (5, 9), (1, 9), (3, 9), (6, 9)]
+    H, W = gi.SEQ_H, gi.SEQ_W
+    Ls, Rs = [], []
+    for a, b in pairs:
+        if a == 0:
+            Ls.append((np.zeros((2, H, W), np.float32), np.zeros((1, H, W), np.float32), np.zeros((1, H, W), np.float32)))
+        else:
+            Ls.append(gi.stub_flowou(0, a))
+        Rs.append(gi.stub_flowou(a, b))
+    return Ls, Rs
+
+
+def test_select_vs_oracle_and_fused_bitwise(ops_mod):
+    Ls, Rs = _candidates()
+    thr = 0.02
+    dL, dR = [dev3(l) for l in Ls], [dev3(r) for r in Rs]
+    chained = [ops_mod.chain(l, r) for l, r in zip(dL, dR)]
+    f1, o1, s1, c1 = ops_mod.select(chained, thr, want_chosen=True)
+    f2, o2, s2, c2 = ops_mod.chain_select(dL, dR, thr, want_chosen=True)
+    # fused == chain -> select, bit for bit (the multi-GPU path relies on it)
+    assert torch.equal(f1, f2) and torch.equal(o1, o2) and torch.equal(s1, s2) and torch.equal(c1, c2)
+    # selection semantics: identical to the oracle given identical candidates
+    of, oo, os_, oi = O.select([tuple(t.cpu() for t in c) for c in chained], thr)
+    assert torch.equal(c1.cpu().long(), oi)
+    assert torch.equal(f1.cpu(), of) and torch.equal(o1.cpu(), oo) and torch.equal(s1.cpu(), os_)
+    assert len(torch.unique(c1)) >= 4                     # several candidates actually win
+    assert bool((oo == 1).any())                          # out-of-image flows marked occluded
+    # the chained candidates themselves agree with the oracle
+    for c, l, r in zip(chained, Ls, Rs):
+        ref = O.chain(tuple(T(x) for x in l), tuple(T(x) for x in r))
+        assert maxerr(c[0].cpu(), ref[0]) < 3e-5 and maxerr(c[2].cpu(), ref[2]) < 1e-5
+
+
+def test_select_all_occluded_picks_first(ops_mod):
+    H, W = 8, 16
+    cands = []
+    for k in range(3):
+        cands.append((torch.full((2, H, W), float(k), device=DEV), torch.ones(1, H, W, device=DEV),
+                      torch.full((1, H, W), 1.0 / (k + 1), device=DEV)))
+    f, o, s, c = ops_mod.select(cands, 0.02, want_chosen=True)
+    assert int(c.abs().sum()) == 0 and float(f.abs().sum()) == 0.0
+    # ties keep the first index
+    cands = [(torch.full((2, H, W), float(k), device=DEV), torch.zeros(1, H, W, device=DEV),
+              torch.full((1, H, W), 0.5, device=DEV)) for k in range(3)]
+    _, _, _, c = ops_mod.select(cands, 0.02, want_chosen=True)
+    assert int(c.abs().sum()) == 0
+
+
+def test_chain_select_arg_errors(ops_mod):
+    from mft_amd._lib import MftxError
+    H, W = 8, 16
+    good = (torch.zeros(2, H, W, device=DEV), torch.zeros(1, H, W, device=DEV), torch.zeros(1, H, W, device=DEV))
+    with pytest.raises(MftxError):
+        ops_mod.chain_select([good] * 17, [good] * 17, 0.02)          # K > 16
+    bad = (torch.zeros(2, H, W + 1, device=DEV), good[1], good[2])
+    with pytest.raises(MftxError):
+        ops_mod.chain(good, bad)
+
+
+# ---------------------------------------------------------------------------
+# full-size (512x512 -> 64x64 grid, BASELINE config 2) size-independent properties
+# ---------------------------------------------------------------------------
+
+def test_fullsize_properties(ops_mod):
+    g = torch.Generator().manual_seed(11)
+    h = w = 64
+    f1 = torch.randn(2, h * w, 256, generator=g).to(DEV)
+    f2 = torch.randn(2, h * w, 256, generator=g).to(DEV)
+    lv = ops_mod.corr_pyramid(f1, f2, h, w)
+    lvT = ops_mod.corr_pyramid(f2, f1, h, w)
+    # V(f1,f2)[i][j] == V(f2,f1)[j][i] bitwise (same fp32 reduction order)
+    assert torch.equal(lv[0][0], lvT[0][0].t())
+    # spot-check level 0 against an fp64 dot product
+    i = torch.tensor([0, 17, 4095]); j = torch.tensor([5, 2048, 4000])
+    ref = (f1[1, i].double() * f2[1, j].double()).sum(1) / 16
+    assert maxerr(lv[0][1][i, j].cpu(), ref.cpu()) < 2e-5
+    # lookup at integer coordinates reads the volume itself (centre tap, all levels' level-0 part)
+    grid = O.pixel_grid(h, w).permute(1, 2, 0).reshape(1, h * w, 2).repeat(2, 1, 1).contiguous().to(DEV)
+    out = ops_mod.corr_lookup(lv, grid, h, w)
+    centre = 4 * 9 + 4
+    diag = torch.arange(h * w, device=DEV)
+    assert maxerr(out[0][:, centre].cpu(), lv[0][0][diag, diag].cpu()) < 1e-6
+    # chain with an identity left result returns the right result
+    H = W = 512
+    R = (torch.randn(2, H, W, generator=g).to(DEV), torch.rand(1, H, W, generator=g).to(DEV),
+         torch.rand(1, H, W, generator=g).to(DEV))
+    I = (torch.zeros(2, H, W, device=DEV), torch.zeros(1, H, W, device=DEV), torch.zeros(1, H, W, device=DEV))
+    c = ops_mod.chain(I, R)
+    assert maxerr(c[0].cpu(), R[0].cpu()) < 2e-4 and maxerr(c[1].cpu(), R[1].cpu()) < 1e-4
+    # convex upsampling of a constant field is that constant (x8 for flow) in the interior
+    M = h * w
+    const = torch.tensor([1.5, -2.0], device=DEV).repeat(M, 1).contiguous()
+    ou = torch.zeros(M, 4, device=DEV)
+    mask = torch.randn(M, 576, generator=g).to(DEV)
+    flow, occl, sigma = ops_mod.convex_upsample(const, ou, mask, 1, h, w)
+    assert maxerr(flow[0, 0, 8:-8, 8:-8].cpu(), torch.full((496, 496), 12.0)) < 1e-4
+    assert maxerr(occl.cpu(), torch.full_like(occl.cpu(), 0.5)) < 1e-6

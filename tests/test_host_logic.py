@@ -1,0 +1,265 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol the header
+declares, weight packing, the tracker's host logic (delta bookkeeping, memory
+ring, cache protocol) and the delta-sharded multi-rank path over gloo.
+
+The tracker's compute backend is the HIP library in the product; here (no GPU)
+the host logic is exercised with a test double built on the CPU oracle."""
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from oracle import mft_oracle as O
+
+REPO = Path(__file__).resolve().parents[1]
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+# ---------------------------------------------------------------------------
+# boundary
+# ---------------------------------------------------------------------------
+
+def test_library_exports_every_header_symbol():
+    if not (REPO / "mft_amd" / "libmftx.so").exists():
+        subprocess.run(["make", "-C", str(REPO / "mft_amd" / "csrc"), "-j8"], check=True, capture_output=True)
+    from mft_amd import _lib
+    lib = _lib.load()
+    header = (REPO / "include" / "mftx.h").read_text()
+    declared = set(re.findall(r"\b(mftx_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mftx_version() == 100
+    assert lib.mftx_raft_workspace_bytes(7, 64, 64) > 7 * 4096 * 4096 * 4
+    assert lib.mftx_raft_workspace_bytes(0, 64, 64) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from mft_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("MFTX_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.MftxError):
+        _lib.load()
+    monkeypatch.delenv("MFTX_LIB")
+    monkeypatch.setattr(_lib, "_lib", None)
+    _lib.load()
+
+
+def test_ops_reject_cpu_tensors():
+    from mft_amd import ops
+    from mft_amd._lib import MftxError
+    z = (torch.zeros(2, 8, 8), torch.zeros(1, 8, 8), torch.zeros(1, 8, 8))
+    with pytest.raises(MftxError):
+        ops.chain(z, z)
+
+
+def test_flow_plugin_refuses_cpu():
+    from mft_amd.config import Config
+    from mft_amd.raft import RAFTWrapper
+    with pytest.raises(RuntimeError):
+        RAFTWrapper(Config(), device="cpu")
+
+
+def test_pack_conv_weight_layout():
+    from mft_amd.ops import pack_conv_weight
+    w = torch.arange(3 * 5 * 1 * 5, dtype=torch.float32).reshape(3, 5, 1, 5)
+    p = pack_conv_weight(w)
+    assert p.shape == (128, 5, 32)
+    assert p[2, 3, 4] == w[2, 4, 0, 3]          # [n][tap][cin]
+    assert float(p[3:].abs().sum()) == 0 and float(p[:, :, 5:].abs().sum()) == 0
+
+
+def test_weight_schema_matches_reference_counts(weights_np):
+    from mft_amd.weights import schema
+    assert len(schema()) == 187
+    n = sum(int(np.prod(s)) for _, s, k in schema())
+    assert n == 6905492
+    assert weights_np["update_block.gru.convz1.weight"].shape == (128, 384, 1, 5)
+
+
+def test_pad_amounts_match_oracle():
+    from mft_amd.raft import pad_amounts
+    for H in range(120, 137):
+        for W in (187, 192, 193):
+            assert pad_amounts(H, W) == O.pad_amounts(H, W)
+    assert pad_amounts(1080, 1920) == (0, 0, 0, 0) and pad_amounts(436, 1024) == (0, 0, 2, 2)
+
+
+def test_config_semantics(tmp_path):
+    from mft_amd.config import Config, load_config
+    c = Config()
+    assert not c.timers_enabled and not c.a.b.c
+    c.x = 3
+    d = Config(); d.x = 4; d.y = 5
+    c.merge(d)
+    assert c.x == 4 and c.y == 5
+    cfg = load_config(REPO / "configs" / "MFT_cfg.py")
+    assert cfg.deltas[0] == np.inf and cfg.deltas[1:] == [1, 2, 4, 8, 16, 32]
+    assert cfg.occlusion_threshold == 0.02 and cfg.flow_config.flow_iters == 12
+
+
+# ---------------------------------------------------------------------------
+# tracker host logic with an oracle-backed test double
+# ---------------------------------------------------------------------------
+
+class OracleBackend:
+    @staticmethod
+    def chain(L, R):
+        return O.chain(L, R)
+
+    @staticmethod
+    def select(cands, thr):
+        f, o, s, idx = O.select(cands, thr)
+        return f, o, s, idx.to(torch.int8)
+
+    @staticmethod
+    def chain_select(Ls, Rs, thr):
+        return OracleBackend.select([O.chain(l, r) for l, r in zip(Ls, Rs)], thr)
+
+
+class StubFlower:
+    def __init__(self):
+        self.calls = []
+
+    def compute_flow(self, src_img, dst_img, mode="flow", init_flow=None, **kw):
+        l, r = gi.decode_id(src_img), gi.decode_id(dst_img)
+        self.calls.append((l, r))
+        flow, occl, sigma = gi.stub_flowou(l, r)
+        return T(flow), {"occlusion": T(occl), "sigma": T(sigma), "debug": None}
+
+
+def make_tracker(flower, deltas=(np.inf, 1, 2, 4, 8, 16, 32), **extra):
+    from mft_amd.config import Config
+    from mft_amd.MFT import MFT
+    c = Config()
+    c.deltas = list(deltas)
+    c.occlusion_threshold = 0.02
+    c.flow_config = Config()
+    c.flow_config.of_class = lambda cfg: flower
+    for k, v in extra.items():
+        setattr(c, k, v)
+    return MFT(c, backend=OracleBackend(), device="cpu")
+
+
+@pytest.mark.parametrize("tag,start,direction", [("fwd", 0, 1), ("bwd", gi.SEQ_FRAMES - 1, -1)])
+def test_tracker_bookkeeping_vs_reference(golden_dir, tag, start, direction):
+    g = np.load(golden_dir / "sequence_stub.npz")
+    fl = StubFlower()
+    tr = make_tracker(fl)
+    tr.init(gi.id_image(start), start_frame_i=start, time_direction=direction)
+    for step in range(1, gi.SEQ_FRAMES):
+        fid = start + direction * step
+        fl.calls.clear()
+        res = tr.track(gi.id_image(fid)).result
+        keys = [k for k in g[f"{tag}_memory_keys"][step - 1].tolist() if k >= 0]
+        assert sorted(tr.memory.keys()) == keys
+        # requested pairs: every delta that does not reach before the start, inf -> start, deduplicated
+        want = []
+        for d in [np.inf, 1, 2, 4, 8, 16, 32]:
+            left = fid - d * direction
+            before = left < start if direction > 0 else left > start
+            if before:
+                if not np.isinf(d):
+                    continue
+                left = start
+            if int(left) not in want:
+                want.append(int(left))
+        assert sorted(l for l, r in fl.calls) == sorted(want) and all(r == fid for l, r in fl.calls)
+        cs = np.concatenate([gi.checksum(res.flow.numpy()), gi.checksum(res.occlusion.numpy()),
+                             gi.checksum(res.sigma.numpy())])
+        assert np.allclose(cs, g[f"{tag}_checksums"][step - 1], rtol=2e-3, atol=1.0), step
+
+
+def test_flow_cache_protocol():
+    """finite deltas go through cache.read/.write, delta=inf does not (unless
+    cache_delta_infinity); a failing cache means recompute (MFT/MFT.py:99-102,214-219)."""
+    class Cache:
+        def __init__(self):
+            self.store, self.reads, self.writes = {}, [], []
+
+        def read(self, l, r):
+            self.reads.append((l, r))
+            if (l, r) == (2, 3):
+                raise IOError("broken entry")
+            return self.store.get((l, r), (None, None, None))
+
+        def write(self, l, r, f, o, s):
+            self.writes.append((l, r))
+            self.store[(l, r)] = (f, o, s)
+
+    fl, cache = StubFlower(), Cache()
+    tr = make_tracker(fl, deltas=(np.inf, 1, 2))
+    tr.init(gi.id_image(0), flow_cache=cache)
+    for i in range(1, 5):
+        tr.track(gi.id_image(i))
+    assert (0, 4) not in cache.reads and (0, 3) not in cache.writes      # delta=inf bypasses the cache
+    assert (3, 4) in cache.writes and (2, 4) in cache.writes
+    assert (2, 3) in cache.reads and (2, 3) in fl.calls                  # broken read -> recomputed
+    # second run over the same frames: everything finite is served from the cache
+    fl2 = StubFlower()
+    tr2 = make_tracker(fl2, deltas=(np.inf, 1, 2))
+    tr2.init(gi.id_image(0), flow_cache=cache)
+    for i in range(1, 5):
+        tr2.track(gi.id_image(i))
+    assert all(l == 0 or (l, r) == (2, 3) for l, r in fl2.calls), fl2.calls
+    # with cache_delta_infinity the inf pair is cached too
+    fl3, cache3 = StubFlower(), Cache()
+    tr3 = make_tracker(fl3, deltas=(np.inf, 1), cache_delta_infinity=True)
+    tr3.init(gi.id_image(0), flow_cache=cache3)
+    tr3.track(gi.id_image(1)); tr3.track(gi.id_image(2))
+    assert (0, 2) in cache3.writes
+
+
+def test_get_flowou_with_cache_and_chain_results_api():
+    from mft_amd.MFT import get_flowou_with_cache
+    fl = StubFlower()
+    r = get_flowou_with_cache(fl, gi.id_image(3), gi.id_image(5))
+    assert r.flow.shape == (2, gi.SEQ_H, gi.SEQ_W) and fl.calls == [(3, 5)]
+    with pytest.raises(AssertionError):
+        get_flowou_with_cache(fl, gi.id_image(3), gi.id_image(5), read_cache=True)   # ids required
+
+
+def test_keep_result_on_device_flag():
+    tr = make_tracker(StubFlower(), deltas=(np.inf, 1), keep_result_on_device=True)
+    tr.init(gi.id_image(0))
+    m = tr.track(gi.id_image(1))
+    assert m.result is tr.memory[1]["result"]
+
+
+# ---------------------------------------------------------------------------
+# multi-rank (gloo, world_size 2): sharded == single-rank, bitwise
+# ---------------------------------------------------------------------------
+
+def test_shard_plan():
+    from mft_amd.dist import shard_indices, slots_per_rank
+    assert shard_indices(7, 8, 7) == [] and shard_indices(7, 2, 1) == [1, 3, 5]
+    assert sorted(sum((shard_indices(7, 4, r) for r in range(4)), [])) == list(range(7))
+    assert slots_per_rank(7, 2) == 4 and slots_per_rank(7, 8) == 1 and slots_per_rank(3, 4) == 1
+
+
+@pytest.mark.timeout(300)
+def test_delta_sharding_two_ranks_gloo(tmp_path):
+    script = REPO / "tests" / "dist_worker.py"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    out = tmp_path / "out"
+    out.mkdir()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29611", str(script), str(out)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    r0 = np.load(out / "rank0.npz")
+    r1 = np.load(out / "rank1.npz")
+    single = np.load(out / "single.npz")
+    for k in single.files:
+        assert np.array_equal(r0[k], r1[k]), k           # replicas stay identical
+        assert np.array_equal(r0[k], single[k]), k       # and equal to the unsharded run
