@@ -46,6 +46,14 @@ extern "C" {
 int mftx_version(void);
 const char *mftx_last_error_string(void);
 
+/* Optional per-kernel timing (HIP events on the launch stream; bench.py's
+ * roofline leg).  Categories: 0 corr volume GEMM, 1 pyramid pooling, 2 lookup,
+ * 3 conv implicit GEMM, 4 convf1, 5 glue, 6 convex upsample, 7 chain/select.
+ * work[] = algorithmic flops (0, 3, 4) or bytes (1, 2, 6, 7) booked per launch. */
+#define MFTX_PROFILE_CATEGORIES 8
+int mftx_profile_begin(void);
+int mftx_profile_end(double *ms, double *work, long long *count, int n);
+
 /* ---- a4 + a5: all-pairs correlation volume and its pyramid ---------------
  * Replaces CorrBlock.corr + CorrBlock.__init__ (MFT/RAFT/core/corr.py:14-28,
  * 53-69).  f1, f2: pixel-major feature maps [P][h*w][C] (C % 32 == 0).

@@ -29,6 +29,8 @@ _PP = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "mftx_version": (C.c_int, []),
     "mftx_last_error_string": (C.c_char_p, []),
+    "mftx_profile_begin": (C.c_int, []),
+    "mftx_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
     "mftx_corr_pyramid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mftx_corr_lookup": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p]),

@@ -19,6 +19,7 @@
 // Compiled with -ffp-contract=off: no FMA contraction, products and sums round
 // exactly as written.
 #include "common.h"
+#include "profile.h"
 
 namespace mftx {
 
@@ -182,6 +183,7 @@ extern "C" int mftx_chain(const float *flowL, const float *occlL, const float *s
     float sx, sy;
     scales(H, W, sx, sy);
     Planes L{flowL, occlL, sigmaL}, R{flowR, occlR, sigmaR};
+    ProfScope prof(PC_CHAIN, (hipStream_t)stream, 48.0 * H * W);
     hipLaunchKernelGGL(chain_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, L, R, H, W, sx, sy,
                        flowO, occlO, sigmaO);
     return check_launch("chain");
@@ -210,6 +212,7 @@ extern "C" int mftx_select(int K, const float *const *flow, const float *const *
         if (!flow[k] || !occl[k] || !sigma[k]) return fail(MFTX_E_ARG, "select: null candidate %d", k);
         ss.C[k] = Planes{flow[k], occl[k], sigma[k]};
     }
+    ProfScope prof(PC_CHAIN, (hipStream_t)stream, (16.0 * K + 16.0) * H * W);
     hipLaunchKernelGGL(select_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, ss, thr, H, W,
                        flowO, occlO, sigmaO, chosen);
     return check_launch("select");
@@ -234,6 +237,7 @@ extern "C" int mftx_chain_select(int K, const float *const *flowL, const float *
     }
     float sx, sy;
     scales(H, W, sx, sy);
+    ProfScope prof(PC_CHAIN, (hipStream_t)stream, (32.0 * K + 16.0) * H * W);
     hipLaunchKernelGGL(chain_select_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, cs, thr, H,
                        W, sx, sy, flowO, occlO, sigmaO, chosen);
     return check_launch("chain_select");

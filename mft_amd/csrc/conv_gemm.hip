@@ -17,6 +17,7 @@
 // 8-wide group, which is a legal permutation of the reduction order as long as
 // A and B use the same one.
 #include "common.h"
+#include "profile.h"
 
 namespace mftx {
 
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
 }
 
 template <int BM, int BN, int WM, int WN>
-static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s) {
+static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat = PC_CONV_GEMM) {
     constexpr size_t lds = 2ull * (BM + BN) * LDK * sizeof(float);
     static bool attr_set = false;
     auto kern = conv_gemm_kernel<BM, BN, WM, WN>;
@@ -220,6 +221,8 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), batch);
+    // algorithmic flops: real (unpadded) reduction length
+    ProfScope prof(cat, s, 2.0 * a.M * a.N * (double)(a.kh * a.kw) * (a.c0 + a.c1) * batch);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     return check_launch("conv_gemm");
 }
@@ -284,8 +287,8 @@ int launch_corr_volume(const float *f1, const float *f2, int P, int C, int N, fl
     a.act = 0; a.out_scale = 1.0f / sqrtf((float)C);
     a.a_bstride = (long long)N * C; a.w_bstride = (long long)N * C; a.o_bstride = (long long)N * N;
     a.gru_mode = 0;
-    if (N >= 1024) return launch_cfg<128, 128, 2, 2>(a, P, s);
-    return launch_cfg<64, 64, 2, 2>(a, P, s);
+    if (N >= 1024) return launch_cfg<128, 128, 2, 2>(a, P, s, PC_CORR_VOLUME);
+    return launch_cfg<64, 64, 2, 2>(a, P, s, PC_CORR_VOLUME);
 }
 
 }  // namespace mftx

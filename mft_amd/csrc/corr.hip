@@ -1,5 +1,6 @@
 // Correlation pyramid pooling and the multi-scale 9x9 lookup (HBM-bound).
 #include "common.h"
+#include "profile.h"
 
 namespace mftx {
 
@@ -57,6 +58,7 @@ int launch_corr_pool(const float *lvl0, int rows, int h, int w, float *lvl1, flo
         if (e != hipSuccess) return fail((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr = lds;
     }
+    ProfScope prof(PC_CORR_POOL, s, 4.0 * rows * ((double)h * w + (h >> 1) * (w >> 1) + (h >> 2) * (w >> 2) + (h >> 3) * (w >> 3)));
     hipLaunchKernelGGL(corr_pool_kernel, dim3(rows), dim3(256), lds, s, lvl0, h, w, lvl1, lvl2, lvl3);
     return check_launch("corr_pool");
 }
@@ -162,6 +164,8 @@ int launch_corr_lookup(const float *const lvl[4], const float *coords, int P, in
     a.coords = coords; a.out = out; a.ld_out = ld_out;
     a.cells = P * h * w; a.n_per_img = h * w;
     const int blocks = cdiv(a.cells, LK_WAVES);
+    // 4 levels x 10x10 unique taps read + coords + 324 outputs written, per cell
+    ProfScope prof(PC_LOOKUP, s, (double)a.cells * (4 * 100 * 4 + 8 + 324 * 4));
     hipLaunchKernelGGL(corr_lookup_kernel, dim3(blocks), dim3(64 * LK_WAVES), 0, s, a);
     return check_launch("corr_lookup");
 }

@@ -1,0 +1,24 @@
+// Optional per-kernel timing with HIP events on the launch stream (bench.py's
+// roofline leg).  Off by default: zero cost in the product path.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mftx {
+
+enum ProfCat { PC_CORR_VOLUME, PC_CORR_POOL, PC_LOOKUP, PC_CONV_GEMM, PC_CONVF1, PC_GLUE, PC_UPSAMPLE, PC_CHAIN, PC_COUNT };
+
+bool prof_enabled();
+// bracket one launch: begin() records an event, end() records another and
+// books `work` (algorithmic flops or bytes) for the category
+void prof_begin(ProfCat c, hipStream_t s);
+void prof_end(ProfCat c, hipStream_t s, double work);
+
+struct ProfScope {
+    ProfCat c; hipStream_t s; double work; bool on;
+    ProfScope(ProfCat c_, hipStream_t s_, double work_) : c(c_), s(s_), work(work_), on(prof_enabled()) {
+        if (on) prof_begin(c, s);
+    }
+    ~ProfScope() { if (on) prof_end(c, s, work); }
+};
+
+}  // namespace mftx

@@ -3,6 +3,7 @@
 // (core/raft.py:141-226) on one HIP stream -- ~14 launches per iteration, no
 // host round trips, batched over P image pairs (M = P*h*w cells).
 #include "common.h"
+#include "profile.h"
 #include <new>
 
 namespace mftx {
@@ -243,6 +244,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     TRY(launch_corr_pool(ws.lvl[0], M, h, w, ws.lvl[1], ws.lvl[2], ws.lvl[3], s));
     {
         const long long slots = (long long)M * 64;
+        ProfScope prof(PC_GLUE, s, 0);
         hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, net, inp,
                            ws.hx, ws.coords1, M, h, w);
         TRY(check_launch("init_state"));
@@ -255,8 +257,11 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         // motion encoder (core/update.py:152-160)
         TRY(launch_conv(conv_desc(ws.corr, 324, 324, nullptr, 0, 0, W[W_CONVC1], W[B_CONVC1], ws.cor1, 256, P, h, w, 256, 1, 1, 1), s));
         TRY(launch_conv(conv_desc(ws.cor1, 256, 256, nullptr, 0, 0, W[W_CONVC2], W[B_CONVC2], ws.corflo, 256, P, h, w, 192, 3, 3, 1), s));
-        hipLaunchKernelGGL(convf1_kernel, dim3(P * h * strips), dim3(128), 0, s, ws.coords1, W[W_CONVF1],
-                           W[B_CONVF1], ws.flo1, ws.hx, h, w, strips);
+        {
+            ProfScope prof(PC_CONVF1, s, 2.0 * M * 128 * 98);
+            hipLaunchKernelGGL(convf1_kernel, dim3(P * h * strips), dim3(128), 0, s, ws.coords1, W[W_CONVF1],
+                               W[B_CONVF1], ws.flo1, ws.hx, h, w, strips);
+        }
         TRY(check_launch("convf1"));
         TRY(launch_conv(conv_desc(ws.flo1, 128, 128, nullptr, 0, 0, W[W_CONVF2], W[B_CONVF2], ws.corflo + 192, 256, P, h, w, 64, 3, 3, 1), s));
         TRY(launch_conv(conv_desc(ws.corflo, 256, 256, nullptr, 0, 0, W[W_CONV], W[B_CONV], ws.hx + 256, 384, P, h, w, 126, 3, 3, 1), s));
@@ -271,8 +276,11 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         // flow head (core/update.py:6-14) and coordinate update (core/raft.py:184)
         TRY(launch_conv(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, W[W_FH1], W[B_FH1], ws.fh, 256, P, h, w, 256, 3, 3, 1), s));
         TRY(launch_conv(conv_desc(ws.fh, 256, 256, nullptr, 0, 0, W[W_FH2], W[B_FH2], ws.delta, 2, P, h, w, 2, 3, 3, 0), s));
-        hipLaunchKernelGGL(add_delta_kernel, dim3((unsigned)((2ll * M + 255) / 256)), dim3(256), 0, s, ws.coords1,
-                           ws.delta, 2ll * M);
+        {
+            ProfScope prof(PC_GLUE, s, 0);
+            hipLaunchKernelGGL(add_delta_kernel, dim3((unsigned)((2ll * M + 255) / 256)), dim3(256), 0, s, ws.coords1,
+                               ws.delta, 2ll * M);
+        }
         TRY(check_launch("add_delta"));
         if (!last) continue;
         // The upsampling mask is consumed only after the last iteration in test
@@ -283,6 +291,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         float *flow_lr = flow_lr_out ? flow_lr_out : ws.flow_lr;
         {
             const long long slots = (long long)M * 178;
+            ProfScope prof(PC_GLUE, s, 0);
             hipLaunchKernelGGL(ou_gather_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, ws.hx,
                                ws.corr, ws.coords1, ws.delta, ws.ouin, flow_lr, M, h, w);
             TRY(check_launch("ou_gather"));

@@ -11,6 +11,7 @@
 // as 8 consecutive floats per k.  The softmax over the 9 mask logits is
 // computed once and shared by the 5 upsampled channels.
 #include "common.h"
+#include "profile.h"
 
 namespace mftx {
 
@@ -77,6 +78,7 @@ int launch_convex_upsample(const float *flow_lr, const float *ou, int ld_ou, con
     a.flow = flow; a.occl = occl; a.sigma = sigma;
     if (a.H0 <= 0 || a.W0 <= 0) return fail(MFTX_E_ARG, "convex_upsample: bad padding");
     dim3 grid(cdiv(a.W0, 256), a.H0, P);
+    ProfScope prof(PC_UPSAMPLE, s, (double)P * h * w * (576 + 5) * 4 + (double)P * 4 * a.H0 * a.W0 * 4);
     hipLaunchKernelGGL(convex_upsample_kernel, grid, dim3(256), 0, s, a);
     return check_launch("convex_upsample");
 }

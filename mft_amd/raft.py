@@ -128,7 +128,10 @@ class RAFTWrapper:
         """uint8 BGR (H,W,3) -> cached pixel-major features (MFT/raft.py:41-48,
         core/raft.py:122-149)."""
         H0, W0 = img_bgr.shape[:2]
-        rgb = torch.from_numpy(np.ascontiguousarray(img_bgr[:, :, ::-1])).to(self.device, non_blocking=True)
+        if isinstance(img_bgr, torch.Tensor):       # frame already resident in HBM (uint8 H,W,3 BGR)
+            rgb = img_bgr.to(self.device).flip(-1)
+        else:
+            rgb = torch.from_numpy(np.ascontiguousarray(img_bgr[:, :, ::-1])).to(self.device, non_blocking=True)
         x = rgb.permute(2, 0, 1)[None].float()
         pads = pad_amounts(H0, W0)
         x = F.pad(x, list(pads), mode="replicate")

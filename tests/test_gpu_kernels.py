@@ -293,7 +293,9 @@ def test_fullsize_properties(ops_mod):
          torch.rand(1, H, W, generator=g).to(DEV))
     I = (torch.zeros(2, H, W, device=DEV), torch.zeros(1, H, W, device=DEV), torch.zeros(1, H, W, device=DEV))
     c = ops_mod.chain(I, R)
-    assert maxerr(c[0].cpu(), R[0].cpu()) < 2e-4 and maxerr(c[1].cpu(), R[1].cpu()) < 1e-4
+    # (white-noise R: the reference's normalise/un-normalise round trip moves the
+    # sample point by ~3e-5 px, times a gradient of a few units per pixel)
+    assert maxerr(c[0].cpu(), R[0].cpu()) < 1e-3 and maxerr(c[1].cpu(), R[1].cpu()) < 2e-4
     # convex upsampling of a constant field is that constant (x8 for flow) in the interior
     M = h * w
     const = torch.tensor([1.5, -2.0], device=DEV).repeat(M, 1).contiguous()
