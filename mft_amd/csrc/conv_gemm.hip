@@ -8,24 +8,37 @@
 //   * the all-pairs correlation volume f1 . f2^T / sqrt(C) (core/corr.py:53-69),
 //     with kh = kw = 1 and "weights" = the second feature map.
 //
-// Tiling: 256 threads = 4 waves; block tile BM x BN, K step 32; each wave owns
-// (BM/WM) x (BN/WN) as 32x32 v_mfma_f32_32x32x2_f32 tiles (exact fp32, 157 TF
-// peak).  Operands are staged global -> VGPR -> LDS (zero-fill for the conv
-// halo and ragged channel counts), double-buffered, rows padded to 36 floats so
-// that the ds_read_b128 fragment reads are bank-conflict free.  Each lane reads
-// 4 consecutive k of its row; lanes 0-31 take k 0..3 and lanes 32-63 k 4..7 of an
-// 8-wide group, which is a legal permutation of the reduction order as long as
-// A and B use the same one.
+// Structure (256 threads = 4 waves, block tile BM x BN, K step 32):
+//   * operands come in through raw BUFFER loads: the conv halo, ragged channel
+//     counts and the M/N tails are expressed as an out-of-range offset, which
+//     the hardware returns as zeros -- no branches, no selects in the K loop;
+//     per-row offsets are recomputed once per filter tap, per K step they only
+//     advance by 128 bytes;
+//   * global -> VGPR -> LDS staging, LDS double buffered, rows padded to 36
+//     floats so the ds_read_b128 fragment reads are bank-conflict free;
+//   * each wave owns (BM/WM) x (BN/WN) as 32x32 v_mfma_f32_32x32x2_f32 tiles
+//     (exact fp32, 157 TF peak).  A lane reads 4 consecutive k of its row; lanes
+//     0-31 take k 0..3 and lanes 32-63 k 4..7 of an 8-wide group -- a legal
+//     permutation of the reduction order as long as A and B use the same one,
+//     and the same for every tile shape (results do not depend on the tiling);
+//   * software pipeline: fragments are double buffered in registers, the next
+//     tile is written to LDS and the barrier taken BEFORE the last 8-wide k
+//     group's MFMAs, so LDS latency and barrier skew hide under matrix work.
 #include "common.h"
 #include "profile.h"
+#include <cstdlib>
 
 namespace mftx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
-constexpr int LDK = BK + 4;  // padded LDS row (floats)
+constexpr int LDK = BK + 4;              // padded LDS row (floats)
+constexpr unsigned OOB = 0x80000000u;    // buffer offset that is out of range for every operand (< 2 GiB)
+
+enum Epi { EPI_GENERIC = 0, EPI_RELU = 1, EPI_GRU_ZR = 2, EPI_GRU_Q = 3 };
 
 struct ConvArgs {
     const float *a0, *a1;
@@ -39,8 +52,8 @@ struct ConvArgs {
     int act;
     float out_scale;
     long long a_bstride, w_bstride, o_bstride;  // per blockIdx.z (correlation batch)
-    int gru_mode;
-    float *hx; int ld_hx; float *z; float *rh;
+    unsigned a0_bytes, a1_bytes, w_bytes;       // buffer extents (per batch element)
+    float *hx; int ld_hx; float *z; float *rh;  // GRU epilogues
 };
 
 __device__ __forceinline__ float act_fn(float v, int act) {
@@ -52,7 +65,11 @@ __device__ __forceinline__ float act_fn(float v, int act) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+
+template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RA = BM / 32, RB = BN / 32;
@@ -68,10 +85,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     const int wm = wid / WN, wn = wid % WN;
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    const float *a0 = p.a0 + blockIdx.z * p.a_bstride;
-    const float *a1 = p.a1;
-    const float *wgt = p.w + blockIdx.z * p.w_bstride;
     float *out = p.out + blockIdx.z * p.o_bstride;
+
+    const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.a0 + blockIdx.z * p.a_bstride), 0, p.a0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.a1 ? p.a1 : p.a0), 0, p.a1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.w + blockIdx.z * p.w_bstride), 0, p.w_bytes, 0x00020000);
 
     // ---- per-thread staging coordinates
     const int col4 = (tid & 7) * 4;
@@ -80,9 +101,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     const int hw = p.h * p.wd;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        int m = m0 + srow + 32 * i;
+        const int m = m0 + srow + 32 * i;
         if (m < p.M) {
-            int rem = m % hw;
+            const int rem = m % hw;
             ay[i] = rem / p.wd;
             ax[i] = rem - ay[i] * p.wd;
             am[i] = m;
@@ -91,42 +112,53 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
         }
     }
     const int taps = p.kh * p.kw;
-    const int cpt = p.cin_pad / BK;          // chunks per tap
+    const int cpt = p.cin_pad / BK;          // K steps per tap
     const int T = taps * cpt;
-    const long long ktot = (long long)taps * p.cin_pad;
+    const unsigned ktot_b = (unsigned)taps * p.cin_pad * 4u;
     const int py = p.kh / 2, px = p.kw / 2;
     const int ctot = p.c0 + p.c1;
 
-    f32x4 ra[RA], rb[RB];
-
-    auto load_tiles = [&](int it) {
-        const int tap = it / cpt;
-        const int cc = it - tap * cpt;
-        const int dy = tap / p.kw - py;
-        const int dx = tap % p.kw - px;
-        const int c = cc * BK + col4;
+    unsigned woff[RB];                       // byte offsets into W, advance 128 B per K step
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = n0 + srow + 32 * i;
+        woff[i] = (n < p.w_rows) ? (unsigned)n * ktot_b + col4 * 4u : OOB;
+    }
+    unsigned aoff0[RA], aoff1[RA];           // byte offsets of this tap's source cell in segment 0 / 1
+    int tap = 0, cc = 0;                     // position of the NEXT tile to fetch
+    auto set_tap = [&]() {
+        const int dy = tap / p.kw - py, dx = tap % p.kw - px;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int yy = ay[i] + dy, xx = ax[i] + dx;
-            const bool ok = (yy >= 0) & (yy < p.h) & (xx >= 0) & (xx < p.wd) & (c < ctot);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                const long long src = (long long)am[i] + dy * p.wd + dx;
-                const float *ptr = (c < p.c0) ? (a0 + src * p.lda0 + c) : (a1 + src * p.lda1 + (c - p.c0));
-                v = *reinterpret_cast<const f32x4 *>(ptr);
-            }
-            ra[i] = v;
+            const bool ok = (yy >= 0) & (yy < p.h) & (xx >= 0) & (xx < p.wd);
+            const unsigned src = (unsigned)(am[i] + dy * p.wd + dx);
+            aoff0[i] = ok ? (src * (unsigned)p.lda0 + col4) * 4u : OOB;
+            aoff1[i] = ok ? (src * (unsigned)p.lda1 + col4) * 4u : OOB;
+        }
+    };
+    set_tap();
+
+    f32x4 ra[RA], rb[RB];
+    auto fetch = [&]() {                     // global -> registers for tile (tap, cc); then advance
+        const int cbase = cc * BK;
+        const bool seg1 = cbase >= p.c0;     // wave-uniform: c0 is a multiple of BK when c1 > 0
+        const unsigned cb = (unsigned)(seg1 ? cbase - p.c0 : cbase) * 4u;
+        const bool cok = cbase + col4 < ctot;  // ragged channel count: zero-fill the tail
+        const __amdgpu_buffer_rsrc_t rA = seg1 ? rA1 : rA0;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const unsigned off = (cok ? (seg1 ? aoff1[i] : aoff0[i]) : OOB) + cb;
+            ra[i] = buf_load(rA, off);
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int n = n0 + srow + 32 * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < p.w_rows)
-                v = *reinterpret_cast<const f32x4 *>(wgt + (long long)n * ktot + (long long)it * BK + col4);
-            rb[i] = v;
+            rb[i] = buf_load(rW, woff[i]);
+            woff[i] += BK * 4u;
         }
+        if (++cc == cpt) { cc = 0; ++tap; if (tap < taps) set_tap(); }
     };
-    auto store_tiles = [&](int buf) {
+    auto stage = [&](int buf) {              // registers -> LDS
         float *as = As + buf * BM * LDK;
         float *bs = Bs + buf * BN * LDK;
 #pragma unroll
@@ -145,38 +177,50 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-
     const int a_row0 = wm * TM * 32 + (lane & 31);
     const int b_row0 = wn * TN * 32 + (lane & 31);
     const int khalf = (lane >> 5) * 4;
+    f32x4 fa[2][TM], fb[2][TN];              // register double buffer of MFMA fragments
+    auto read_frags = [&](int buf, int kk, int slot) {
+        const float *as = As + buf * BM * LDK + kk * 8 + khalf;
+        const float *bs = Bs + buf * BN * LDK + kk * 8 + khalf;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const f32x4 *>(as + (a_row0 + 32 * i) * LDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const f32x4 *>(bs + (b_row0 + 32 * j) * LDK);
+    };
+    auto mma = [&](int slot) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i][s], fb[slot][j][s], acc[i][j], 0, 0, 0);
+    };
+
+    // prologue: tile 0 -> LDS buffer 0, first fragments -> slot 0
+    fetch();
+    stage(0);
+    __syncthreads();
+    read_frags(0, 0, 0);
 
     for (int it = 0; it < T; ++it) {
         const int buf = it & 1;
-        if (it + 1 < T) load_tiles(it + 1);
-        const float *as = As + buf * BM * LDK;
-        const float *bs = Bs + buf * BN * LDK;
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            f32x4 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fa[i] = *reinterpret_cast<const f32x4 *>(as + (a_row0 + 32 * i) * LDK + kk * 8 + khalf);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fb[j] = *reinterpret_cast<const f32x4 *>(bs + (b_row0 + 32 * j) * LDK + kk * 8 + khalf);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+        const bool more = it + 1 < T;
+        if (more) fetch();                   // next tile's global loads fly under this tile's MFMAs
+        read_frags(buf, 1, 1);
+        mma(0);
+        read_frags(buf, 2, 0);
+        mma(1);
+        read_frags(buf, 3, 1);
+        mma(0);
+        if (more) {
+            stage(buf ^ 1);                  // all reads of buf^1 finished before the previous barrier
+            __syncthreads();
+            read_frags(buf ^ 1, 0, 0);       // next tile's first fragments, hidden under the last k group
         }
-        if (it + 1 < T) store_tiles(buf ^ 1);
-        __syncthreads();
+        mma(1);
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -193,27 +237,31 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
                 if (!n_ok || m >= p.M) continue;
-                float v = act_fn(acc[i][j][r] + bias, p.act) * p.out_scale;
-                if (p.gru_mode == 0) {
-                    out[(long long)m * p.ldo + n] = v;
-                } else if (p.gru_mode == 1) {     // [z | r] gates; r is folded into r*h
+                const float s = acc[i][j][r] + bias;
+                if constexpr (EPI == EPI_RELU) {
+                    out[(long long)m * p.ldo + n] = fmaxf(s, 0.f) * p.out_scale;
+                } else if constexpr (EPI == EPI_GRU_ZR) {   // [z | r] gates; r is folded into r*h
+                    const float v = 1.f / (1.f + expf(-s));
                     if (n < 128) p.z[(long long)m * 128 + n] = v;
                     else p.rh[(long long)m * 128 + (n - 128)] = v * p.hx[(long long)m * p.ld_hx + (n - 128)];
-                } else {                          // candidate q, h <- (1-z) h + z q
+                } else if constexpr (EPI == EPI_GRU_Q) {    // candidate q, h <- (1-z) h + z q
+                    const float v = tanhf(s);
                     const float zz = p.z[(long long)m * 128 + n];
                     float *hp = p.hx + (long long)m * p.ld_hx + n;
                     *hp = (1.f - zz) * (*hp) + zz * v;
+                } else {
+                    out[(long long)m * p.ldo + n] = act_fn(s, p.act) * p.out_scale;
                 }
             }
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat = PC_CONV_GEMM) {
+template <int BM, int BN, int WM, int WN, int EPI>
+static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) {
     constexpr size_t lds = 2ull * (BM + BN) * LDK * sizeof(float);
     static bool attr_set = false;
-    auto kern = conv_gemm_kernel<BM, BN, WM, WN>;
+    auto kern = conv_gemm_kernel<BM, BN, WM, WN, EPI>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -227,15 +275,38 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat =
     return check_launch("conv_gemm");
 }
 
-static int dispatch(const ConvArgs &a, int batch, hipStream_t s) {
-    // Tile choice: the largest tile that still yields >= ~1.5 workgroups per CU
-    // (256 CUs); N <= 32 (flow / OU output heads) gets a 128x32 tile.
-    const long long M = a.M, N = a.N;
-    if (N <= 32) return launch_cfg<128, 32, 4, 1>(a, batch, s);
-    auto blocks = [&](int bm, int bn) { return (long long)cdiv((int)M, bm) * cdiv((int)N, bn) * batch; };
-    if (N % 128 == 0 && blocks(128, 128) >= 384) return launch_cfg<128, 128, 2, 2>(a, batch, s);
-    if (blocks(128, 64) >= 384) return launch_cfg<128, 64, 2, 2>(a, batch, s);
-    return launch_cfg<64, 64, 2, 2>(a, batch, s);
+// tile shapes: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x32
+template <int EPI>
+static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) {
+    switch (tile) {
+        case 0: return launch_cfg<128, 128, 2, 2, EPI>(a, batch, s, cat);
+        case 1: return launch_cfg<128, 64, 2, 2, EPI>(a, batch, s, cat);
+        case 2: return launch_cfg<64, 64, 2, 2, EPI>(a, batch, s, cat);
+        default: return launch_cfg<128, 32, 4, 1, EPI>(a, batch, s, cat);
+    }
+}
+
+static int pick_tile(const ConvArgs &a, int batch) {
+    // debug/tuning override: MFTX_CONV_TILE=0..3
+    static const int forced = [] { const char *e = getenv("MFTX_CONV_TILE"); return e ? atoi(e) : -1; }();
+    if (forced >= 0 && forced <= 3) return forced;
+    // The largest tile that still yields >= ~1.5 workgroups per CU (256 CUs);
+    // N <= 32 (flow / OU output heads) gets the 128x32 tile.
+    if (a.N <= 32) return 3;
+    auto blocks = [&](int bm, int bn) { return (long long)cdiv(a.M, bm) * cdiv(a.N, bn) * batch; };
+    if (a.N % 128 == 0 && blocks(128, 128) >= 384) return 0;
+    if (blocks(128, 64) >= 384) return 1;
+    return 2;
+}
+
+static int dispatch(const ConvArgs &a, int epi, int batch, hipStream_t s, ProfCat cat) {
+    const int tile = pick_tile(a, batch);
+    switch (epi) {
+        case EPI_RELU: return launch_tile<EPI_RELU>(tile, a, batch, s, cat);
+        case EPI_GRU_ZR: return launch_tile<EPI_GRU_ZR>(tile, a, batch, s, cat);
+        case EPI_GRU_Q: return launch_tile<EPI_GRU_Q>(tile, a, batch, s, cat);
+        default: return launch_tile<EPI_GENERIC>(tile, a, batch, s, cat);
+    }
 }
 
 static int validate(const mftx_conv_desc &d) {
@@ -248,7 +319,12 @@ static int validate(const mftx_conv_desc &d) {
     if (d.lda0 % 4 || (d.c1 > 0 && d.lda1 % 4) || !aligned16(d.a0) || (d.c1 > 0 && !aligned16(d.a1)) || !aligned16(d.wpk))
         return fail(MFTX_E_ALIGN, "conv2d: operands must be 16-byte aligned");
     if (d.act < 0 || d.act > 3) return fail(MFTX_E_ARG, "conv2d: bad activation");
-    if ((long long)d.P * d.h * d.w > 0x7fffffffLL) return fail(MFTX_E_ARG, "conv2d: too many cells");
+    const long long M = (long long)d.P * d.h * d.w;
+    const long long lim = 0x7fffffffLL;      // buffer offsets are 32-bit, bit 31 marks "out of range"
+    if (M > lim || M * d.lda0 * 4 > lim || (d.c1 > 0 && M * d.lda1 * 4 > lim))
+        return fail(MFTX_E_ARG, "conv2d: activation operand exceeds 2 GiB");
+    const long long wbytes = (long long)round_up(d.N, 128) * d.kh * d.kw * round_up(d.c0 + d.c1, BK) * 4;
+    if (wbytes > lim) return fail(MFTX_E_ARG, "conv2d: weight operand exceeds 2 GiB");
     return 0;
 }
 
@@ -260,25 +336,30 @@ static ConvArgs to_args(const mftx_conv_desc &d) {
     a.cin_pad = round_up(d.c0 + d.c1, BK);
     a.w_rows = round_up(d.N, 128);
     a.act = d.act; a.out_scale = d.out_scale;
-    a.gru_mode = 0;
+    // extents: the last cell's row ends at (M-1)*lda + c
+    a.a0_bytes = (unsigned)(((long long)(a.M - 1) * d.lda0 + d.c0) * 4);
+    a.a1_bytes = d.c1 > 0 ? (unsigned)(((long long)(a.M - 1) * d.lda1 + d.c1) * 4) : 0u;
+    a.w_bytes = (unsigned)((long long)a.w_rows * d.kh * d.kw * a.cin_pad * 4);
     return a;
 }
 
 int launch_conv(const mftx_conv_desc &d, hipStream_t s) {
     if (int e = validate(d)) return e;
-    return dispatch(to_args(d), 1, s);
+    const bool relu = d.act == 1;
+    return dispatch(to_args(d), relu ? EPI_RELU : EPI_GENERIC, 1, s, PC_CONV_GEMM);
 }
 
 int launch_conv_gru(const mftx_conv_desc &d, const GruEpilogue &g, hipStream_t s) {
     if (int e = validate(d)) return e;
     ConvArgs a = to_args(d);
-    a.gru_mode = g.mode; a.hx = g.hx; a.ld_hx = g.ld_hx; a.z = g.z; a.rh = g.rh;
+    a.hx = g.hx; a.ld_hx = g.ld_hx; a.z = g.z; a.rh = g.rh;
     if ((g.mode == 1 && d.N != 256) || (g.mode == 2 && d.N != 128)) return fail(MFTX_E_ARG, "gru epilogue: bad N");
-    return dispatch(a, 1, s);
+    return dispatch(a, g.mode == 1 ? EPI_GRU_ZR : EPI_GRU_Q, 1, s, PC_CONV_GEMM);
 }
 
 // lvl0[p][i][j] = <f1[p][i][:], f2[p][j][:]> / sqrt(C)
 int launch_corr_volume(const float *f1, const float *f2, int P, int C, int N, float *lvl0, hipStream_t s) {
+    if ((long long)N * C * 4 > 0x7fffffffLL) return fail(MFTX_E_ARG, "corr_volume: feature map exceeds 2 GiB");
     ConvArgs a{};
     a.a0 = f1; a.lda0 = C; a.c0 = C; a.c1 = 0; a.a1 = nullptr; a.lda1 = 0;
     a.w = f2; a.bias = nullptr; a.out = lvl0; a.ldo = N;
@@ -286,9 +367,9 @@ int launch_corr_volume(const float *f1, const float *f2, int P, int C, int N, fl
     a.w_rows = N;
     a.act = 0; a.out_scale = 1.0f / sqrtf((float)C);
     a.a_bstride = (long long)N * C; a.w_bstride = (long long)N * C; a.o_bstride = (long long)N * N;
-    a.gru_mode = 0;
-    if (N >= 1024) return launch_cfg<128, 128, 2, 2>(a, P, s, PC_CORR_VOLUME);
-    return launch_cfg<64, 64, 2, 2>(a, P, s, PC_CORR_VOLUME);
+    a.a0_bytes = (unsigned)((long long)N * C * 4); a.a1_bytes = 0; a.w_bytes = a.a0_bytes;
+    if (N >= 1024) return launch_cfg<128, 128, 2, 2, EPI_GENERIC>(a, P, s, PC_CORR_VOLUME);
+    return launch_cfg<64, 64, 2, 2, EPI_GENERIC>(a, P, s, PC_CORR_VOLUME);
 }
 
 }  // namespace mftx

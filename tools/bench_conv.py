@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Per-layer micro-benchmark of the fp32-MFMA implicit-GEMM conv kernel
+(`mftx_conv2d`) on the shapes of the RAFT update block / OU heads, at the
+batch sizes the tracker uses (P = 7 pairs on one GPU, P = 1 when delta-sharded).
+
+    python tools/bench_conv.py [--P 7] [--h 64] [--w 64]
+"""
+import argparse
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from mft_amd import ops  # noqa: E402
+
+LAYERS = [
+    # name, cin, cout, kh, kw, calls per iteration (12 iters) or per pair
+    ("convc1 1x1 324->256", 324, 256, 1, 1, 12),
+    ("convc2 3x3 256->192", 256, 192, 3, 3, 12),
+    ("convf2 3x3 128->64", 128, 64, 3, 3, 12),
+    ("conv   3x3 256->126", 256, 126, 3, 3, 12),
+    ("gru zr 1x5 384->256", 384, 256, 1, 5, 12),
+    ("gru q  1x5 384->128", 384, 128, 1, 5, 12),
+    ("gru zr 5x1 384->256", 384, 256, 5, 1, 12),
+    ("gru q  5x1 384->128", 384, 128, 5, 1, 12),
+    ("fh1    3x3 128->256", 128, 256, 3, 3, 12),
+    ("fh2    3x3 256->2", 256, 2, 3, 3, 12),
+    ("mask0  3x3 128->256", 128, 256, 3, 3, 1),
+    ("mask2  1x1 256->576", 256, 576, 1, 1, 1),
+    ("ou1    3x3 712->256", 712, 256, 3, 3, 1),
+    ("ou2    3x3 256->3", 256, 3, 3, 3, 1),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--P", type=int, default=7)
+    ap.add_argument("--h", type=int, default=64)
+    ap.add_argument("--w", type=int, default=64)
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    P, h, w = args.P, args.h, args.w
+    M = P * h * w
+    dev = "cuda"
+    tot_t = tot_f = 0.0
+    print(f"M = {M} cells (P={P}, {h}x{w})")
+    for name, cin, cout, kh, kw, calls in LAYERS:
+        x = torch.randn(M, cin, device=dev)
+        wt = ops.pack_conv_weight(torch.randn(cout, cin, kh, kw, device=dev) * 0.05)
+        b = torch.randn(cout, device=dev)
+        for _ in range(3):
+            ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu")
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / args.reps * 1e-3
+        fl = 2.0 * M * cout * cin * kh * kw
+        tot_t += t * calls
+        tot_f += fl * calls
+        print(f"{name:24s} {t * 1e6:9.1f} us  {fl / t / 1e12:7.1f} TFLOP/s  ({fl / 1e9:6.2f} GFLOP)")
+    print(f"weighted per pair-batch: {tot_t * 1e3:.2f} ms, {tot_f / tot_t / 1e12:.1f} TFLOP/s "
+          f"({tot_f / tot_t / 157.3e12 * 100:.1f}% of 157.3)")
+
+
+if __name__ == "__main__":
+    main()
