@@ -112,7 +112,7 @@ class MFT():
         plan = self._plan()
         self.last_pairs = [(left_id, right_id) for _, left_id, _ in plan]
 
-        if self.sharder is not None and self.sharder.world_size > 1:
+        if self.sharder is not None and (self.sharder.world_size > 1 or self.C.delta_sharding == "force"):
             flow, occl, sigma, chosen = self.sharder.track_step(self, plan, input_img)
         else:
             rights = self._flows_for(plan, input_img, range(len(plan)))

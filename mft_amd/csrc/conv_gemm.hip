@@ -14,8 +14,12 @@
 //     the hardware returns as zeros -- no branches, no selects in the K loop;
 //     per-row offsets are recomputed once per filter tap, per K step they only
 //     advance by 128 bytes;
-//   * global -> VGPR -> LDS staging, LDS double buffered, rows padded to 36
-//     floats so the ds_read_b128 fragment reads are bank-conflict free;
+//   * the loads are LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging VGPRs and
+//     no ds_write pass.  An LDS-DMA lands lane-linear (1 KiB per wave
+//     instruction = 8 rows of 32 floats), so rows cannot be padded; instead the
+//     16-byte chunk c of row r is stored at chunk c ^ ((r >> 1) & 7) -- applied to
+//     the SOURCE address on the way in and to the ds_read_b128 address on the way
+//     out -- which makes the fragment reads bank-conflict free;
 //   * each wave owns (BM/WM) x (BN/WN) as 32x32 v_mfma_f32_32x32x2_f32 tiles
 //     (exact fp32, 157 TF peak).  A lane reads 4 consecutive k of its row; lanes
 //     0-31 take k 0..3 and lanes 32-63 k 4..7 of an 8-wide group -- a legal
@@ -35,7 +39,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
-constexpr int LDK = BK + 4;              // padded LDS row (floats)
+constexpr int LDK = BK;                  // LDS row (floats): unpadded, XOR-swizzled 16-byte chunks
 constexpr unsigned OOB = 0x80000000u;    // buffer offset that is out of range for every operand (< 2 GiB)
 
 enum Epi { EPI_GENERIC = 0, EPI_RELU = 1, EPI_GRU_ZR = 2, EPI_GRU_Q = 3 };
@@ -51,9 +55,11 @@ struct ConvArgs {
     int w_rows;               // valid rows of the W operand
     int act;
     float out_scale;
-    long long a_bstride, w_bstride, o_bstride;  // per blockIdx.z (correlation batch)
+    int batch;                                  // correlation volume: one GEMM per pair
+    long long a_bstride, w_bstride, o_bstride;  // per batch element
     unsigned a0_bytes, a1_bytes, w_bytes;       // buffer extents (per batch element)
     float *hx; int ld_hx; float *z; float *rh;  // GRU epilogues
+    int ablate;               // tuning only (MFTX_CONV_ABLATE): 1 no global loads, 2 + no LDS staging, 3 + no LDS reads
 };
 
 __device__ __forceinline__ float act_fn(float v, int act) {
@@ -67,6 +73,12 @@ __device__ __forceinline__ float act_fn(float v, int act) {
 
 __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+
+// 16 bytes per lane straight into LDS: the wave's 64 lanes land lane-linear at `dst` (wave-uniform);
+// an out-of-range offset stores zeros.
+__device__ __forceinline__ void buf_load_lds(__amdgpu_buffer_rsrc_t r, float *dst, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)dst, 16, voff, 0, 0, 0);
 }
 
 template <int BM, int BN, int WM, int WN, int EPI>
@@ -83,20 +95,34 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     const int lane = tid & 63;
     const int wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-    float *out = p.out + blockIdx.z * p.o_bstride;
+    const int srow = tid >> 3;  // 0..31: staging row of this lane within a 32-row group
+    // this lane's LDS chunk (tid & 7) receives logical chunk (tid & 7) ^ swz(row); rows advance by
+    // 32 per group, so swz = (row >> 1) & 7 depends on srow only
+    const int col4 = ((tid & 7) ^ ((srow >> 1) & 7)) * 4;
+
+    // Persistent workgroups: tile t of the (batch, M/BM, N/BN) grid goes to
+    // workgroup t mod gridDim.x.  The hardware dispatcher fills free slots
+    // greedily, which leaves whole CUs idle in a ragged last round (7 * 2^k tiles
+    // on 2^k slots = 12.5 % loss); a fixed round-robin keeps every CU equally loaded.
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_mn = ((p.M + BM - 1) / BM) * tiles_n;
+    const int n_tiles = tiles_mn * p.batch;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int bz = tile / tiles_mn;
+    const int tmn = tile - bz * tiles_mn;
+    const int m0 = (tmn / tiles_n) * BM;
+    const int n0 = (tmn % tiles_n) * BN;
+    float *out = p.out + bz * p.o_bstride;
+    if (tile != (int)blockIdx.x) __syncthreads();   // previous tile's last LDS reads are done
 
     const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.a0 + blockIdx.z * p.a_bstride), 0, p.a0_bytes, 0x00020000);
+        const_cast<float *>(p.a0 + bz * p.a_bstride), 0, p.a0_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rA1 =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.a1 ? p.a1 : p.a0), 0, p.a1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(p.w + blockIdx.z * p.w_bstride), 0, p.w_bytes, 0x00020000);
+        const_cast<float *>(p.w + bz * p.w_bstride), 0, p.w_bytes, 0x00020000);
 
     // ---- per-thread staging coordinates
-    const int col4 = (tid & 7) * 4;
-    const int srow = tid >> 3;  // 0..31
     int ay[RA], ax[RA], am[RA];
     const int hw = p.h * p.wd;
 #pragma unroll
@@ -139,34 +165,26 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     };
     set_tap();
 
-    f32x4 ra[RA], rb[RB];
-    auto fetch = [&]() {                     // global -> registers for tile (tap, cc); then advance
+    auto fetch = [&](int buf) {              // global -> LDS (DMA) for tile (tap, cc); then advance
         const int cbase = cc * BK;
         const bool seg1 = cbase >= p.c0;     // wave-uniform: c0 is a multiple of BK when c1 > 0
         const unsigned cb = (unsigned)(seg1 ? cbase - p.c0 : cbase) * 4u;
         const bool cok = cbase + col4 < ctot;  // ragged channel count: zero-fill the tail
         const __amdgpu_buffer_rsrc_t rA = seg1 ? rA1 : rA0;
+        // wave `wid` fills rows [32 i + 8 wid, +8) of each 32-row group: 1 KiB, lane-linear
+        float *as = As + buf * BM * LDK + wid * 8 * LDK;
+        float *bs = Bs + buf * BN * LDK + wid * 8 * LDK;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const unsigned off = (cok ? (seg1 ? aoff1[i] : aoff0[i]) : OOB) + cb;
-            ra[i] = buf_load(rA, off);
+            buf_load_lds(rA, as + 32 * i * LDK, off);
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            rb[i] = buf_load(rW, woff[i]);
+            buf_load_lds(rW, bs + 32 * i * LDK, woff[i]);
             woff[i] += BK * 4u;
         }
         if (++cc == cpt) { cc = 0; ++tap; if (tap < taps) set_tap(); }
-    };
-    auto stage = [&](int buf) {              // registers -> LDS
-        float *as = As + buf * BM * LDK;
-        float *bs = Bs + buf * BN * LDK;
-#pragma unroll
-        for (int i = 0; i < RA; ++i)
-            *reinterpret_cast<f32x4 *>(as + (srow + 32 * i) * LDK + col4) = ra[i];
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-            *reinterpret_cast<f32x4 *>(bs + (srow + 32 * i) * LDK + col4) = rb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -179,15 +197,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
 
     const int a_row0 = wm * TM * 32 + (lane & 31);
     const int b_row0 = wn * TN * 32 + (lane & 31);
-    const int khalf = (lane >> 5) * 4;
+    const int khalf = lane >> 5;             // lanes 0-31: chunk 2kk, lanes 32-63: chunk 2kk+1
+    const int a_sw = (a_row0 >> 1) & 7, b_sw = (b_row0 >> 1) & 7;   // same for every 32-row step
     f32x4 fa[2][TM], fb[2][TN];              // register double buffer of MFMA fragments
     auto read_frags = [&](int buf, int kk, int slot) {
-        const float *as = As + buf * BM * LDK + kk * 8 + khalf;
-        const float *bs = Bs + buf * BN * LDK + kk * 8 + khalf;
+        const float *as = As + buf * BM * LDK + a_row0 * LDK + (((kk * 2 + khalf) ^ a_sw) * 4);
+        const float *bs = Bs + buf * BN * LDK + b_row0 * LDK + (((kk * 2 + khalf) ^ b_sw) * 4);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const f32x4 *>(as + (a_row0 + 32 * i) * LDK);
+        for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const f32x4 *>(as + 32 * i * LDK);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const f32x4 *>(bs + (b_row0 + 32 * j) * LDK);
+        for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const f32x4 *>(bs + 32 * j * LDK);
     };
     auto mma = [&](int slot) {
 #pragma unroll
@@ -200,26 +219,24 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     };
 
     // prologue: tile 0 -> LDS buffer 0, first fragments -> slot 0
-    fetch();
-    stage(0);
-    __syncthreads();
+    fetch(0);
+    __syncthreads();                         // drains the DMA (vmcnt(0)) and publishes it to all waves
     read_frags(0, 0, 0);
 
     for (int it = 0; it < T; ++it) {
         const int buf = it & 1;
         const bool more = it + 1 < T;
-        if (more) fetch();                   // next tile's global loads fly under this tile's MFMAs
-        read_frags(buf, 1, 1);
+        // next tile's DMA flies under this tile's MFMAs; every wave finished reading buf^1 before
+        // the previous barrier
+        if (more && p.ablate < 1) fetch(buf ^ 1);
+        if (p.ablate < 3) read_frags(buf, 1, 1);
         mma(0);
-        read_frags(buf, 2, 0);
+        if (p.ablate < 3) read_frags(buf, 2, 0);
         mma(1);
-        read_frags(buf, 3, 1);
+        if (p.ablate < 3) read_frags(buf, 3, 1);
         mma(0);
-        if (more) {
-            stage(buf ^ 1);                  // all reads of buf^1 finished before the previous barrier
-            __syncthreads();
-            read_frags(buf ^ 1, 0, 0);       // next tile's first fragments, hidden under the last k group
-        }
+        if (more && p.ablate < 2) __syncthreads();   // vmcnt(0) + barrier: the next tile is in LDS
+        if (more && p.ablate < 3) read_frags(buf ^ 1, 0, 0);   // next tile's first fragments, hidden under the last k group
         mma(1);
     }
 
@@ -255,6 +272,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
             }
         }
     }
+    }  // persistent tile loop
+}
+
+static int num_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                cus = prop.multiProcessorCount;
+        }
+        return cus;
+    }();
+    return n;
 }
 
 template <int BM, int BN, int WM, int WN, int EPI>
@@ -268,10 +299,18 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) 
         if (e != hipSuccess) return fail((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), batch);
+    ConvArgs args = a;
+    args.batch = batch;
+    static const int ablate = [] { const char *e = getenv("MFTX_CONV_ABLATE"); return e ? atoi(e) : 0; }();
+    args.ablate = ablate;
+    // resident workgroups per CU: LDS-bound (160 KiB per CU), at most 4 (16 waves)
+    constexpr int resident = (160 * 1024) / (int)lds < 4 ? (160 * 1024) / (int)lds : 4;
+    const long long n_tiles = (long long)cdiv(a.M, BM) * cdiv(a.N, BN) * batch;
+    const long long slots = (long long)num_cus() * resident;
+    dim3 grid((unsigned)(n_tiles < slots ? n_tiles : slots));
     // algorithmic flops: real (unpadded) reduction length
     ProfScope prof(cat, s, 2.0 * a.M * a.N * (double)(a.kh * a.kw) * (a.c0 + a.c1) * batch);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, args);
     return check_launch("conv_gemm");
 }
 
@@ -345,6 +384,7 @@ static ConvArgs to_args(const mftx_conv_desc &d) {
 
 int launch_conv(const mftx_conv_desc &d, hipStream_t s) {
     if (int e = validate(d)) return e;
+    if (conv_small_applicable(d)) return launch_conv_small(d, s);   // N <= 4: VALU kernel, no MFMA padding waste
     const bool relu = d.act == 1;
     return dispatch(to_args(d), relu ? EPI_RELU : EPI_GENERIC, 1, s, PC_CONV_GEMM);
 }

@@ -80,7 +80,6 @@ int launch_corr_pool(const float *lvl0, int rows, int h, int w, float *lvl1, flo
 // c/2^l + (a-4) agrees to O(1e-6 * |grad V|).
 // ---------------------------------------------------------------------------
 constexpr int LK_WAVES = 4;
-constexpr int LK_TAPS = 400;   // 4 levels x 10 x 10
 
 struct LookupArgs {
     const float *lvl[4];
@@ -93,7 +92,7 @@ struct LookupArgs {
 };
 
 __global__ __launch_bounds__(64 * LK_WAVES) void corr_lookup_kernel(LookupArgs p) {
-    __shared__ float taps[LK_WAVES][LK_TAPS + 16];
+    __shared__ float taps[LK_WAVES][4 * 128];   // 100 taps per level, padded to 128 slots
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     float *tp = taps[wv];
@@ -109,12 +108,19 @@ __global__ __launch_bounds__(64 * LK_WAVES) void corr_lookup_kernel(LookupArgs p
         const int rem = o - l * 81;
         const int a = rem / 9, b = rem - a * 9;   // a offsets x, b offsets y
         o_lvl[j] = l;
-        o_off[j] = l * 100 + b * 10 + a;          // tap (row b, col a) of level l
+        o_off[j] = l * 128 + b * 10 + a;          // tap (row b, col a) of level l
     }
 
-    for (int cell = blockIdx.x * LK_WAVES + wv; cell < p.cells; cell += gridDim.x * LK_WAVES) {
+    for (int cell_v = blockIdx.x * LK_WAVES + wv; cell_v < p.cells; cell_v += gridDim.x * LK_WAVES) {
+        // one cell per wave: make that provable so the buffer descriptors stay in SGPRs
+        const int cell = __builtin_amdgcn_readfirstlane(cell_v);
         const float2 c = reinterpret_cast<const float2 *>(p.coords)[cell];
         float fx[4], fy[4];
+        float t0[4], t1[4];
+        // Issue all 8 tap loads of the cell back to back.  Each level slice is its
+        // own buffer; taps outside the slice get an out-of-range offset, which
+        // the hardware returns as 0 (= grid_sample's zero padding) -- no branches,
+        // so the 8 round trips overlap instead of serialising.
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             const float sx = c.x / (float)(1 << l), sy = c.y / (float)(1 << l);
@@ -124,19 +130,25 @@ __global__ __launch_bounds__(64 * LK_WAVES) void corr_lookup_kernel(LookupArgs p
             const int x0 = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f) - 4;
             const int y0 = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f) - 4;
             const int H = p.hl[l], W = p.wl[l];
-            const float *base = p.lvl[l] + (long long)cell * H * W;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(p.lvl[l] + (long long)cell * H * W), 0, (unsigned)(H * W * 4), 0x00020000);
             {
                 const int yy = y0 + tr0, xx = x0 + tc0;
-                float v = 0.f;
-                if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = base[yy * W + xx];
-                tp[l * 100 + lane] = v;
+                const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+                t0[l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rs, ok ? (unsigned)(yy * W + xx) * 4u : 0x80000000u, 0, 0));
             }
-            if (lane < 36) {
+            {
                 const int yy = y0 + tr1, xx = x0 + tc1;
-                float v = 0.f;
-                if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = base[yy * W + xx];
-                tp[l * 100 + 64 + lane] = v;
+                const bool ok = (lane < 36) & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+                t1[l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                      rs, ok ? (unsigned)(yy * W + xx) * 4u : 0x80000000u, 0, 0));
             }
+        }
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            tp[l * 128 + lane] = t0[l];
+            tp[l * 128 + 64 + lane] = t1[l];          // lanes >= 36 park zeros in the padding
         }
         // LDS operations of one wave complete in issue order, so the wave can
         // read back what its other lanes just wrote without a barrier.
