@@ -100,20 +100,30 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     // 32 per group, so swz = (row >> 1) & 7 depends on srow only
     const int col4 = ((tid & 7) ^ ((srow >> 1) & 7)) * 4;
 
-    // Persistent workgroups: tile t of the (batch, M/BM, N/BN) grid goes to
-    // workgroup t mod gridDim.x.  The hardware dispatcher fills free slots
-    // greedily, which leaves whole CUs idle in a ragged last round (7 * 2^k tiles
-    // on 2^k slots = 12.5 % loss); a fixed round-robin keeps every CU equally loaded.
+    // Persistent workgroups with an XCD-aware tile order.  The hardware dispatcher
+    // fills free slots greedily, which leaves whole CUs idle in a ragged last
+    // round (7 * 2^k tiles on 2^k slots); a fixed round-robin keeps every CU
+    // equally loaded.  Workgroup b runs on XCD b % 8 (observed; only speed depends
+    // on it), so virtual tile v is decoded as xcd = v % 8, and each XCD walks its
+    // own contiguous band of M tiles with the N tiles innermost: the column tiles
+    // of one A tile and the 3x3 halo rows of neighbouring A tiles then meet in
+    // the same 4 MiB L2 instead of being fetched once per XCD.
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tiles_mn = ((p.M + BM - 1) / BM) * tiles_n;
-    const int n_tiles = tiles_mn * p.batch;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int bz = tile / tiles_mn;
-    const int tmn = tile - bz * tiles_mn;
-    const int m0 = (tmn / tiles_n) * BM;
-    const int n0 = (tmn % tiles_n) * BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int band = (tiles_m + 7) / 8;               // M tiles per XCD
+    const int per_batch = band * tiles_n;              // virtual tiles per XCD per batch element
+    const int n_virtual = 8 * per_batch * p.batch;
+    for (int vt = blockIdx.x; vt < n_virtual; vt += gridDim.x) {
+    const int xcd = vt & 7;
+    const int q = vt >> 3;
+    const int bz = q / per_batch;
+    const int r = q - bz * per_batch;
+    const int tm = xcd * band + r / tiles_n;
+    if (tm >= tiles_m) continue;                       // ragged band (uniform per workgroup)
+    const int m0 = tm * BM;
+    const int n0 = (r % tiles_n) * BN;
     float *out = p.out + bz * p.o_bstride;
-    if (tile != (int)blockIdx.x) __syncthreads();   // previous tile's last LDS reads are done
+    __syncthreads();                                   // previous tile's last LDS reads are done
 
     const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.a0 + bz * p.a_bstride), 0, p.a0_bytes, 0x00020000);
@@ -305,9 +315,9 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) 
     args.ablate = ablate;
     // resident workgroups per CU: LDS-bound (160 KiB per CU), at most 4 (16 waves)
     constexpr int resident = (160 * 1024) / (int)lds < 4 ? (160 * 1024) / (int)lds : 4;
-    const long long n_tiles = (long long)cdiv(a.M, BM) * cdiv(a.N, BN) * batch;
+    const long long n_virtual = 8ll * cdiv(cdiv(a.M, BM), 8) * cdiv(a.N, BN) * batch;
     const long long slots = (long long)num_cus() * resident;
-    dim3 grid((unsigned)(n_tiles < slots ? n_tiles : slots));
+    dim3 grid((unsigned)(n_virtual < slots ? n_virtual : slots));
     // algorithmic flops: real (unpadded) reduction length
     ProfScope prof(cat, s, 2.0 * a.M * a.N * (double)(a.kh * a.kw) * (a.c0 + a.c1) * batch);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, args);
@@ -329,12 +339,15 @@ static int pick_tile(const ConvArgs &a, int batch) {
     // debug/tuning override: MFTX_CONV_TILE=0..3
     static const int forced = [] { const char *e = getenv("MFTX_CONV_TILE"); return e ? atoi(e) : -1; }();
     if (forced >= 0 && forced <= 3) return forced;
-    // The largest tile that still yields >= ~1.5 workgroups per CU (256 CUs);
-    // N <= 32 (flow / OU output heads) gets the 128x32 tile.
+    // Measured on MI355X (tools/bench_conv.py, M = 7 x 4096 and 4096): the 64x64
+    // tile (4 workgroups per CU, LDS-bound) wins or ties on every layer -- more
+    // resident waves hide the LDS-DMA latency better than bigger tiles save on
+    // operand re-reads -- except for N = 192 (convc2), where 128x64 avoids a
+    // half-empty column tile.  N <= 32 (only reached when the small-N VALU
+    // kernel does not apply) gets the 128x32 tile.
+    (void)batch;
     if (a.N <= 32) return 3;
-    auto blocks = [&](int bm, int bn) { return (long long)cdiv(a.M, bm) * cdiv(a.N, bn) * batch; };
-    if (a.N % 128 == 0 && blocks(128, 128) >= 384) return 0;
-    if (blocks(128, 64) >= 384) return 1;
+    if (a.N > 128 && a.N % 128 == 64) return 1;
     return 2;
 }
 
