@@ -81,15 +81,28 @@ __device__ __forceinline__ void buf_load_lds(__amdgpu_buffer_rsrc_t r, float *ds
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)dst, 16, voff, 0, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+// s_barrier with compiler fences on both sides (the intrinsic alone does not order LDS accesses)
+__device__ __forceinline__ void block_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {   // counted wait: leaves N LDS-DMA loads in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, int NS>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RA = BM / 32, RB = BN / 32;
     static_assert(WM * WN == 4, "4 waves");
     static_assert(TM >= 1 && TN >= 1, "tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;                       // [2][BM][LDK]
-    float *Bs = smem + 2 * BM * LDK;        // [2][BN][LDK]
+    float *As = smem;                       // [NS][BM][LDK]  (ring of NS tiles)
+    float *Bs = smem + NS * BM * LDK;       // [NS][BN][LDK]
+    constexpr int L = RA + RB;              // LDS-DMA instructions per thread per tile
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -123,7 +136,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     const int m0 = tm * BM;
     const int n0 = (r % tiles_n) * BN;
     float *out = p.out + bz * p.o_bstride;
-    __syncthreads();                                   // previous tile's last LDS reads are done
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    block_barrier();                      // previous tile's last LDS reads are done
 
     const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.a0 + bz * p.a_bstride), 0, p.a0_bytes, 0x00020000);
@@ -228,26 +242,38 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i][s], fb[slot][j][s], acc[i][j], 0, 0, 0);
     };
 
-    // prologue: tile 0 -> LDS buffer 0, first fragments -> slot 0
-    fetch(0);
-    __syncthreads();                         // drains the DMA (vmcnt(0)) and publishes it to all waves
+    // prologue: tiles 0 .. NS-2 in flight, tile 0 landed, first fragments -> slot 0
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < T) fetch(st);
+    if (T >= NS - 1) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+    block_barrier();
     read_frags(0, 0, 0);
 
+    int buf = 0, nbuf = (NS > 1) ? 1 : 0, fbuf = NS - 1;   // ring slots: current, next, the one to refill
     for (int it = 0; it < T; ++it) {
-        const int buf = it & 1;
         const bool more = it + 1 < T;
-        // next tile's DMA flies under this tile's MFMAs; every wave finished reading buf^1 before
-        // the previous barrier
-        if (more && p.ablate < 1) fetch(buf ^ 1);
+        // refill the slot every wave finished reading before the previous barrier; the DMA has
+        // NS-1 tiles of MFMA work to land
+        if (it + NS - 1 < T && p.ablate < 1) fetch(fbuf);
         if (p.ablate < 3) read_frags(buf, 1, 1);
         mma(0);
         if (p.ablate < 3) read_frags(buf, 2, 0);
         mma(1);
         if (p.ablate < 3) read_frags(buf, 3, 1);
         mma(0);
-        if (more && p.ablate < 2) __syncthreads();   // vmcnt(0) + barrier: the next tile is in LDS
-        if (more && p.ablate < 3) read_frags(buf ^ 1, 0, 0);   // next tile's first fragments, hidden under the last k group
+        if (more && p.ablate < 2) {
+            // own LDS reads of `buf` done (lgkmcnt), own DMA of tile it+1 landed (counted vmcnt:
+            // the NS-2 younger tiles stay in flight), then every wave agrees (barrier)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (it + NS - 1 < T) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+            block_barrier();
+        }
+        if (more && p.ablate < 3) read_frags(nbuf, 0, 0);   // next tile's first fragments, hidden under the last k group
         mma(1);
+        buf = nbuf;
+        nbuf = (nbuf + 1 == NS) ? 0 : nbuf + 1;
+        fbuf = (fbuf + 1 == NS) ? 0 : fbuf + 1;
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -298,11 +324,11 @@ static int num_cus() {
     return n;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int NS>
 static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) {
-    constexpr size_t lds = 2ull * (BM + BN) * LDK * sizeof(float);
+    constexpr size_t lds = (size_t)NS * (BM + BN) * LDK * sizeof(float);
     static bool attr_set = false;
-    auto kern = conv_gemm_kernel<BM, BN, WM, WN, EPI>;
+    auto kern = conv_gemm_kernel<BM, BN, WM, WN, EPI, NS>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -324,14 +350,16 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) 
     return check_launch("conv_gemm");
 }
 
-// tile shapes: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x32
+// tile shapes: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x32.  The LDS ring depth NS is a template
+// parameter of the kernel; rings of 3 and 4 tiles (counted vmcnt) were measured and do not pay at
+// either M = 28672 or M = 4096 (tools/bench_conv.py), so only NS = 2 is instantiated.
 template <int EPI>
 static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) {
     switch (tile) {
-        case 0: return launch_cfg<128, 128, 2, 2, EPI>(a, batch, s, cat);
-        case 1: return launch_cfg<128, 64, 2, 2, EPI>(a, batch, s, cat);
-        case 2: return launch_cfg<64, 64, 2, 2, EPI>(a, batch, s, cat);
-        default: return launch_cfg<128, 32, 4, 1, EPI>(a, batch, s, cat);
+        case 0: return launch_cfg<128, 128, 2, 2, EPI, 2>(a, batch, s, cat);
+        case 1: return launch_cfg<128, 64, 2, 2, EPI, 2>(a, batch, s, cat);
+        case 2: return launch_cfg<64, 64, 2, 2, EPI, 2>(a, batch, s, cat);
+        default: return launch_cfg<128, 32, 4, 1, EPI, 2>(a, batch, s, cat);
     }
 }
 
@@ -421,8 +449,8 @@ int launch_corr_volume(const float *f1, const float *f2, int P, int C, int N, fl
     a.act = 0; a.out_scale = 1.0f / sqrtf((float)C);
     a.a_bstride = (long long)N * C; a.w_bstride = (long long)N * C; a.o_bstride = (long long)N * N;
     a.a0_bytes = (unsigned)((long long)N * C * 4); a.a1_bytes = 0; a.w_bytes = a.a0_bytes;
-    if (N >= 1024) return launch_cfg<128, 128, 2, 2, EPI_GENERIC>(a, P, s, PC_CORR_VOLUME);
-    return launch_cfg<64, 64, 2, 2, EPI_GENERIC>(a, P, s, PC_CORR_VOLUME);
+    if (N >= 1024) return launch_cfg<128, 128, 2, 2, EPI_GENERIC, 2>(a, P, s, PC_CORR_VOLUME);
+    return launch_cfg<64, 64, 2, 2, EPI_GENERIC, 2>(a, P, s, PC_CORR_VOLUME);
 }
 
 }  // namespace mftx

@@ -181,3 +181,38 @@ def test_result_api(flower):
     assert torch.allclose(r2.warp_forward_points(pts), pts + 1)
     f, o, s = r2.sample(pts)
     assert f.shape == (2, 2) and o.shape == (1, 2)
+
+
+def test_compute_flow_540p_odd_pyramid_vs_oracle(flower, weights_cpu):
+    """544x960 (half of BASELINE config 5's 1080p): 68x120 grid, pyramid
+    68->34->17->8 (a floored level), N = 8160 not a power of two."""
+    vid = SyntheticVideo(544, 960, n_frames=4, seed=13)
+    flower.C.flow_iters = 3
+    try:
+        flow, extra = flower.compute_flow(vid[0], vid[2], mode="flow")
+    finally:
+        flower.C.flow_iters = 12
+    with torch.no_grad():
+        rf, ro, rs = O.compute_flow(weights_cpu, vid[0], vid[2], 3)
+    e = epe(flow.cpu(), rf)
+    assert e.mean() < 1e-3 and e.max() < 1e-2, (float(e.mean()), float(e.max()))
+    assert (extra["occlusion"].cpu() - ro).abs().max() < 2e-3
+    assert ((extra["sigma"].cpu() - rs).abs() / rs).max() < 2e-3
+
+
+def test_compute_flow_1080p_smoke(flower):
+    """BASELINE config 5 size (1080x1920, 135x240 grid, 4.2 GB level-0 volume per
+    pair): runs, is finite, and a pair's result does not depend on batching."""
+    vid = SyntheticVideo(1080, 1920, n_frames=3, seed=17)
+    flower.C.flow_iters = 2
+    try:
+        a = flower.compute_flow_many([(None, vid[0])], (None, vid[2]))
+        b = flower.compute_flow_many([(None, vid[1]), (None, vid[0])], (None, vid[2]))
+    finally:
+        flower.C.flow_iters = 12
+    for t in a[0]:
+        assert bool(torch.isfinite(t).all())
+    assert a[0][0].shape == (2, 1080, 1920)
+    for x, y in zip(a[0], b[1]):
+        assert torch.equal(x, y)
+    torch.cuda.empty_cache()
