@@ -78,8 +78,10 @@ int mftx_corr_lookup(const float *lvl0, const float *lvl1, const float *lvl2, co
  * the channel axis (c0 % 32 == 0 when c1 > 0).  wpk: weights packed
  * [n_pad][kh*kw][cin_pad] (cin_pad = round_up(c0+c1, 32), n_pad =
  * round_up(N, 128), zero filled), tap index = ky*kw + kx.
- * out[m][n] = out_scale * act(conv + bias).  act: 0 none, 1 relu, 2 sigmoid,
- * 3 tanh. */
+ * out[m][n] = out_scale * act(conv + bias + addend[m][n]).  act: 0 none, 1 relu,
+ * 2 sigmoid, 3 tanh.  addend (optional, pixel-major [M][ld_addend]) carries a
+ * pre-computed partial convolution: the engine uses it to evaluate the
+ * iteration-invariant "inp" third of the GRU gate convolutions once per pair. */
 typedef struct mftx_conv_desc {
     const float *a0; int lda0; int c0;
     const float *a1; int lda1; int c1;
@@ -90,6 +92,7 @@ typedef struct mftx_conv_desc {
     int kh, kw;
     int act;
     float out_scale;
+    const float *addend; int ld_addend;
 } mftx_conv_desc;
 int mftx_conv2d(const mftx_conv_desc *d, void *stream);
 
@@ -99,7 +102,7 @@ int mftx_conv2d(const mftx_conv_desc *d, void *stream);
  * once.  mftx_raft_create keeps pointers to packed weights (see
  * mft_amd/raft.py:pack_weights for the order). */
 typedef struct mftx_raft mftx_raft;
-#define MFTX_RAFT_NUM_WEIGHTS 30
+#define MFTX_RAFT_NUM_WEIGHTS 34
 int mftx_raft_create(const float *const *weights, int n_weights, mftx_raft **out);
 void mftx_raft_destroy(mftx_raft *r);
 size_t mftx_raft_workspace_bytes(int P, int h, int w);

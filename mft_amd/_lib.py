@@ -10,7 +10,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libmftx.so"
 
 MAX_CANDIDATES = 16
-NUM_RAFT_WEIGHTS = 30
+NUM_RAFT_WEIGHTS = 34
 
 
 class ConvDesc(C.Structure):
@@ -20,7 +20,8 @@ class ConvDesc(C.Structure):
                 ("out", C.c_void_p), ("ldo", C.c_int),
                 ("P", C.c_int), ("h", C.c_int), ("w", C.c_int),
                 ("N", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
-                ("act", C.c_int), ("out_scale", C.c_float)]
+                ("act", C.c_int), ("out_scale", C.c_float),
+                ("addend", C.c_void_p), ("ld_addend", C.c_int)]
 
 
 _PP = C.POINTER(C.c_void_p)

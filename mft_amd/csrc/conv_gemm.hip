@@ -49,6 +49,7 @@ struct ConvArgs {
     int lda0, lda1, c0, c1;
     const float *w;
     const float *bias;
+    const float *addend; int ld_addend;   // optional per-output partial sum (pre-computed inp part of a GRU gate)
     float *out;
     int ldo;
     int M, N, h, wd, kh, kw, cin_pad;
@@ -290,7 +291,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
                 if (!n_ok || m >= p.M) continue;
-                const float s = acc[i][j][r] + bias;
+                float s = acc[i][j][r] + bias;
+                if (p.addend != nullptr) s += p.addend[(long long)m * p.ld_addend + n];
                 if constexpr (EPI == EPI_RELU) {
                     out[(long long)m * p.ldo + n] = fmaxf(s, 0.f) * p.out_scale;
                 } else if constexpr (EPI == EPI_GRU_ZR) {   // [z | r] gates; r is folded into r*h
@@ -416,6 +418,7 @@ static ConvArgs to_args(const mftx_conv_desc &d) {
     a.cin_pad = round_up(d.c0 + d.c1, BK);
     a.w_rows = round_up(d.N, 128);
     a.act = d.act; a.out_scale = d.out_scale;
+    a.addend = d.addend; a.ld_addend = d.ld_addend;
     // extents: the last cell's row ends at (M-1)*lda + c
     a.a0_bytes = (unsigned)(((long long)(a.M - 1) * d.lda0 + d.c0) * 4);
     a.a1_bytes = d.c1 > 0 ? (unsigned)(((long long)(a.M - 1) * d.lda1 + d.c1) * 4) : 0u;
@@ -425,7 +428,7 @@ static ConvArgs to_args(const mftx_conv_desc &d) {
 
 int launch_conv(const mftx_conv_desc &d, hipStream_t s) {
     if (int e = validate(d)) return e;
-    if (conv_small_applicable(d)) return launch_conv_small(d, s);   // N <= 4: VALU kernel, no MFMA padding waste
+    if (d.addend == nullptr && conv_small_applicable(d)) return launch_conv_small(d, s);   // N <= 4: VALU kernel, no MFMA padding waste
     const bool relu = d.act == 1;
     return dispatch(to_args(d), relu ? EPI_RELU : EPI_GENERIC, 1, s, PC_CONV_GEMM);
 }

@@ -116,7 +116,9 @@ __global__ void ou_gather_kernel(const float *__restrict__ hx, const float *__re
 // ---------------------------------------------------------------------------
 enum WeightSlot {
     W_CONVC1, B_CONVC1, W_CONVC2, B_CONVC2, W_CONVF1, B_CONVF1, W_CONVF2, B_CONVF2, W_CONV, B_CONV,
-    W_ZR1, B_ZR1, W_Q1, B_Q1, W_ZR2, B_ZR2, W_Q2, B_Q2,
+    // GRU gates: *_DYN = columns of [h | motion] (evaluated every iteration), *_INP = columns of the
+    // context features `inp` (evaluated once per pair, with the bias)
+    W_ZR1_DYN, W_ZR1_INP, B_ZR1, W_Q1_DYN, W_Q1_INP, B_Q1, W_ZR2_DYN, W_ZR2_INP, B_ZR2, W_Q2_DYN, W_Q2_INP, B_Q2,
     W_FH1, B_FH1, W_FH2, B_FH2, W_MASK0, B_MASK0, W_MASK2, B_MASK2,
     W_OU1, B_OU1, W_OU2, B_OU2, W_COUNT
 };
@@ -124,6 +126,7 @@ enum WeightSlot {
 struct Workspace {
     float *lvl[4];
     float *coords1, *corr, *cor1, *corflo, *flo1, *hx, *z, *rh, *fh, *delta, *mask, *ouin, *ouh, *ou, *flow_lr;
+    float *pre_zr[2], *pre_q[2];   // inp part of the GRU gate convolutions (+ bias), per pass
     size_t bytes;
 };
 
@@ -152,6 +155,7 @@ static Workspace carve(void *base, int P, int h, int w) {
     ws.ouh = take(M * 256);
     ws.ou = take(M * 4);
     ws.flow_lr = take(M * 2);
+    for (int pass = 0; pass < 2; ++pass) { ws.pre_zr[pass] = take(M * 256); ws.pre_q[pass] = take(M * 128); }
     ws.bytes = off;
     return ws;
 }
@@ -207,8 +211,10 @@ extern "C" int mftx_raft_workspace_layout(int P, int h, int w, size_t *offsets, 
 
 static mftx_conv_desc conv_desc(const float *a0, int lda0, int c0, const float *a1, int lda1, int c1,
                                 const float *w, const float *b, float *out, int ldo, int P, int h, int wd, int N,
-                                int kh, int kw, int act, float scale = 1.f) {
+                                int kh, int kw, int act, float scale = 1.f, const float *addend = nullptr,
+                                int ld_addend = 0) {
     mftx_conv_desc d{};
+    d.addend = addend; d.ld_addend = ld_addend;
     d.a0 = a0; d.lda0 = lda0; d.c0 = c0; d.a1 = a1; d.lda1 = lda1; d.c1 = c1;
     d.wpk = w; d.bias = b; d.out = out; d.ldo = ldo; d.P = P; d.h = h; d.w = wd; d.N = N;
     d.kh = kh; d.kw = kw; d.act = act; d.out_scale = scale;
@@ -249,6 +255,14 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
                            ws.hx, ws.coords1, M, h, w);
         TRY(check_launch("init_state"));
     }
+    // The gate convolutions are linear in their input [h | inp | motion] and `inp` does not change
+    // over the iterations (core/raft.py:146-149): its third of every gate sum (+ bias) is computed
+    // once here and enters the per-iteration GEMMs as an epilogue addend.  Same terms, summed once.
+    for (int pass = 0; pass < 2; ++pass) {
+        const int kh = pass ? 5 : 1, kw = pass ? 1 : 5;
+        TRY(launch_conv(conv_desc(ws.hx + 128, 384, 128, nullptr, 0, 0, W[pass ? W_ZR2_INP : W_ZR1_INP], W[pass ? B_ZR2 : B_ZR1], ws.pre_zr[pass], 256, P, h, w, 256, kh, kw, 0), s));
+        TRY(launch_conv(conv_desc(ws.hx + 128, 384, 128, nullptr, 0, 0, W[pass ? W_Q2_INP : W_Q1_INP], W[pass ? B_Q2 : B_Q1], ws.pre_q[pass], 128, P, h, w, 128, kh, kw, 0), s));
+    }
     const float *lv[4] = {ws.lvl[0], ws.lvl[1], ws.lvl[2], ws.lvl[3]};
     const int strips = cdiv(w, F1_CELLS);
     for (int it = 0; it < iters; ++it) {
@@ -269,9 +283,9 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         for (int pass = 0; pass < 2; ++pass) {
             const int kh = pass ? 5 : 1, kw = pass ? 1 : 5;
             GruEpilogue g1{1, ws.hx, 384, ws.z, ws.rh};
-            TRY(launch_conv_gru(conv_desc(ws.hx, 384, 384, nullptr, 0, 0, W[pass ? W_ZR2 : W_ZR1], W[pass ? B_ZR2 : B_ZR1], ws.z, 128, P, h, w, 256, kh, kw, 2), g1, s));
+            TRY(launch_conv_gru(conv_desc(ws.hx, 384, 128, ws.hx + 256, 384, 128, W[pass ? W_ZR2_DYN : W_ZR1_DYN], nullptr, ws.z, 128, P, h, w, 256, kh, kw, 2, 1.f, ws.pre_zr[pass], 256), g1, s));
             GruEpilogue g2{2, ws.hx, 384, ws.z, ws.rh};
-            TRY(launch_conv_gru(conv_desc(ws.rh, 128, 128, ws.hx + 128, 384, 256, W[pass ? W_Q2 : W_Q1], W[pass ? B_Q2 : B_Q1], ws.hx, 384, P, h, w, 128, kh, kw, 3), g2, s));
+            TRY(launch_conv_gru(conv_desc(ws.rh, 128, 128, ws.hx + 256, 384, 128, W[pass ? W_Q2_DYN : W_Q1_DYN], nullptr, ws.hx, 384, P, h, w, 128, kh, kw, 3, 1.f, ws.pre_q[pass], 128), g2, s));
         }
         // flow head (core/update.py:6-14) and coordinate update (core/raft.py:184)
         TRY(launch_conv(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, W[W_FH1], W[B_FH1], ws.fh, 256, P, h, w, 256, 3, 3, 1), s));

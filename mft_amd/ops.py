@@ -69,11 +69,19 @@ def pack_raft_weights(sd: dict, device) -> list:
     out.append(g(u + "encoder.convf1.bias").contiguous())
     conv(u + "encoder.convf2")
     conv(u + "encoder.conv")
+    # GRU gates: input channels are [h(128) | inp(128) | motion(128)].  The inp columns are split off
+    # (they are evaluated once per pair, csrc/raft_engine.hip); the remaining [h | motion] columns form
+    # the per-iteration GEMM.
+    dyn = list(range(0, 128)) + list(range(256, 384))
     for sfx in ("1", "2"):
-        wz, wr = g(u + f"gru.convz{sfx}.weight"), g(u + f"gru.convr{sfx}.weight")
-        out.append(pack_conv_weight(torch.cat([wz, wr], 0)))
+        wzr = torch.cat([g(u + f"gru.convz{sfx}.weight"), g(u + f"gru.convr{sfx}.weight")], 0)
+        out.append(pack_conv_weight(wzr[:, dyn].contiguous()))
+        out.append(pack_conv_weight(wzr[:, 128:256].contiguous()))
         out.append(torch.cat([g(u + f"gru.convz{sfx}.bias"), g(u + f"gru.convr{sfx}.bias")]).contiguous())
-        conv(u + f"gru.convq{sfx}")
+        wq = g(u + f"gru.convq{sfx}.weight")
+        out.append(pack_conv_weight(wq[:, dyn].contiguous()))
+        out.append(pack_conv_weight(wq[:, 128:256].contiguous()))
+        out.append(g(u + f"gru.convq{sfx}.bias").contiguous())
     conv(u + "flow_head.conv1")
     conv(u + "flow_head.conv2")
     conv(u + "mask.0")
@@ -115,7 +123,8 @@ def corr_lookup(lv, coords: torch.Tensor, h: int, w: int, r: int = 4):
     return out
 
 
-def conv2d(x: torch.Tensor, wpk: torch.Tensor, bias, P, h, w, N, kh, kw, act=None, out_scale=1.0, x2=None):
+def conv2d(x: torch.Tensor, wpk: torch.Tensor, bias, P, h, w, N, kh, kw, act=None, out_scale=1.0, x2=None,
+           addend=None):
     """x: pixel-major [P*h*w, C0] (optionally concatenated with x2 [P*h*w, C1]) ->
     [P*h*w, N]."""
     lib = _lib.load()
@@ -131,6 +140,7 @@ def conv2d(x: torch.Tensor, wpk: torch.Tensor, bias, P, h, w, N, kh, kw, act=Non
     d.out, d.ldo = out.data_ptr(), N
     d.P, d.h, d.w, d.N, d.kh, d.kw = P, h, w, N, kh, kw
     d.act, d.out_scale = ACT[act], out_scale
+    d.addend, d.ld_addend = (_chk(addend, "addend"), addend.shape[1]) if addend is not None else (None, 0)
     check(lib.mftx_conv2d(C.byref(d), _stream()), "mftx_conv2d")
     return out
 

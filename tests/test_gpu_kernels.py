@@ -304,3 +304,22 @@ def test_fullsize_properties(ops_mod):
     flow, occl, sigma = ops_mod.convex_upsample(const, ou, mask, 1, h, w)
     assert maxerr(flow[0, 0, 8:-8, 8:-8].cpu(), torch.full((496, 496), 12.0)) < 1e-4
     assert maxerr(occl.cpu(), torch.full_like(occl.cpu(), 0.5)) < 1e-6
+
+
+def test_conv2d_addend_splits_linear_conv(ops_mod):
+    """conv([a | b]) == conv_a(a) + conv_b(b): the engine evaluates the `inp`
+    part of the GRU gates once and feeds it back as an epilogue addend."""
+    g = torch.Generator().manual_seed(21)
+    P, h, w = 2, 16, 24
+    a = torch.randn(P, 128, h, w, generator=g)
+    b = torch.randn(P, 128, h, w, generator=g)
+    wt = torch.randn(256, 256, 1, 5, generator=g) * 0.03
+    bias = torch.randn(256, generator=g) * 0.1
+    ref = torch.sigmoid(F.conv2d(torch.cat([a, b], 1), wt, bias, padding=(0, 2)))
+    ap = a.permute(0, 2, 3, 1).reshape(-1, 128).contiguous().to(DEV)
+    bp = b.permute(0, 2, 3, 1).reshape(-1, 128).contiguous().to(DEV)
+    pre = ops_mod.conv2d(bp, ops_mod.pack_conv_weight(wt[:, 128:].contiguous().to(DEV)), bias.to(DEV), P, h, w, 256,
+                         1, 5)
+    out = ops_mod.conv2d(ap, ops_mod.pack_conv_weight(wt[:, :128].contiguous().to(DEV)), None, P, h, w, 256, 1, 5,
+                         act="sigmoid", addend=pre)
+    assert maxerr(out.reshape(P, h, w, 256).permute(0, 3, 1, 2).cpu(), ref) < 2e-5
