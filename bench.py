@@ -64,6 +64,7 @@ def build_tracker(args, sharded):
     conf = load_config(REPO / "configs" / "MFT_cfg.py")
     conf.flow_config.synthetic_weights_seed = 0
     conf.flow_config.flow_iters = args.iters
+    conf.flow_config.async_encode = not args.sync_encode
     conf.keep_result_on_device = True
     conf.delta_sharding = sharded
     return conf.tracker_class(conf), conf
@@ -150,6 +151,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--sync-encode", action="store_true", help="encode frames on the main stream")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

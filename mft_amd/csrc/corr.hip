@@ -1,6 +1,7 @@
 // Correlation pyramid pooling and the multi-scale 9x9 lookup (HBM-bound).
 #include "common.h"
 #include "profile.h"
+#include <cstdlib>
 
 namespace mftx {
 
@@ -89,34 +90,40 @@ struct LookupArgs {
     int cells;      // P*h*w
     int n_per_img;  // h*w
     int hl[4], wl[4];
+    int ablate;     // tuning only (MFTX_LOOKUP_ABLATE): 1 no tap loads, 2 no stores, 3 neither
 };
 
 __global__ __launch_bounds__(64 * LK_WAVES) void corr_lookup_kernel(LookupArgs p) {
-    __shared__ float taps[LK_WAVES][4 * 128];   // 100 taps per level, padded to 128 slots
+    // per wave: 4 levels x 128 tap slots (100 used) + 4 x 4 bilinear weights
+    __shared__ __attribute__((aligned(16))) float taps[LK_WAVES][4 * 128 + 16];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     float *tp = taps[wv];
+    float *wts = tp + 512;
 
     // lane-constant decode: tap slots (2 per level per lane) and output slots (6 per lane)
     const int tr0 = lane / 10, tc0 = lane - tr0 * 10;                   // taps 0..63
     const int tr1 = (lane + 64) / 10, tc1 = (lane + 64) - tr1 * 10;     // taps 64..99 (lanes 0..35)
-    int o_lvl[6], o_off[6];
+    const bool t1_lane = lane < 36;
+    int o_off[6], o_w[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         const int o = lane + 64 * j;
-        const int l = o / 81;
+        const int l = min(o / 81, 3);
         const int rem = o - l * 81;
         const int a = rem / 9, b = rem - a * 9;   // a offsets x, b offsets y
-        o_lvl[j] = l;
         o_off[j] = l * 128 + b * 10 + a;          // tap (row b, col a) of level l
+        o_w[j] = 512 + l * 4;                     // that level's 4 weights
     }
+    // lanes 0..15 publish the bilinear weights: lane = 4 * level + {w00, w01, w10, w11}
+    const int w_lvl = (lane >> 2) & 3, w_idx = lane & 3;
 
     for (int cell_v = blockIdx.x * LK_WAVES + wv; cell_v < p.cells; cell_v += gridDim.x * LK_WAVES) {
         // one cell per wave: make that provable so the buffer descriptors stay in SGPRs
         const int cell = __builtin_amdgcn_readfirstlane(cell_v);
         const float2 c = reinterpret_cast<const float2 *>(p.coords)[cell];
-        float fx[4], fy[4];
         float t0[4], t1[4];
+        float my_fx = 0.f, my_fy = 0.f;
         // Issue all 8 tap loads of the cell back to back.  Each level slice is its
         // own buffer; taps outside the slice get an out-of-range offset, which
         // the hardware returns as 0 (= grid_sample's zero padding) -- no branches,
@@ -125,25 +132,30 @@ __global__ __launch_bounds__(64 * LK_WAVES) void corr_lookup_kernel(LookupArgs p
         for (int l = 0; l < 4; ++l) {
             const float sx = c.x / (float)(1 << l), sy = c.y / (float)(1 << l);
             const float flx = floorf(sx), fly = floorf(sy);
-            fx[l] = sx - flx; fy[l] = sy - fly;
+            if (w_lvl == l) { my_fx = sx - flx; my_fy = sy - fly; }
             // clamp so that the int conversion is defined for wild coordinates
             const int x0 = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f) - 4;
             const int y0 = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f) - 4;
-            const int H = p.hl[l], W = p.wl[l];
+            const unsigned H = p.hl[l], W = p.wl[l];
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float *>(p.lvl[l] + (long long)cell * H * W), 0, (unsigned)(H * W * 4), 0x00020000);
-            {
-                const int yy = y0 + tr0, xx = x0 + tc0;
-                const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+                const_cast<float *>(p.lvl[l] + (long long)cell * H * W), 0, H * W * 4u, 0x00020000);
+            {   // unsigned compares fold the lower bounds in
+                const unsigned yy = (unsigned)(y0 + tr0), xx = (unsigned)(x0 + tc0);
+                const bool ok = (yy < H) & (xx < W) & !(p.ablate & 1);
                 t0[l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                      rs, ok ? (unsigned)(yy * W + xx) * 4u : 0x80000000u, 0, 0));
+                                                      rs, ok ? (yy * W + xx) * 4u : 0x80000000u, 0, 0));
             }
             {
-                const int yy = y0 + tr1, xx = x0 + tc1;
-                const bool ok = (lane < 36) & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+                const unsigned yy = (unsigned)(y0 + tr1), xx = (unsigned)(x0 + tc1);
+                const bool ok = t1_lane & (yy < H) & (xx < W) & !(p.ablate & 1);
                 t1[l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                                      rs, ok ? (unsigned)(yy * W + xx) * 4u : 0x80000000u, 0, 0));
+                                                      rs, ok ? (yy * W + xx) * 4u : 0x80000000u, 0, 0));
             }
+        }
+        if (lane < 16) {
+            const float ax = (w_idx & 1) ? my_fx : 1.f - my_fx;
+            const float ay = (w_idx & 2) ? my_fy : 1.f - my_fy;
+            wts[lane] = ax * ay;
         }
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
@@ -156,14 +168,11 @@ __global__ __launch_bounds__(64 * LK_WAVES) void corr_lookup_kernel(LookupArgs p
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int o = lane + 64 * j;
-            if (o < 324) {
-                const int l = o_lvl[j];
-                const float wx = (l == 0) ? fx[0] : (l == 1) ? fx[1] : (l == 2) ? fx[2] : fx[3];
-                const float wy = (l == 0) ? fy[0] : (l == 1) ? fy[1] : (l == 2) ? fy[2] : fy[3];
+            if ((j < 5 || o < 324) && (!(p.ablate & 2) || (j == 0 && lane == 0))) {
+                const float4 wq = *reinterpret_cast<const float4 *>(tp + o_w[j]);
                 const float *t4 = tp + o_off[j];
                 const float v00 = t4[0], v01 = t4[1], v10 = t4[10], v11 = t4[11];
-                dst[o] = v00 * ((1.f - wx) * (1.f - wy)) + v01 * (wx * (1.f - wy)) +
-                         v10 * ((1.f - wx) * wy) + v11 * (wx * wy);
+                dst[o] = v00 * wq.x + v01 * wq.y + v10 * wq.z + v11 * wq.w;
             }
         }
     }
@@ -175,6 +184,8 @@ int launch_corr_lookup(const float *const lvl[4], const float *coords, int P, in
     for (int l = 0; l < 4; ++l) { a.lvl[l] = lvl[l]; a.hl[l] = h >> l; a.wl[l] = w >> l; }
     a.coords = coords; a.out = out; a.ld_out = ld_out;
     a.cells = P * h * w; a.n_per_img = h * w;
+    static const int ablate = [] { const char *e = getenv("MFTX_LOOKUP_ABLATE"); return e ? atoi(e) : 0; }();
+    a.ablate = ablate;
     const int blocks = cdiv(a.cells, LK_WAVES);
     // 4 levels x 10x10 unique taps read + coords + 324 outputs written, per cell
     ProfScope prof(PC_LOOKUP, s, (double)a.cells * (4 * 100 * 4 + 8 + 324 * 4));

@@ -111,6 +111,11 @@ class RAFTWrapper:
         self.cnet = Encoder(self.sd, "cnet", "batch")
         self.engine = ops.RaftEngine(self.sd, self.device)
         self._frames = {}
+        # Optional (C.async_encode): encode new frames on a side stream.  The encoders of frame t
+        # only need the image, so with results kept on the device (no per-frame host sync) their
+        # small MIOpen kernels overlap the tail of frame t-1's GEMM-bound refinement instead of
+        # sitting on the critical path.  Device-tensor frames must be complete when passed in.
+        self._enc_stream = torch.cuda.Stream(device=self.device) if getattr(config, "async_encode", False) else None
 
     @staticmethod
     def _load_weights(config):
@@ -153,12 +158,24 @@ class RAFTWrapper:
         for k in [k for k in self._frames if k not in keep]:
             del self._frames[k]
 
+    def _encode(self, img):
+        if self._enc_stream is None:
+            return self.encode(img)
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self._enc_stream):
+            f = self.encode(img)
+        main.wait_stream(self._enc_stream)
+        for t in (f.fmap, f.net, f.inp):          # allocated on the side stream, consumed on `main`
+            if t is not None:
+                t.record_stream(main)
+        return f
+
     def _features(self, key, img):
         if key is None:
-            return self.encode(img)
+            return self._encode(img)
         f = self._frames.get(key)
         if f is None or f.shape != img.shape[:2]:
-            f = self.encode(img)
+            f = self._encode(img)
             self._frames[key] = f
         return f
 

@@ -216,3 +216,24 @@ def test_compute_flow_1080p_smoke(flower):
     for x, y in zip(a[0], b[1]):
         assert torch.equal(x, y)
     torch.cuda.empty_cache()
+
+
+def test_async_encode_is_bitwise_identical(weights_np):
+    """Encoding frames on a side stream (C.async_encode) must not change results."""
+    from mft_amd.config import Config
+    from mft_amd.raft import RAFTWrapper
+    vid = SyntheticVideo(128, 160, n_frames=8, seed=21)
+    outs = []
+    for flag in (False, True):
+        c = Config()
+        c.flow_iters = 3
+        c.async_encode = flag
+        fl = RAFTWrapper(c, state_dict=weights_np)
+        tr = make_tracker(fl, deltas=(np.inf, 1, 2, 4))
+        tr.C.keep_result_on_device = True
+        tr.init(torch.from_numpy(vid[0]).cuda())
+        res = [tr.track(torch.from_numpy(vid[i]).cuda()).result for i in range(1, 8)]
+        torch.cuda.synchronize()
+        outs.append(res)
+    for a, b in zip(*outs):
+        assert torch.equal(a.flow, b.flow) and torch.equal(a.occlusion, b.occlusion) and torch.equal(a.sigma, b.sigma)
