@@ -98,6 +98,24 @@ def profile_pass(tracker, frames, first, steps):
     return out
 
 
+def profiled_traffic():
+    """HBM bytes per conv-GEMM launch measured offline with rocprofv3 PMC passes on this same
+    command (profiles/*_pmc_hbm_traffic.csv: FETCH_SIZE x2-corrected + WRITE_SIZE, launch-weighted)."""
+    files = sorted((REPO / "profiles").glob("*_pmc_hbm_traffic.csv"))
+    if not files:
+        return None, None
+    tot = n = 0.0
+    for line in files[-1].read_text().splitlines():
+        if line.startswith("#") or "conv_gemm_kernel" not in line:
+            continue
+        name, launches, _fetch, fetch_x2, write = line.rsplit(",", 4)     # the kernel name contains commas
+        if name.rstrip().endswith("0, 2>"):                                # <...,0,2> = correlation volume
+            continue
+        tot += float(launches) * (float(fetch_x2) + float(write)) * 1e6
+        n += float(launches)
+    return (tot / n if n else None), files[-1].name
+
+
 def cpu_baseline(args, vid):
     """The oracle (CPU restatement of the reference algorithm, torch CPU ops,
     features recomputed per pair like the reference) on a bounded sample."""
@@ -222,7 +240,8 @@ def main():
         if dom:
             result["roofline"] = {"kernel": "conv_gemm_kernel (fp32 MFMA implicit GEMM: update block + OU heads)",
                                   "bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"],
-                                  "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None,
+                                  "unit": "TFLOP/s", "frac": dom["frac"], "traffic": profiled_traffic()[0],
+                                  "traffic_source": profiled_traffic()[1],
                                   "avg_launch_us": dom["avg_us"], "flops_per_launch": dom["work_per_launch"]}
             result["kernels"] = kernels
     if world == 1 and rank == 0:
