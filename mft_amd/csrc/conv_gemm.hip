@@ -95,11 +95,12 @@ __device__ __forceinline__ void wait_vmcnt() {   // counted wait: leaves N LDS-D
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, int NS>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int RA = BM / 32, RB = BN / 32;
-    static_assert(WM * WN == 4, "4 waves");
-    static_assert(TM >= 1 && TN >= 1, "tile");
+    constexpr int RPP = 8 * WM * WN;            // rows staged per pass: 8 per wave (one 1 KiB LDS-DMA)
+    constexpr int RA = BM / RPP, RB = BN / RPP;
+    static_assert(TM >= 1 && TN >= 1 && RA >= 1 && RB >= 1, "tile");
+    static_assert(RPP % 16 == 0, "the chunk swizzle must not depend on the pass");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                       // [NS][BM][LDK]  (ring of NS tiles)
     float *Bs = smem + NS * BM * LDK;       // [NS][BN][LDK]
@@ -109,9 +110,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     const int lane = tid & 63;
     const int wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int srow = tid >> 3;  // 0..31: staging row of this lane within a 32-row group
+    const int srow = tid >> 3;  // 0..RPP-1: staging row of this lane within an RPP-row group
     // this lane's LDS chunk (tid & 7) receives logical chunk (tid & 7) ^ swz(row); rows advance by
-    // 32 per group, so swz = (row >> 1) & 7 depends on srow only
+    // RPP (a multiple of 16) per group, so swz = (row >> 1) & 7 depends on srow only
     const int col4 = ((tid & 7) ^ ((srow >> 1) & 7)) * 4;
 
     // Persistent workgroups with an XCD-aware tile order.  The hardware dispatcher
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     const int hw = p.h * p.wd;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = m0 + srow + 32 * i;
+        const int m = m0 + srow + RPP * i;
         if (m < p.M) {
             const int rem = m % hw;
             ay[i] = rem / p.wd;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
     unsigned woff[RB];                       // byte offsets into W, advance 128 B per K step
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        const int n = n0 + srow + 32 * i;
+        const int n = n0 + srow + RPP * i;
         woff[i] = (n < p.w_rows) ? (unsigned)n * ktot_b + col4 * 4u : OOB;
     }
     unsigned aoff0[RA], aoff1[RA];           // byte offsets of this tap's source cell in segment 0 / 1
@@ -196,17 +197,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs p) {
         const unsigned cb = (unsigned)(seg1 ? cbase - p.c0 : cbase) * 4u;
         const bool cok = cbase + col4 < ctot;  // ragged channel count: zero-fill the tail
         const __amdgpu_buffer_rsrc_t rA = seg1 ? rA1 : rA0;
-        // wave `wid` fills rows [32 i + 8 wid, +8) of each 32-row group: 1 KiB, lane-linear
+        // wave `wid` fills rows [RPP i + 8 wid, +8) of each RPP-row group: 1 KiB, lane-linear
         float *as = As + buf * BM * LDK + wid * 8 * LDK;
         float *bs = Bs + buf * BN * LDK + wid * 8 * LDK;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const unsigned off = (cok ? (seg1 ? aoff1[i] : aoff0[i]) : OOB) + cb;
-            buf_load_lds(rA, as + 32 * i * LDK, off);
+            buf_load_lds(rA, as + RPP * i * LDK, off);
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            buf_load_lds(rW, bs + 32 * i * LDK, woff[i]);
+            buf_load_lds(rW, bs + RPP * i * LDK, woff[i]);
             woff[i] += BK * 4u;
         }
         if (++cc == cpt) { cc = 0; ++tap; if (tap < taps) set_tap(); }
@@ -342,13 +343,14 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) 
     static const int ablate = [] { const char *e = getenv("MFTX_CONV_ABLATE"); return e ? atoi(e) : 0; }();
     args.ablate = ablate;
     // resident workgroups per CU: LDS-bound (160 KiB per CU), at most 4 (16 waves)
-    constexpr int resident = (160 * 1024) / (int)lds < 4 ? (160 * 1024) / (int)lds : 4;
+    constexpr int max_res = 16 / (WM * WN);     // at most 16 waves per CU
+    constexpr int resident = (160 * 1024) / (int)lds < max_res ? (160 * 1024) / (int)lds : max_res;
     const long long n_virtual = 8ll * cdiv(cdiv(a.M, BM), 8) * cdiv(a.N, BN) * batch;
     const long long slots = (long long)num_cus() * resident;
     dim3 grid((unsigned)(n_virtual < slots ? n_virtual : slots));
     // algorithmic flops: real (unpadded) reduction length
     ProfScope prof(cat, s, 2.0 * a.M * a.N * (double)(a.kh * a.kw) * (a.c0 + a.c1) * batch);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, args);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, args);
     return check_launch("conv_gemm");
 }
 
@@ -361,6 +363,7 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
         case 0: return launch_cfg<128, 128, 2, 2, EPI, 2>(a, batch, s, cat);
         case 1: return launch_cfg<128, 64, 2, 2, EPI, 2>(a, batch, s, cat);
         case 2: return launch_cfg<64, 64, 2, 2, EPI, 2>(a, batch, s, cat);
+        case 4: return launch_cfg<64, 32, 2, 1, EPI, 2>(a, batch, s, cat);   // 2 waves: twice the tiles of 64x64
         default: return launch_cfg<128, 32, 4, 1, EPI, 2>(a, batch, s, cat);
     }
 }
@@ -368,16 +371,17 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
 static int pick_tile(const ConvArgs &a, int batch) {
     // debug/tuning override: MFTX_CONV_TILE=0..3
     static const int forced = [] { const char *e = getenv("MFTX_CONV_TILE"); return e ? atoi(e) : -1; }();
-    if (forced >= 0 && forced <= 3) return forced;
+    if (forced >= 0 && forced <= 4) return forced;
     // Measured on MI355X (tools/bench_conv.py, M = 7 x 4096 and 4096): the 64x64
     // tile (4 workgroups per CU, LDS-bound) wins or ties on every layer -- more
     // resident waves hide the LDS-DMA latency better than bigger tiles save on
     // operand re-reads -- except for N = 192 (convc2), where 128x64 avoids a
     // half-empty column tile.  N <= 32 (only reached when the small-N VALU
-    // kernel does not apply) gets the 128x32 tile.
+    // kernel does not apply) gets the 128x32 tile.  A two-wave 64x32 tile (twice
+    // the tiles, better CU balance for N = 128) was measured and loses 20 %.
     (void)batch;
     if (a.N <= 32) return 3;
-    if (a.N > 128 && a.N % 128 == 64) return 1;
+    if (a.N > 128 && a.N % 128 == 64 && a.M >= 16384) return 1;   // at small M the extra tiles of 64x64 win
     return 2;
 }
 

@@ -20,10 +20,13 @@ LAYERS = [
     ("convc2 3x3 256->192", 256, 192, 3, 3, 12),
     ("convf2 3x3 128->64", 128, 64, 3, 3, 12),
     ("conv   3x3 256->126", 256, 126, 3, 3, 12),
-    ("gru zr 1x5 384->256", 384, 256, 1, 5, 12),
-    ("gru q  1x5 384->128", 384, 128, 1, 5, 12),
-    ("gru zr 5x1 384->256", 384, 256, 5, 1, 12),
-    ("gru q  5x1 384->128", 384, 128, 5, 1, 12),
+    # GRU gates: the inp third of the input is hoisted out of the loop -> 256 input channels
+    ("gru zr 1x5 256->256", 256, 256, 1, 5, 12),
+    ("gru q  1x5 256->128", 256, 128, 1, 5, 12),
+    ("gru zr 5x1 256->256", 256, 256, 5, 1, 12),
+    ("gru q  5x1 256->128", 256, 128, 5, 1, 12),
+    ("gru inp 1x5 128->384", 128, 384, 1, 5, 1),
+    ("gru inp 5x1 128->384", 128, 384, 5, 1, 1),
     ("fh1    3x3 128->256", 128, 256, 3, 3, 12),
     ("fh2    3x3 256->2", 256, 2, 3, 3, 12),
     ("mask0  3x3 128->256", 128, 256, 3, 3, 1),
