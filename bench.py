@@ -65,6 +65,7 @@ def build_tracker(args, sharded):
     conf.flow_config.synthetic_weights_seed = 0
     conf.flow_config.flow_iters = args.iters
     conf.flow_config.async_encode = not args.sync_encode
+    conf.flow_config.torch_encoders = args.torch_encoders
     conf.keep_result_on_device = True
     conf.delta_sharding = sharded
     return conf.tracker_class(conf), conf
@@ -170,6 +171,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--sync-encode", action="store_true", help="encode frames on the main stream")
+    ap.add_argument("--torch-encoders", action="store_true", help="PyTorch-ROCm/MIOpen encoders instead of the native ones")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -93,6 +93,10 @@ typedef struct mftx_conv_desc {
     int act;
     float out_scale;
     const float *addend; int ld_addend;
+    /* strided / unpadded convolutions (encoders, core/extractor.py): all 0 = stride 1 on the output grid with
+     * "same" zero padding.  stride: 1..4; hin, win: input grid per image (0 = h, w); pad_y, pad_x: 0 = k/2,
+     * -1 = no padding, else explicit; residual_mode 1: out = relu(act(conv + bias) + addend). */
+    int stride, hin, win, pad_y, pad_x, residual_mode;
 } mftx_conv_desc;
 int mftx_conv2d(const mftx_conv_desc *d, void *stream);
 
@@ -119,6 +123,20 @@ int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters,
                      int pad_left, int pad_right, int pad_top, int pad_bottom,
                      float *flow, float *occl, float *sigma, float *flow_lr,
                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- a3: feature / context encoder (BasicEncoder, core/extractor.py:118-195) ---------
+ * Replaces fnet / cnet of RAFT.forward (core/raft.py:122-149) incl. RAFTWrapper's
+ * pre-processing (MFT/raft.py:41-48): BGR->RGB, replicate pad to /8, 2x/255-1.
+ * weights: 16 (instance_norm = 1, fnet) or 17 (cnet, batch norm folded, head split into
+ * tanh / relu halves) x (packed weight, bias), order in mft_amd/ops.py:pack_encoder_weights.
+ * img: uint8 [H0][W0][3] BGR (device).  fnet: out0 = [h*w][256]; cnet: out0 = net [h*w][128],
+ * out1 = inp [h*w][128]; h = ceil(H0/8), w = ceil(W0/8). */
+typedef struct mftx_encoder mftx_encoder;
+int mftx_encoder_create(const float *const *weights, int n_weights, int instance_norm, mftx_encoder **out);
+void mftx_encoder_destroy(mftx_encoder *e);
+size_t mftx_encoder_workspace_bytes(int H0, int W0);
+int mftx_encoder_forward(mftx_encoder *e, const uint8_t *img, int H0, int W0, float *out0, float *out1,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- a10 + a12: convex 8x upsampling + post-processing ---------------------
  * Replaces RAFT.upsample_flow (core/raft.py:83-94) for the three heads and

@@ -21,7 +21,9 @@ class ConvDesc(C.Structure):
                 ("P", C.c_int), ("h", C.c_int), ("w", C.c_int),
                 ("N", C.c_int), ("kh", C.c_int), ("kw", C.c_int),
                 ("act", C.c_int), ("out_scale", C.c_float),
-                ("addend", C.c_void_p), ("ld_addend", C.c_int)]
+                ("addend", C.c_void_p), ("ld_addend", C.c_int),
+                ("stride", C.c_int), ("hin", C.c_int), ("win", C.c_int), ("pad_y", C.c_int), ("pad_x", C.c_int),
+                ("residual_mode", C.c_int)]
 
 
 _PP = C.POINTER(C.c_void_p)
@@ -45,6 +47,11 @@ SIGNATURES = {
                                    C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mftx_encoder_create": (C.c_int, [_PP, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "mftx_encoder_destroy": (None, [C.c_void_p]),
+    "mftx_encoder_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "mftx_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "mftx_convex_upsample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 7
                              + [C.c_void_p] * 4),
     "mftx_chain": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int] + [C.c_void_p] * 4),

@@ -53,6 +53,8 @@ struct ConvArgs {
     float *out;
     int ldo;
     int M, N, h, wd, kh, kw, cin_pad;
+    int stride, hin, win, pad_y, pad_x;   // input grid (hin x win cells per image), conv stride and padding
+    int residual_mode;                    // 1: out = relu(act(.) + addend) (residual block tail) instead of a pre-activation addend
     int w_rows;               // valid rows of the W operand
     int act;
     float out_scale;
@@ -149,16 +151,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs p) {
         const_cast<float *>(p.w + bz * p.w_bstride), 0, p.w_bytes, 0x00020000);
 
     // ---- per-thread staging coordinates
-    int ay[RA], ax[RA], am[RA];
+    int ay[RA], ax[RA], am[RA];              // input-grid origin of the row's window, and its image's first cell
     const int hw = p.h * p.wd;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         const int m = m0 + srow + RPP * i;
         if (m < p.M) {
-            const int rem = m % hw;
-            ay[i] = rem / p.wd;
-            ax[i] = rem - ay[i] * p.wd;
-            am[i] = m;
+            const int img = m / hw;
+            const int rem = m - img * hw;
+            const int oy = rem / p.wd;
+            ay[i] = oy * p.stride - p.pad_y;
+            ax[i] = (rem - oy * p.wd) * p.stride - p.pad_x;
+            am[i] = img * p.hin * p.win;
         } else {
             ay[i] = -100000; ax[i] = -100000; am[i] = 0;
         }
@@ -167,7 +171,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs p) {
     const int cpt = p.cin_pad / BK;          // K steps per tap
     const int T = taps * cpt;
     const unsigned ktot_b = (unsigned)taps * p.cin_pad * 4u;
-    const int py = p.kh / 2, px = p.kw / 2;
     const int ctot = p.c0 + p.c1;
 
     unsigned woff[RB];                       // byte offsets into W, advance 128 B per K step
@@ -179,12 +182,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs p) {
     unsigned aoff0[RA], aoff1[RA];           // byte offsets of this tap's source cell in segment 0 / 1
     int tap = 0, cc = 0;                     // position of the NEXT tile to fetch
     auto set_tap = [&]() {
-        const int dy = tap / p.kw - py, dx = tap % p.kw - px;
+        const int dy = tap / p.kw, dx = tap % p.kw;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int yy = ay[i] + dy, xx = ax[i] + dx;
-            const bool ok = (yy >= 0) & (yy < p.h) & (xx >= 0) & (xx < p.wd);
-            const unsigned src = (unsigned)(am[i] + dy * p.wd + dx);
+            const bool ok = (yy >= 0) & (yy < p.hin) & (xx >= 0) & (xx < p.win);
+            const unsigned src = (unsigned)(am[i] + yy * p.win + xx);
             aoff0[i] = ok ? (src * (unsigned)p.lda0 + col4) * 4u : OOB;
             aoff1[i] = ok ? (src * (unsigned)p.lda1 + col4) * 4u : OOB;
         }
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs p) {
                 const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
                 if (!n_ok || m >= p.M) continue;
                 float s = acc[i][j][r] + bias;
-                if (p.addend != nullptr) s += p.addend[(long long)m * p.ld_addend + n];
+                if (p.addend != nullptr && p.residual_mode == 0) s += p.addend[(long long)m * p.ld_addend + n];
                 if constexpr (EPI == EPI_RELU) {
                     out[(long long)m * p.ldo + n] = fmaxf(s, 0.f) * p.out_scale;
                 } else if constexpr (EPI == EPI_GRU_ZR) {   // [z | r] gates; r is folded into r*h
@@ -306,7 +309,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs p) {
                     float *hp = p.hx + (long long)m * p.ld_hx + n;
                     *hp = (1.f - zz) * (*hp) + zz * v;
                 } else {
-                    out[(long long)m * p.ldo + n] = act_fn(s, p.act) * p.out_scale;
+                    float v = act_fn(s, p.act) * p.out_scale;
+                    if (p.residual_mode == 1) v = fmaxf(v + p.addend[(long long)m * p.ld_addend + n], 0.f);
+                    out[(long long)m * p.ldo + n] = v;
                 }
             }
         }
@@ -399,15 +404,18 @@ static int validate(const mftx_conv_desc &d) {
     if (!d.a0 || !d.wpk || !d.out) return fail(MFTX_E_ARG, "conv2d: null pointer");
     if (d.P <= 0 || d.h <= 0 || d.w <= 0 || d.N <= 0 || d.c0 <= 0 || d.c1 < 0)
         return fail(MFTX_E_ARG, "conv2d: bad sizes");
-    if (d.kh < 1 || d.kw < 1 || !(d.kh & 1) || !(d.kw & 1)) return fail(MFTX_E_ARG, "conv2d: odd kernels only");
+    if (d.kh < 1 || d.kw < 1 || !(d.kh & 1)) return fail(MFTX_E_ARG, "conv2d: kernel height must be odd");
+    if (d.stride < 0 || d.stride > 4 || d.hin < 0 || d.win < 0) return fail(MFTX_E_ARG, "conv2d: bad stride / input grid");
+    if (d.residual_mode != 0 && (d.residual_mode != 1 || !d.addend)) return fail(MFTX_E_ARG, "conv2d: bad residual mode");
     if (d.c1 > 0 && (!d.a1 || d.c0 % BK)) return fail(MFTX_E_ARG, "conv2d: segment 0 must be a multiple of 32 channels");
     if ((d.c0 + d.c1) % 4 || d.c0 % 4) return fail(MFTX_E_ARG, "conv2d: channel counts must be multiples of 4");
     if (d.lda0 % 4 || (d.c1 > 0 && d.lda1 % 4) || !aligned16(d.a0) || (d.c1 > 0 && !aligned16(d.a1)) || !aligned16(d.wpk))
         return fail(MFTX_E_ALIGN, "conv2d: operands must be 16-byte aligned");
     if (d.act < 0 || d.act > 3) return fail(MFTX_E_ARG, "conv2d: bad activation");
     const long long M = (long long)d.P * d.h * d.w;
+    const long long Min = (long long)d.P * (d.hin ? d.hin : d.h) * (d.win ? d.win : d.w);
     const long long lim = 0x7fffffffLL;      // buffer offsets are 32-bit, bit 31 marks "out of range"
-    if (M > lim || M * d.lda0 * 4 > lim || (d.c1 > 0 && M * d.lda1 * 4 > lim))
+    if (M > lim || Min * d.lda0 * 4 > lim || (d.c1 > 0 && Min * d.lda1 * 4 > lim))
         return fail(MFTX_E_ARG, "conv2d: activation operand exceeds 2 GiB");
     const long long wbytes = (long long)round_up(d.N, 128) * d.kh * d.kw * round_up(d.c0 + d.c1, BK) * 4;
     if (wbytes > lim) return fail(MFTX_E_ARG, "conv2d: weight operand exceeds 2 GiB");
@@ -422,18 +430,23 @@ static ConvArgs to_args(const mftx_conv_desc &d) {
     a.cin_pad = round_up(d.c0 + d.c1, BK);
     a.w_rows = round_up(d.N, 128);
     a.act = d.act; a.out_scale = d.out_scale;
-    a.addend = d.addend; a.ld_addend = d.ld_addend;
-    // extents: the last cell's row ends at (M-1)*lda + c
-    a.a0_bytes = (unsigned)(((long long)(a.M - 1) * d.lda0 + d.c0) * 4);
-    a.a1_bytes = d.c1 > 0 ? (unsigned)(((long long)(a.M - 1) * d.lda1 + d.c1) * 4) : 0u;
+    a.addend = d.addend; a.ld_addend = d.ld_addend; a.residual_mode = d.residual_mode;
+    a.stride = d.stride ? d.stride : 1;
+    a.hin = d.hin ? d.hin : d.h; a.win = d.win ? d.win : d.w;
+    a.pad_y = d.pad_y < 0 ? 0 : (d.pad_y ? d.pad_y : d.kh / 2);   // 0 = "same" default, -1 = no padding
+    a.pad_x = d.pad_x < 0 ? 0 : (d.pad_x ? d.pad_x : d.kw / 2);
+    // extents: the last input cell's row ends at (Min-1)*lda + c
+    const long long Min = (long long)d.P * a.hin * a.win;
+    a.a0_bytes = (unsigned)(((Min - 1) * d.lda0 + d.c0) * 4);
+    a.a1_bytes = d.c1 > 0 ? (unsigned)(((Min - 1) * d.lda1 + d.c1) * 4) : 0u;
     a.w_bytes = (unsigned)((long long)a.w_rows * d.kh * d.kw * a.cin_pad * 4);
     return a;
 }
 
 int launch_conv(const mftx_conv_desc &d, hipStream_t s) {
     if (int e = validate(d)) return e;
-    if (d.addend == nullptr && conv_small_applicable(d)) return launch_conv_small(d, s);   // N <= 4: VALU kernel, no MFMA padding waste
-    const bool relu = d.act == 1;
+    if (d.addend == nullptr && d.stride <= 1 && d.hin == 0 && conv_small_applicable(d)) return launch_conv_small(d, s);   // N <= 4: VALU kernel, no MFMA padding waste
+    const bool relu = d.act == 1 && d.residual_mode == 0;   // the residual tail lives in the generic epilogue
     return dispatch(to_args(d), relu ? EPI_RELU : EPI_GENERIC, 1, s, PC_CONV_GEMM);
 }
 
@@ -452,6 +465,7 @@ int launch_corr_volume(const float *f1, const float *f2, int P, int C, int N, fl
     a.a0 = f1; a.lda0 = C; a.c0 = C; a.c1 = 0; a.a1 = nullptr; a.lda1 = 0;
     a.w = f2; a.bias = nullptr; a.out = lvl0; a.ldo = N;
     a.M = N; a.N = N; a.h = 1; a.wd = N; a.kh = 1; a.kw = 1; a.cin_pad = C;
+    a.stride = 1; a.hin = 1; a.win = N; a.pad_y = 0; a.pad_x = 0;
     a.w_rows = N;
     a.act = 0; a.out_scale = 1.0f / sqrtf((float)C);
     a.a_bstride = (long long)N * C; a.w_bstride = (long long)N * C; a.o_bstride = (long long)N * N;

@@ -1,0 +1,283 @@
+// Feature / context encoders (BasicEncoder, core/extractor.py:118-195) on the
+// fp32-MFMA implicit-GEMM kernel, pixel-major end to end:
+//
+//   prep      uint8 BGR frame -> RGB, 2x/255-1, replicate pad to /8 (InputPadder 'sintel',
+//             core/utils/utils.py:9-19), 4th channel and 3 zero columns each side
+//   stem      7x7 stride-2 conv 3->64 as a 7-tap GEMM over 28-float windows (7 pixels x RGBX)
+//   3 stages  of 2 residual blocks (64 s1, 96 s2, 128 s2): 3x3 convs, 1x1 stride-2 shortcut
+//   head      1x1 conv 128->256 (fnet) or 128->128 tanh | 128->128 relu (cnet, core/raft.py:146-149)
+//
+// fnet uses InstanceNorm2d (no affine, eps 1e-5): one statistics pass (fp64 sums, fixed
+// reduction order -> deterministic) + one normalise/ReLU(/residual) pass per conv.  cnet
+// uses eval-mode BatchNorm2d, folded into the conv weights and biases at load, so every
+// layer is a single GEMM launch with a fused ReLU or residual epilogue.
+#include "common.h"
+#include "profile.h"
+#include <new>
+
+namespace mftx {
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+
+// img: uint8 [H0][W0][3] BGR  ->  out: fp32 [Hp][Wp + 6][4] (RGB0), Hp x Wp = padded size
+__global__ void enc_prep_kernel(const uint8_t *__restrict__ img, int H0, int W0, int pl, int pt, int Hp, int Wp,
+                                float *__restrict__ out) {
+    const int xo = blockIdx.x * blockDim.x + threadIdx.x;     // 0 .. Wp+5
+    const int y = blockIdx.y;
+    if (xo >= Wp + 6) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int x = xo - 3;
+    if (x >= 0 && x < Wp) {
+        const int sy = min(max(y - pt, 0), H0 - 1), sx = min(max(x - pl, 0), W0 - 1);   // replicate padding
+        const uint8_t *p = img + ((long long)sy * W0 + sx) * 3;
+        v.x = 2.f * ((float)p[2] / 255.0f) - 1.0f;     // R   (core/raft.py:122-124: 2*(x/255) - 1)
+        v.y = 2.f * ((float)p[1] / 255.0f) - 1.0f;     // G
+        v.z = 2.f * ((float)p[0] / 255.0f) - 1.0f;     // B
+    }
+    reinterpret_cast<float4 *>(out)[(long long)y * (Wp + 6) + xo] = v;
+}
+
+// per-channel partial sums over a slab of rows: x [rows][C] -> part [slabs][C][2] (sum, sum of squares; fp64)
+constexpr int IN_SLABS = 64;
+__global__ __launch_bounds__(256) void instnorm_partial_kernel(const float *__restrict__ x, int rows, int C,
+                                                               double *__restrict__ part) {
+    __shared__ double sh[256][2];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int g = threadIdx.x >> 6;                    // 4 row groups per block
+    const int slab = blockIdx.y;
+    const int r0 = (int)((long long)rows * slab / IN_SLABS), r1 = (int)((long long)rows * (slab + 1) / IN_SLABS);
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int r = r0 + g; r < r1; r += 4) {
+            const double v = (double)x[(long long)r * C + c];
+            s += v;
+            q += v * v;
+        }
+    sh[threadIdx.x][0] = s;
+    sh[threadIdx.x][1] = q;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        for (int k = 1; k < 4; ++k) { s += sh[threadIdx.x + 64 * k][0]; q += sh[threadIdx.x + 64 * k][1]; }
+        part[((long long)slab * C + c) * 2] = s;
+        part[((long long)slab * C + c) * 2 + 1] = q;
+    }
+}
+
+// y = relu((x - mean) * rstd)            [mode 0]
+// y = relu(res + relu((x - mean)*rstd))  [mode 1: residual block tail]
+// y = (x - mean) * rstd                  [mode 2: shortcut branch, no activation]
+__global__ __launch_bounds__(256) void instnorm_apply_kernel(float *__restrict__ x, int rows, int C,
+                                                             const double *__restrict__ part,
+                                                             const float *__restrict__ res, int mode) {
+    __shared__ float mean_s[256], rstd_s[256];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < IN_SLABS; ++k) { s += part[((long long)k * C + c) * 2]; q += part[((long long)k * C + c) * 2 + 1]; }
+        const double m = s / rows;
+        const double var = q / rows - m * m;           // biased variance, as nn.InstanceNorm2d
+        mean_s[c] = (float)m;
+        rstd_s[c] = (float)(1.0 / sqrt((var > 0 ? var : 0.0) + 1e-5));
+    }
+    __syncthreads();
+    const long long n4 = (long long)rows * C / 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        float4 v = reinterpret_cast<float4 *>(x)[i];
+        float o[4] = {v.x, v.y, v.z, v.w};
+        float rr[4] = {0.f, 0.f, 0.f, 0.f};
+        if (mode == 1) {
+            const float4 rv = reinterpret_cast<const float4 *>(res)[i];
+            rr[0] = rv.x; rr[1] = rv.y; rr[2] = rv.z; rr[3] = rv.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float t = (o[k] - mean_s[c + k]) * rstd_s[c + k];
+            if (mode != 2) t = fmaxf(t, 0.f);
+            if (mode == 1) t = fmaxf(rr[k] + t, 0.f);
+            o[k] = t;
+        }
+        reinterpret_cast<float4 *>(x)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------
+// weight slots per encoder: 16 convs x (weight, bias); the cnet head is two convs
+enum EncConv { EC_STEM, EC_L1B0C1, EC_L1B0C2, EC_L1B1C1, EC_L1B1C2, EC_L2B0C1, EC_L2B0C2, EC_L2B0DS, EC_L2B1C1,
+               EC_L2B1C2, EC_L3B0C1, EC_L3B0C2, EC_L3B0DS, EC_L3B1C1, EC_L3B1C2, EC_HEAD, EC_HEAD2, EC_COUNT };
+
+struct EncWs {
+    float *img;           // [Hp][Wp+6][4]
+    float *a, *b, *c;     // activation ping-pong, each max(stage maps)
+    double *part;         // instance-norm partial sums
+    size_t bytes;
+};
+
+static EncWs enc_carve(void *base, int Hp, int Wp) {
+    EncWs ws{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *p = base ? static_cast<char *>(base) + off : nullptr;
+        off += (bytes + 255) & ~size_t(255);
+        return p;
+    };
+    const size_t big = (size_t)(Hp / 2) * (Wp / 2) * 64 * sizeof(float);   // stage-1 map, the largest
+    ws.img = reinterpret_cast<float *>(take((size_t)Hp * (Wp + 6) * 4 * sizeof(float)));
+    ws.a = reinterpret_cast<float *>(take(big));
+    ws.b = reinterpret_cast<float *>(take(big));
+    ws.c = reinterpret_cast<float *>(take(big));
+    ws.part = reinterpret_cast<double *>(take((size_t)IN_SLABS * 256 * 2 * sizeof(double)));
+    ws.bytes = off;
+    return ws;
+}
+
+}  // namespace mftx
+
+using namespace mftx;
+
+struct mftx_encoder {
+    uint32_t magic;
+    int instance_norm;          // 1: fnet (instance norm), 0: cnet (batch norm folded into the weights)
+    const float *w[EC_COUNT], *b[EC_COUNT];
+};
+static constexpr uint32_t ENC_MAGIC = 0x454e4358;
+
+extern "C" int mftx_encoder_create(const float *const *weights, int n_weights, int instance_norm, mftx_encoder **out) {
+    if (!weights || !out) return fail(MFTX_E_ARG, "encoder_create: null pointer");
+    const int n_conv = instance_norm ? EC_COUNT - 1 : EC_COUNT;
+    if (n_weights != 2 * n_conv) return fail(MFTX_E_ARG, "encoder_create: expected %d tensors, got %d", 2 * n_conv, n_weights);
+    for (int i = 0; i < n_weights; ++i)
+        if (!weights[i] || !aligned16(weights[i])) return fail(MFTX_E_ALIGN, "encoder_create: tensor %d null or unaligned", i);
+    mftx_encoder *e = new (std::nothrow) mftx_encoder;
+    if (!e) return fail(MFTX_E_ARG, "encoder_create: out of host memory");
+    e->magic = ENC_MAGIC;
+    e->instance_norm = instance_norm ? 1 : 0;
+    for (int i = 0; i < EC_COUNT; ++i) { e->w[i] = nullptr; e->b[i] = nullptr; }
+    for (int i = 0; i < n_conv; ++i) { e->w[i] = weights[2 * i]; e->b[i] = weights[2 * i + 1]; }
+    *out = e;
+    return 0;
+}
+
+extern "C" void mftx_encoder_destroy(mftx_encoder *e) {
+    if (e && e->magic == ENC_MAGIC) { e->magic = 0; delete e; }
+}
+
+extern "C" size_t mftx_encoder_workspace_bytes(int H0, int W0) {
+    if (H0 <= 0 || W0 <= 0) return 0;
+    const int Hp = (H0 + 7) / 8 * 8, Wp = (W0 + 7) / 8 * 8;
+    return enc_carve(nullptr, Hp, Wp).bytes;
+}
+
+#define TRY(expr) do { int _e = (expr); if (_e) return _e; } while (0)
+
+namespace {
+struct Enc {
+    const mftx_encoder *e;
+    EncWs ws;
+    hipStream_t s;
+
+    int conv(int slot, const float *in, int cin, int lda, int hin, int win, float *out, int cout, int ldo, int h,
+             int w, int k, int stride, int act, const float *residual = nullptr, int w_row0 = 0) {
+        mftx_conv_desc d{};
+        d.a0 = in; d.lda0 = lda; d.c0 = cin;
+        d.wpk = e->w[slot]; d.bias = e->b[slot];
+        (void)w_row0;
+        d.out = out; d.ldo = ldo; d.P = 1; d.h = h; d.w = w; d.N = cout; d.kh = k; d.kw = k;
+        d.act = act; d.out_scale = 1.f;
+        d.stride = stride; d.hin = hin; d.win = win;
+        if (residual) { d.addend = residual; d.ld_addend = cout; d.residual_mode = 1; }
+        return launch_conv(d, s);
+    }
+    int norm(float *x, int rows, int C, int mode, const float *res = nullptr) {
+        {
+            ProfScope prof(PC_GLUE, s, 0);
+            hipLaunchKernelGGL(instnorm_partial_kernel, dim3(cdiv(C, 64), IN_SLABS), dim3(256), 0, s, x, rows, C, ws.part);
+        }
+        TRY(check_launch("instnorm_partial"));
+        const long long n4 = (long long)rows * C / 4;
+        const int blocks = (int)std::min<long long>((n4 + 255) / 256, 2048);
+        {
+            ProfScope prof(PC_GLUE, s, 0);
+            hipLaunchKernelGGL(instnorm_apply_kernel, dim3(blocks), dim3(256), 0, s, x, rows, C, ws.part, res, mode);
+        }
+        return check_launch("instnorm_apply");
+    }
+    // one residual block (core/extractor.py:6-62); x: [hin*win][cin] -> out: [h*w][planes]; tmp, sc scratch
+    int block(int c1, int c2, int ds, const float *x, int cin, int hin, int win, float *tmp, float *sc, float *out,
+              int planes, int h, int w, int stride) {
+        const int rows = h * w;
+        if (e->instance_norm) {
+            TRY(conv(c1, x, cin, cin, hin, win, tmp, planes, planes, h, w, 3, stride, 0));
+            TRY(norm(tmp, rows, planes, 0));
+            TRY(conv(c2, tmp, planes, planes, h, w, out, planes, planes, h, w, 3, 1, 0));
+            const float *shortcut = x;
+            if (stride != 1) {
+                TRY(conv(ds, x, cin, cin, hin, win, sc, planes, planes, h, w, 1, stride, 0));
+                TRY(norm(sc, rows, planes, 2));
+                shortcut = sc;
+            }
+            return norm(out, rows, planes, 1, shortcut);
+        }
+        // batch norm folded: conv+bias+relu, then relu(x + relu(conv+bias))
+        TRY(conv(c1, x, cin, cin, hin, win, tmp, planes, planes, h, w, 3, stride, 1));
+        const float *shortcut = x;
+        if (stride != 1) {
+            TRY(conv(ds, x, cin, cin, hin, win, sc, planes, planes, h, w, 1, stride, 0));
+            shortcut = sc;
+        }
+        return conv(c2, tmp, planes, planes, h, w, out, planes, planes, h, w, 3, 1, 1, shortcut);
+    }
+};
+}  // namespace
+
+// img: uint8 [H0][W0][3] BGR on the device.  fnet: out0 = fmap [h*w][256].  cnet: out0 = net
+// [h*w][128] (tanh), out1 = inp [h*w][128] (relu); h = Hp/8, w = Wp/8.
+extern "C" int mftx_encoder_forward(mftx_encoder *e, const uint8_t *img, int H0, int W0, float *out0, float *out1,
+                                    void *workspace, size_t workspace_bytes, void *stream) {
+    if (!e || e->magic != ENC_MAGIC) return fail(MFTX_E_STATE, "encoder_forward: bad handle");
+    if (!img || !out0 || !workspace || (!e->instance_norm && !out1)) return fail(MFTX_E_ARG, "encoder_forward: null pointer");
+    if (H0 < 16 || W0 < 16) return fail(MFTX_E_ARG, "encoder_forward: image too small");
+    if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(MFTX_E_ALIGN, "encoder_forward: workspace must be 256-byte aligned");
+    const int ph = (((H0 / 8) + 1) * 8 - H0) % 8, pw = (((W0 / 8) + 1) * 8 - W0) % 8;
+    const int Hp = H0 + ph, Wp = W0 + pw, pl = pw / 2, pt = ph / 2;
+    Enc E{e, enc_carve(workspace, Hp, Wp), (hipStream_t)stream};
+    if (E.ws.bytes > workspace_bytes) return fail(MFTX_E_WORKSPACE, "encoder_forward: workspace %zu < %zu", workspace_bytes, E.ws.bytes);
+    hipStream_t s = E.s;
+    {
+        ProfScope prof(PC_GLUE, s, 0);
+        hipLaunchKernelGGL(enc_prep_kernel, dim3(cdiv(Wp + 6, 256), Hp), dim3(256), 0, s, img, H0, W0, pl, pt, Hp, Wp, E.ws.img);
+    }
+    TRY(check_launch("enc_prep"));
+    // stem: 7 taps (rows) x 28-float windows starting at padded column 2x: kh = 7, kw = 1, no x padding
+    const int h1 = Hp / 2, w1 = Wp / 2;
+    {
+        mftx_conv_desc d{};
+        d.a0 = E.ws.img; d.lda0 = 4; d.c0 = 28;
+        d.wpk = e->w[EC_STEM]; d.bias = e->b[EC_STEM];
+        d.out = E.ws.a; d.ldo = 64; d.P = 1; d.h = h1; d.w = w1; d.N = 64; d.kh = 7; d.kw = 1;
+        d.act = e->instance_norm ? 0 : 1; d.out_scale = 1.f;
+        d.stride = 2; d.hin = Hp; d.win = Wp + 6; d.pad_y = 3; d.pad_x = -1;
+        TRY(launch_conv(d, s));
+    }
+    if (e->instance_norm) TRY(E.norm(E.ws.a, h1 * w1, 64, 0));
+    // stage 1 (64, stride 1): a -> c -> a
+    TRY(E.block(EC_L1B0C1, EC_L1B0C2, -1, E.ws.a, 64, h1, w1, E.ws.b, nullptr, E.ws.c, 64, h1, w1, 1));
+    TRY(E.block(EC_L1B1C1, EC_L1B1C2, -1, E.ws.c, 64, h1, w1, E.ws.b, nullptr, E.ws.a, 64, h1, w1, 1));
+    // stage 2 (96, stride 2)
+    const int h2 = h1 / 2, w2 = w1 / 2;
+    float *sc2 = E.ws.b + (size_t)h2 * w2 * 96;      // tmp and shortcut share buffer b (both quarter-size maps)
+    TRY(E.block(EC_L2B0C1, EC_L2B0C2, EC_L2B0DS, E.ws.a, 64, h1, w1, E.ws.b, sc2, E.ws.c, 96, h2, w2, 2));
+    TRY(E.block(EC_L2B1C1, EC_L2B1C2, -1, E.ws.c, 96, h2, w2, E.ws.b, nullptr, E.ws.a, 96, h2, w2, 1));
+    // stage 3 (128, stride 2)
+    const int h3 = h2 / 2, w3 = w2 / 2;
+    float *sc3 = E.ws.b + (size_t)h3 * w3 * 128;
+    TRY(E.block(EC_L3B0C1, EC_L3B0C2, EC_L3B0DS, E.ws.a, 96, h2, w2, E.ws.b, sc3, E.ws.c, 128, h3, w3, 2));
+    TRY(E.block(EC_L3B1C1, EC_L3B1C2, -1, E.ws.c, 128, h3, w3, E.ws.b, nullptr, E.ws.a, 128, h3, w3, 1));
+    // head
+    if (e->instance_norm) return E.conv(EC_HEAD, E.ws.a, 128, 128, h3, w3, out0, 256, 256, h3, w3, 1, 1, 0);
+    TRY(E.conv(EC_HEAD, E.ws.a, 128, 128, h3, w3, out0, 128, 128, h3, w3, 1, 1, 3));   // net = tanh(first 128)
+    return E.conv(EC_HEAD2, E.ws.a, 128, 128, h3, w3, out1, 128, 128, h3, w3, 1, 1, 1);  // inp = relu(last 128)
+}

@@ -98,6 +98,96 @@ def pack_raft_weights(sd: dict, device) -> list:
     return out
 
 
+_ENC_CONVS = ["conv1", "layer1.0.conv1", "layer1.0.conv2", "layer1.1.conv1", "layer1.1.conv2",
+              "layer2.0.conv1", "layer2.0.conv2", "layer2.0.downsample.0", "layer2.1.conv1", "layer2.1.conv2",
+              "layer3.0.conv1", "layer3.0.conv2", "layer3.0.downsample.0", "layer3.1.conv1", "layer3.1.conv2",
+              "conv2"]
+
+
+def _bn_name(conv_name):
+    """BatchNorm that follows a conv of BasicEncoder (core/extractor.py:6-62,118-166)."""
+    if conv_name == "conv1":
+        return "norm1"
+    if conv_name.endswith("downsample.0"):
+        return conv_name[:-1] + "1"
+    if conv_name == "conv2":
+        return None
+    blk, c = conv_name.rsplit(".", 1)
+    return f"{blk}.norm{c[-1]}"
+
+
+def pack_encoder_weights(sd: dict, prefix: str, batch_norm: bool, device) -> list:
+    """(packed weight, bias) per conv of a BasicEncoder, in EncConv order
+    (csrc/encoder.hip).  Eval-mode batch norm (cnet) is folded into the conv:
+    BN(conv_w(x) + b) = conv_{w*s}(x) + (b*s + t), s = gamma/sqrt(var+eps), t = beta - mean*s.
+    The 7x7 stem is repacked as 7 row taps over 28-float (7 pixels x RGB0) windows; the cnet
+    head is split into its tanh (net) and relu (inp) halves (core/raft.py:146-149)."""
+    g = lambda k: sd[f"{prefix}.{k}"].to(device=device, dtype=torch.float32)  # noqa: E731
+    out = []
+    for name in _ENC_CONVS:
+        w, b = g(name + ".weight"), g(name + ".bias")
+        bn = _bn_name(name) if batch_norm else None
+        if bn is not None:
+            s_ = g(bn + ".weight") / torch.sqrt(g(bn + ".running_var") + 1e-5)
+            t_ = g(bn + ".bias") - g(bn + ".running_mean") * s_
+            w = w * s_.reshape(-1, 1, 1, 1)
+            b = b * s_ + t_
+        if name == "conv1":                       # [64,3,7,7] -> [128][ky][kx*4 + c], c = 3 zero
+            w4 = torch.zeros(64, 7, 7, 4, dtype=torch.float32, device=device)
+            w4[..., :3] = w.permute(0, 2, 3, 1)
+            pk = torch.zeros(128, 7, 32, dtype=torch.float32, device=device)
+            pk[:64, :, :28] = w4.reshape(64, 7, 28)
+            out += [pk.contiguous(), b.contiguous()]
+        elif name == "conv2" and batch_norm:       # cnet head: net | inp halves
+            out += [pack_conv_weight(w[:128].contiguous()), b[:128].contiguous(),
+                    pack_conv_weight(w[128:].contiguous()), b[128:].contiguous()]
+        else:
+            out += [pack_conv_weight(w.contiguous()), b.contiguous()]
+    return out
+
+
+class EncoderEngine:
+    """Handle on the native encoder runtime (``mftx_encoder_*``): fnet or cnet."""
+
+    def __init__(self, state_dict: dict, prefix: str, instance_norm: bool, device):
+        lib = _lib.load()
+        self.device = torch.device(device)
+        self.instance_norm = instance_norm
+        self.weights = pack_encoder_weights(state_dict, prefix, not instance_norm, self.device)
+        arr, self._keep = _lib.ptr_array([_chk(t, "weight") for t in self.weights])
+        handle = C.c_void_p()
+        check(lib.mftx_encoder_create(arr, len(self.weights), int(instance_norm), C.byref(handle)),
+              "mftx_encoder_create")
+        self._h = handle
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.load().mftx_encoder_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def forward(self, img_u8: torch.Tensor):
+        """img_u8: uint8 [H0, W0, 3] BGR on the device -> pixel-major maps at 1/8 resolution."""
+        lib = _lib.load()
+        H0, W0 = img_u8.shape[:2]
+        h, w = -(-H0 // 8), -(-W0 // 8)
+        need = lib.mftx_encoder_workspace_bytes(H0, W0)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if self.instance_norm:
+            outs = (torch.empty(h * w, 256, dtype=torch.float32, device=self.device), None)
+        else:
+            outs = (torch.empty(h * w, 128, dtype=torch.float32, device=self.device),
+                    torch.empty(h * w, 128, dtype=torch.float32, device=self.device))
+        check(lib.mftx_encoder_forward(self._h, _chk(img_u8, "img", torch.uint8), H0, W0, outs[0].data_ptr(),
+                                       outs[1].data_ptr() if outs[1] is not None else None,
+                                       self._ws.data_ptr(), self._ws.numel(), _stream()), "mftx_encoder_forward")
+        return outs
+
+
 # ---------------------------------------------------------------------------
 # per-op wrappers
 # ---------------------------------------------------------------------------
@@ -124,7 +214,7 @@ def corr_lookup(lv, coords: torch.Tensor, h: int, w: int, r: int = 4):
 
 
 def conv2d(x: torch.Tensor, wpk: torch.Tensor, bias, P, h, w, N, kh, kw, act=None, out_scale=1.0, x2=None,
-           addend=None):
+           addend=None, stride=0, hin=0, win=0, pad_y=0, pad_x=0, residual_mode=0):
     """x: pixel-major [P*h*w, C0] (optionally concatenated with x2 [P*h*w, C1]) ->
     [P*h*w, N]."""
     lib = _lib.load()
@@ -141,6 +231,7 @@ def conv2d(x: torch.Tensor, wpk: torch.Tensor, bias, P, h, w, N, kh, kw, act=Non
     d.P, d.h, d.w, d.N, d.kh, d.kw = P, h, w, N, kh, kw
     d.act, d.out_scale = ACT[act], out_scale
     d.addend, d.ld_addend = (_chk(addend, "addend"), addend.shape[1]) if addend is not None else (None, 0)
+    d.stride, d.hin, d.win, d.pad_y, d.pad_x, d.residual_mode = stride, hin, win, pad_y, pad_x, residual_mode
     check(lib.mftx_conv2d(C.byref(d), _stream()), "mftx_conv2d")
     return out
 

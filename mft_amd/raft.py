@@ -107,8 +107,14 @@ class RAFTWrapper:
         sd = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v)))
               for k, v in strip_module_prefix(state_dict).items()}
         self.sd = {k: v.to(self.device) for k, v in sd.items()}
-        self.fnet = Encoder(self.sd, "fnet", "instance")
-        self.cnet = Encoder(self.sd, "cnet", "batch")
+        # encoders: native HIP (default) or the PyTorch-ROCm/MIOpen implementation (C.torch_encoders)
+        self.native_encoders = not getattr(config, "torch_encoders", False)
+        if self.native_encoders:
+            self.fnet_engine = ops.EncoderEngine(self.sd, "fnet", True, self.device)
+            self.cnet_engine = ops.EncoderEngine(self.sd, "cnet", False, self.device)
+        else:
+            self.fnet = Encoder(self.sd, "fnet", "instance")
+            self.cnet = Encoder(self.sd, "cnet", "batch")
         self.engine = ops.RaftEngine(self.sd, self.device)
         self._frames = {}
         # Optional (C.async_encode): encode new frames on a side stream.  The encoders of frame t
@@ -133,6 +139,16 @@ class RAFTWrapper:
         """uint8 BGR (H,W,3) -> cached pixel-major features (MFT/raft.py:41-48,
         core/raft.py:122-149)."""
         H0, W0 = img_bgr.shape[:2]
+        if self.native_encoders:
+            img = img_bgr if isinstance(img_bgr, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img_bgr))
+            img = img.to(self.device, non_blocking=True).contiguous()
+            pads = pad_amounts(H0, W0)
+            h, w = (H0 + pads[2] + pads[3]) // 8, (W0 + pads[0] + pads[1]) // 8
+            fmap, _ = self.fnet_engine.forward(img)
+            net = inp = None
+            if want_context:
+                net, inp = self.cnet_engine.forward(img)
+            return FrameFeatures(fmap, net, inp, h, w, pads, (H0, W0))
         if isinstance(img_bgr, torch.Tensor):       # frame already resident in HBM (uint8 H,W,3 BGR)
             rgb = img_bgr.to(self.device).flip(-1)
         else:

@@ -323,3 +323,51 @@ def test_conv2d_addend_splits_linear_conv(ops_mod):
     out = ops_mod.conv2d(ap, ops_mod.pack_conv_weight(wt[:, :128].contiguous().to(DEV)), None, P, h, w, 256, 1, 5,
                          act="sigmoid", addend=pre)
     assert maxerr(out.reshape(P, h, w, 256).permute(0, 3, 1, 2).cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,h,w", [(64, 96, 3, 2, 32, 48), (64, 96, 1, 2, 32, 48), (96, 128, 3, 2, 17, 23)])
+def test_conv2d_strided_vs_torch(ops_mod, cin, cout, k, stride, h, w):
+    """Stride-2 convolutions of the encoders (core/extractor.py:6-62): input grid h x w,
+    output grid floor((h + 2p - k)/2) + 1."""
+    g = torch.Generator().manual_seed(31 + k)
+    x = torch.randn(1, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * 0.05
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x, wt, b, stride=stride, padding=k // 2)
+    ho, wo = ref.shape[-2:]
+    xp = x.permute(0, 2, 3, 1).reshape(h * w, cin).contiguous().to(DEV)
+    out = ops_mod.conv2d(xp, ops_mod.pack_conv_weight(wt.to(DEV)), b.to(DEV), 1, ho, wo, cout, k, k, stride=stride,
+                         hin=h, win=w)
+    assert maxerr(out.reshape(1, ho, wo, cout).permute(0, 3, 1, 2).cpu(), ref) < 2e-5
+    # residual epilogue: relu(relu(conv + b) + res)
+    res = torch.randn(1, cout, ho, wo, generator=g)
+    out = ops_mod.conv2d(xp, ops_mod.pack_conv_weight(wt.to(DEV)), b.to(DEV), 1, ho, wo, cout, k, k, act="relu",
+                         stride=stride, hin=h, win=w, residual_mode=1,
+                         addend=res.permute(0, 2, 3, 1).reshape(ho * wo, cout).contiguous().to(DEV))
+    assert maxerr(out.reshape(1, ho, wo, cout).permute(0, 3, 1, 2).cpu(), torch.relu(torch.relu(ref) + res)) < 2e-5
+
+
+@pytest.mark.parametrize("size", [(128, 192), (125, 187)])
+def test_native_encoders_vs_oracle(ops_mod, gold, weights_np, weights_cpu, size):
+    """fnet (instance norm) and cnet (folded batch norm) on the MFMA conv kernel vs the
+    oracle's encoders; the 128x192 case is also pinned to the reference-generated golden."""
+    from mft_amd.synth import SyntheticVideo
+    H, W = size
+    vid = SyntheticVideo(H, W, n_frames=4, seed=3)
+    sd = {k: T(v).to(DEV) for k, v in weights_np.items()}
+    fe = ops_mod.EncoderEngine(sd, "fnet", True, DEV)
+    ce = ops_mod.EncoderEngine(sd, "cnet", False, DEV)
+    img = T(vid[0]).to(DEV)
+    fmap, _ = fe.forward(img)
+    net, inp = ce.forward(img)
+    x = O.normalise_image(O.preprocess(vid[0]))
+    rf = O.encoder(x, weights_cpu, "fnet", "instance")
+    rc = O.encoder(x, weights_cpu, "cnet", "batch")
+    h, w = rf.shape[-2:]
+    assert maxerr(from_pm(fmap, h, w), rf) < 1e-4
+    assert maxerr(from_pm(net, h, w), torch.tanh(rc[:, :128])) < 1e-4
+    assert maxerr(from_pm(inp, h, w), torch.relu(rc[:, 128:])) < 1e-4
+    if size == (128, 192):
+        assert maxerr(from_pm(fmap, h, w), T(gold["fnet"])) < 1e-4
+        assert maxerr(torch.cat([from_pm(net, h, w), from_pm(inp, h, w)], 1),
+                      torch.cat([torch.tanh(T(gold["cnet"])[:, :128]), torch.relu(T(gold["cnet"])[:, 128:])], 1)) < 1e-4
