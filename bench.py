@@ -36,8 +36,9 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak
 CATS = ["corr_volume_gemm", "corr_pool", "corr_lookup", "conv_gemm", "convf1", "glue", "convex_upsample",
-        "chain_select"]
-FLOP_CATS = {0, 3, 4}
+        "chain_select", "conv_small_n", "encoder_instnorm"]
+FLOP_CATS = {0, 3, 4, 8}
+VALU_CATS = {4, 8}
 _T0 = time.time()
 
 
@@ -72,12 +73,18 @@ def build_tracker(args, sharded):
 
 
 def profile_pass(tracker, frames, first, steps):
-    """Same steps again with HIP-event brackets around every kernel launch."""
+    """Same steps again with HIP-event brackets around every kernel launch.  Frames are encoded on the
+    main stream here so that every kernel is timed alone (in the timed region the encoders of frame
+    t+1 overlap frame t on a side stream, which would stretch the bracketed intervals)."""
     from mft_amd import _lib
     lib = _lib.load()
+    enc_stream = getattr(tracker.flower, "_enc_stream", None)
+    tracker.flower._enc_stream = None
+    torch.cuda.synchronize()
     lib.mftx_profile_begin()
     for i in range(first, first + steps):
         tracker.track(frames[i])
+    tracker.flower._enc_stream = enc_stream
     n = len(CATS)
     ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
     _lib.check(lib.mftx_profile_end(ms, work, cnt, n), "mftx_profile_end")
@@ -88,8 +95,8 @@ def profile_pass(tracker, frames, first, steps):
         t = ms[i] * 1e-3
         d = {"launches": int(cnt[i]), "avg_us": 1e6 * t / cnt[i], "total_ms_per_step": ms[i] / steps}
         if i in FLOP_CATS:
-            d.update(unit="TFLOP/s", achieved=work[i] / t / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, bound="mfma",
-                     work_per_launch=work[i] / cnt[i])
+            d.update(unit="TFLOP/s", achieved=work[i] / t / 1e12, peak=FP32_MFMA_PEAK_TFLOPS,
+                     bound="valu" if i in VALU_CATS else "mfma", work_per_launch=work[i] / cnt[i])
         elif work[i] > 0:
             d.update(unit="GB/s", achieved=work[i] / t / 1e9, peak=HBM_PEAK_GBS, bound="hbm",
                      work_per_launch=work[i] / cnt[i])

@@ -48,9 +48,10 @@ const char *mftx_last_error_string(void);
 
 /* Optional per-kernel timing (HIP events on the launch stream; bench.py's
  * roofline leg).  Categories: 0 corr volume GEMM, 1 pyramid pooling, 2 lookup,
- * 3 conv implicit GEMM, 4 convf1, 5 glue, 6 convex upsample, 7 chain/select.
- * work[] = algorithmic flops (0, 3, 4) or bytes (1, 2, 6, 7) booked per launch. */
-#define MFTX_PROFILE_CATEGORIES 8
+ * 3 conv implicit GEMM, 4 convf1, 5 glue, 6 convex upsample, 7 chain/select,
+ * 8 small-N conv, 9 encoder instance-norm passes.
+ * work[] = algorithmic flops (0, 3, 4, 8) or bytes (1, 2, 6, 7, 9) booked per launch. */
+#define MFTX_PROFILE_CATEGORIES 10
 int mftx_profile_begin(void);
 int mftx_profile_end(double *ms, double *work, long long *count, int n);
 

@@ -88,7 +88,7 @@ int launch_conv_small(const mftx_conv_desc &d, hipStream_t s) {
     const int strips = cdiv(d.w, SN_STRIP);
     const int waves = d.P * d.h * strips;
     dim3 grid(cdiv(waves, 4));
-    ProfScope prof(PC_CONVF1, s, 2.0 * d.P * d.h * d.w * d.N * 9.0 * 256.0);
+    ProfScope prof(PC_CONV_SMALL, s, 2.0 * d.P * d.h * d.w * d.N * 9.0 * 256.0);
 #define SN_LAUNCH(NN)                                                                                              \
     hipLaunchKernelGGL(conv3x3_small_kernel<NN>, grid, dim3(256), 0, s, d.a0, d.lda0, d.wpk, d.bias, d.out, d.ldo, \
                        d.P, d.h, d.w, strips)

@@ -40,7 +40,7 @@ __global__ void enc_prep_kernel(const uint8_t *__restrict__ img, int H0, int W0,
 }
 
 // per-channel partial sums over a slab of rows: x [rows][C] -> part [slabs][C][2] (sum, sum of squares; fp64)
-constexpr int IN_SLABS = 64;
+constexpr int IN_SLABS = 256;   // row slabs per map: enough workgroups to stream at HBM rate
 __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float *__restrict__ x, int rows, int C,
                                                                double *__restrict__ part) {
     __shared__ double sh[256][2];
@@ -65,21 +65,26 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float *__re
     }
 }
 
+// partial sums -> per-channel (mean, rstd), in a fixed order (deterministic)
+__global__ void instnorm_finalize_kernel(const double *__restrict__ part, int rows, int C, float *__restrict__ stat) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < IN_SLABS; ++k) { s += part[((long long)k * C + c) * 2]; q += part[((long long)k * C + c) * 2 + 1]; }
+    const double m = s / rows;
+    const double var = q / rows - m * m;               // biased variance, as nn.InstanceNorm2d
+    stat[2 * c] = (float)m;
+    stat[2 * c + 1] = (float)(1.0 / sqrt((var > 0 ? var : 0.0) + 1e-5));
+}
+
 // y = relu((x - mean) * rstd)            [mode 0]
 // y = relu(res + relu((x - mean)*rstd))  [mode 1: residual block tail]
 // y = (x - mean) * rstd                  [mode 2: shortcut branch, no activation]
 __global__ __launch_bounds__(256) void instnorm_apply_kernel(float *__restrict__ x, int rows, int C,
-                                                             const double *__restrict__ part,
+                                                             const float *__restrict__ stat,
                                                              const float *__restrict__ res, int mode) {
     __shared__ float mean_s[256], rstd_s[256];
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double s = 0.0, q = 0.0;
-        for (int k = 0; k < IN_SLABS; ++k) { s += part[((long long)k * C + c) * 2]; q += part[((long long)k * C + c) * 2 + 1]; }
-        const double m = s / rows;
-        const double var = q / rows - m * m;           // biased variance, as nn.InstanceNorm2d
-        mean_s[c] = (float)m;
-        rstd_s[c] = (float)(1.0 / sqrt((var > 0 ? var : 0.0) + 1e-5));
-    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { mean_s[c] = stat[2 * c]; rstd_s[c] = stat[2 * c + 1]; }
     __syncthreads();
     const long long n4 = (long long)rows * C / 4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -113,6 +118,7 @@ struct EncWs {
     float *img;           // [Hp][Wp+6][4]
     float *a, *b, *c;     // activation ping-pong, each max(stage maps)
     double *part;         // instance-norm partial sums
+    float *stat;          // per-channel (mean, rstd)
     size_t bytes;
 };
 
@@ -130,6 +136,7 @@ static EncWs enc_carve(void *base, int Hp, int Wp) {
     ws.b = reinterpret_cast<float *>(take(big));
     ws.c = reinterpret_cast<float *>(take(big));
     ws.part = reinterpret_cast<double *>(take((size_t)IN_SLABS * 256 * 2 * sizeof(double)));
+    ws.stat = reinterpret_cast<float *>(take(256 * 2 * sizeof(float)));
     ws.bytes = off;
     return ws;
 }
@@ -193,15 +200,20 @@ struct Enc {
     }
     int norm(float *x, int rows, int C, int mode, const float *res = nullptr) {
         {
-            ProfScope prof(PC_GLUE, s, 0);
+            ProfScope prof(PC_ENC_NORM, s, 4.0 * rows * C);
             hipLaunchKernelGGL(instnorm_partial_kernel, dim3(cdiv(C, 64), IN_SLABS), dim3(256), 0, s, x, rows, C, ws.part);
         }
         TRY(check_launch("instnorm_partial"));
-        const long long n4 = (long long)rows * C / 4;
-        const int blocks = (int)std::min<long long>((n4 + 255) / 256, 2048);
         {
-            ProfScope prof(PC_GLUE, s, 0);
-            hipLaunchKernelGGL(instnorm_apply_kernel, dim3(blocks), dim3(256), 0, s, x, rows, C, ws.part, res, mode);
+            ProfScope prof(PC_ENC_NORM, s, 0);
+            hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, ws.part, rows, C, ws.stat);
+        }
+        TRY(check_launch("instnorm_finalize"));
+        const long long n4 = (long long)rows * C / 4;
+        const int blocks = (int)std::min<long long>((n4 + 255) / 256, 4096);
+        {
+            ProfScope prof(PC_ENC_NORM, s, (mode == 1 ? 12.0 : 8.0) * rows * C);
+            hipLaunchKernelGGL(instnorm_apply_kernel, dim3(blocks), dim3(256), 0, s, x, rows, C, ws.stat, res, mode);
         }
         return check_launch("instnorm_apply");
     }

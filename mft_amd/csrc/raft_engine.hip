@@ -39,7 +39,8 @@ __global__ __launch_bounds__(128) void convf1_kernel(const float *__restrict__ c
                                                      const float *__restrict__ w98,   // [98][128]
                                                      const float *__restrict__ bias, float *__restrict__ flo1,
                                                      float *__restrict__ hx, int h, int w, int strips_per_row) {
-    __shared__ float patch[7][F1_CELLS + 6][2];
+    // flow patch of the strip: 7 rows x (16 + 6) cells x (fx, fy), rows padded to 48 floats
+    __shared__ __attribute__((aligned(16))) float patch[7][48];
     const int strip = blockIdx.x % strips_per_row;
     const int rowid = blockIdx.x / strips_per_row;   // img*h + y
     const int y = rowid % h;
@@ -54,8 +55,8 @@ __global__ __launch_bounds__(128) void convf1_kernel(const float *__restrict__ c
             fx = coords1[2 * cell] - (float)xx;
             fy = coords1[2 * cell + 1] - (float)yy;
         }
-        patch[r][c][0] = fx;
-        patch[r][c][1] = fy;
+        patch[r][2 * c] = fx;
+        patch[r][2 * c + 1] = fy;
     }
     __syncthreads();
     const int co = threadIdx.x;
@@ -63,21 +64,31 @@ __global__ __launch_bounds__(128) void convf1_kernel(const float *__restrict__ c
     const float b = bias[co];
 #pragma unroll
     for (int t = 0; t < F1_CELLS; ++t) acc[t] = b;
-    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll 1
+    for (int ky = 0; ky < 7; ++ky) {
+        // the whole patch row goes to registers once (11 broadcast ds_read_b128), then 7 x 16 x 2 FMAs
+        float row[44];
+#pragma unroll
+        for (int q = 0; q < 11; ++q) {
+            const float4 v = *reinterpret_cast<const float4 *>(&patch[ky][4 * q]);
+            row[4 * q] = v.x; row[4 * q + 1] = v.y; row[4 * q + 2] = v.z; row[4 * q + 3] = v.w;
+        }
+#pragma unroll
         for (int kx = 0; kx < 7; ++kx) {
             const float w0 = w98[((ky * 7 + kx) * 2 + 0) * 128 + co];
             const float w1 = w98[((ky * 7 + kx) * 2 + 1) * 128 + co];
 #pragma unroll
             for (int t = 0; t < F1_CELLS; ++t)
-                acc[t] += w0 * patch[ky][t + kx][0] + w1 * patch[ky][t + kx][1];
+                acc[t] += w0 * row[2 * (t + kx)] + w1 * row[2 * (t + kx) + 1];
         }
+    }
 #pragma unroll
     for (int t = 0; t < F1_CELLS; ++t) {
         const int x = x0 + t;
         if (x < w) {
             const long long cell = img_base + (long long)y * w + x;
             flo1[cell * 128 + co] = fmaxf(acc[t], 0.f);
-            if (co < 2) hx[cell * 384 + 382 + co] = patch[3][t + 3][co];
+            if (co < 2) hx[cell * 384 + 382 + co] = patch[3][2 * (t + 3) + co];
         }
     }
 }
