@@ -371,3 +371,38 @@ def test_native_encoders_vs_oracle(ops_mod, gold, weights_np, weights_cpu, size)
         assert maxerr(from_pm(fmap, h, w), T(gold["fnet"])) < 1e-4
         assert maxerr(torch.cat([from_pm(net, h, w), from_pm(inp, h, w)], 1),
                       torch.cat([torch.tanh(T(gold["cnet"])[:, :128]), torch.relu(T(gold["cnet"])[:, 128:])], 1)) < 1e-4
+
+
+def test_raft_engine_argument_errors(ops_mod, weights_np):
+    """Error behaviour of the engine entry points: negative codes surface as MftxError
+    (the reference's native op raises RuntimeError through TORCH_CHECK)."""
+    import ctypes as C
+    from mft_amd import _lib
+    from mft_amd._lib import MftxError
+    lib = _lib.load()
+    sd = {k: T(v).to(DEV) for k, v in weights_np.items()}
+    eng = ops_mod.RaftEngine(sd, DEV)
+    h = w = 16
+    f = torch.zeros(1, h * w, 256, device=DEV)
+    n = torch.zeros(1, h * w, 128, device=DEV)
+    out = [torch.zeros(1, c, 8 * h, 8 * w, device=DEV) for c in (2, 1, 1)]
+    ws = torch.zeros(1024, dtype=torch.uint8, device=DEV)            # far too small
+    rc = lib.mftx_raft_refine(eng._h, 1, h, w, 2, f.data_ptr(), f.data_ptr(), n.data_ptr(), n.data_ptr(), 0, 0, 0, 0,
+                              out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), None, ws.data_ptr(), ws.numel(), None)
+    assert rc == -3 and b"workspace" in lib.mftx_last_error_string()
+    with pytest.raises(MftxError):
+        eng.refine(f, f, n, n, 8, 8, 2)                               # grid too small for 4 pyramid levels
+    with pytest.raises(MftxError):
+        eng.refine(f, f, n, n, h, w, 0)                               # iters < 1
+    with pytest.raises(MftxError):
+        eng.refine(f, f, n, n, h, w, 2, pads=(4, 4, 0, 0))            # padding >= 8
+    with pytest.raises(MftxError):
+        eng.refine(f.cpu(), f, n, n, h, w, 2)                         # CPU tensor
+    bad = C.c_void_p()
+    assert lib.mftx_raft_create(None, 34, C.byref(bad)) == -1
+    assert lib.mftx_raft_refine(None, 1, h, w, 2, f.data_ptr(), f.data_ptr(), n.data_ptr(), n.data_ptr(), 0, 0, 0, 0,
+                                out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), None, ws.data_ptr(), ws.numel(),
+                                None) == -4
+    # the happy path still works after the failures
+    flow, occl, sigma = eng.refine(f, f, n, n, h, w, 2)
+    assert bool(torch.isfinite(flow).all()) and float(occl.min()) >= 0 and float(sigma.min()) >= 0

@@ -263,3 +263,40 @@ def test_delta_sharding_two_ranks_gloo(tmp_path):
     for k in single.files:
         assert np.array_equal(r0[k], r1[k]), k           # replicas stay identical
         assert np.array_equal(r0[k], single[k]), k       # and equal to the unsharded run
+
+
+def test_flow_cache_tiers(tmp_path):
+    from mft_amd.io import FlowCache
+    f = lambda v: (torch.full((2, 4, 4), float(v)), torch.zeros(1, 4, 4), torch.ones(1, 4, 4))  # noqa: E731
+    one = 4 * 4 * 4 * 4                      # bytes of one (flow, occl, sigma) triple
+    c = FlowCache(tmp_path / "c", max_RAM_MB=2 * one / 1e6, max_GPU_RAM_MB=one / 1e6, device="cpu")
+    assert c.read(0, 1) == (None, None, None)
+    for i in range(5):
+        c.write(i, i + 1, *f(i))
+    assert len(c.gpu_ram_cache) == 1 and len(c.ram_cache) == 2 and len(list((tmp_path / "c").glob("*.pt"))) == 2
+    for i in range(5):
+        assert float(c.read(i, i + 1)[0][0, 0, 0]) == i
+    assert c.backup_to_disk() == 3
+    d = FlowCache(tmp_path / "c", device="cpu")
+    assert d.load_from_disk() == 5 and float(d.read(3, 4)[0][0, 0, 0]) == 3
+    c.clear()
+    assert c.read(0, 1) == (None, None, None)
+    # drives the tracker like the reference's FlowCache does
+    fl = StubFlower()
+    cache = FlowCache(None, device="cpu")
+    tr = make_tracker(fl, deltas=(np.inf, 1, 2))
+    tr.init(gi.id_image(0), flow_cache=cache)
+    for i in range(1, 4):
+        tr.track(gi.id_image(i))
+    assert (2, 3) in cache.gpu_ram_cache and (0, 3) not in cache.gpu_ram_cache
+
+
+def test_point_tracking_adapter():
+    from mft_amd.point_tracking import convert_to_point_tracking
+    from mft_amd.results import FlowOUTrackingResult
+    flow = torch.zeros(2, 16, 24); flow[0] = 2.0; flow[1] = -1.0
+    occl = torch.zeros(1, 16, 24); occl[0, 8:, :] = 1.0
+    r = FlowOUTrackingResult(flow, occl, torch.zeros(1, 16, 24))
+    q = np.array([[3.0, 4.0], [10.0, 12.0]], np.float32)
+    coords, o = convert_to_point_tracking(r, q)
+    assert np.allclose(coords, q + [2.0, -1.0]) and np.allclose(o, [0.0, 1.0])
