@@ -470,6 +470,9 @@ int launch_corr_volume(const float *f1, const float *f2, int P, int C, int N, fl
     a.act = 0; a.out_scale = 1.0f / sqrtf((float)C);
     a.a_bstride = (long long)N * C; a.w_bstride = (long long)N * C; a.o_bstride = (long long)N * N;
     a.a0_bytes = (unsigned)((long long)N * C * 4); a.a1_bytes = 0; a.w_bytes = a.a0_bytes;
+    static const int forced = [] { const char *e = getenv("MFTX_CORR_TILE"); return e ? atoi(e) : -1; }();
+    if (forced == 2) return launch_cfg<64, 64, 2, 2, EPI_GENERIC, 2>(a, P, s, PC_CORR_VOLUME);
+    if (forced == 1) return launch_cfg<128, 64, 2, 2, EPI_GENERIC, 2>(a, P, s, PC_CORR_VOLUME);
     if (N >= 1024) return launch_cfg<128, 128, 2, 2, EPI_GENERIC, 2>(a, P, s, PC_CORR_VOLUME);
     return launch_cfg<64, 64, 2, 2, EPI_GENERIC, 2>(a, P, s, PC_CORR_VOLUME);
 }
