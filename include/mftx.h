@@ -176,6 +176,23 @@ int mftx_chain_select(int K,
                       float thr, int H, int W,
                       float *flowO, float *occlO, float *sigmaO, int8_t *chosen, void *stream);
 
+/* ---- 8f-2: flow-cache codec (".flowouX16" entries) -----------------------------
+ * Replaces compress_channel / decompress_channel of write_flowou_X16 / read_flowou_X16
+ * (MFT/utils/io.py:495-512, 548-551): per-channel min/max, uint16 quantisation with
+ * round-half-even, and its inverse, in float32 exactly as numpy evaluates them.
+ *   x [n] float32 (device), q [n] uint16 (device), lohi [2] float32 (device: min, max)
+ *   workspace: mftx_quantize_workspace_bytes() bytes of device memory. */
+size_t mftx_quantize_workspace_bytes(void);
+int mftx_quantize_u16(const float *x, long long n, uint16_t *q, float *lohi,
+                      void *workspace, size_t workspace_bytes, void *stream);
+int mftx_dequantize_u16(const uint16_t *q, long long n, float lo, float hi, float *x, void *stream);
+
+/* HOST helper of the same codec: reconstruct the scanlines of an inflated, non-interlaced PNG
+ * IDAT stream in place (what cv2.imdecode does inside read_flowou_X16, MFT/utils/io.py:541-543).
+ * rows: height x (1 + row_bytes) bytes in, height x row_bytes bytes out (compacted to the front);
+ * bpp: bytes per pixel. */
+int mftx_png_unfilter(uint8_t *rows, int height, int row_bytes, int bpp);
+
 #ifdef __cplusplus
 }
 #endif

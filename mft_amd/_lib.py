@@ -58,6 +58,10 @@ SIGNATURES = {
     "mftx_warp_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mftx_select": (C.c_int, [C.c_int, _PP, _PP, _PP, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 5),
     "mftx_chain_select": (C.c_int, [C.c_int] + [_PP] * 6 + [C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "mftx_quantize_workspace_bytes": (C.c_size_t, []),
+    "mftx_quantize_u16": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mftx_dequantize_u16": (C.c_int, [C.c_void_p, C.c_longlong, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "mftx_png_unfilter": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
 }
 
 _lib = None

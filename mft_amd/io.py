@@ -5,8 +5,11 @@ and ``write(left_id, right_id, flow, occl, sigma)``.
 
 Tiers, filled in this order like the reference: device memory (HBM, default budget 5 GB --
 raise it freely, an MI355X has 288 GB), host RAM, then one file per pair in ``cache_dir``.
-The on-disk format is a plain ``torch.save`` of the three fp32 tensors, not the reference's
-``.flowouX16.pkl`` (uint16-quantised PNG-in-pickle, needs cv2).
+The on-disk format is the reference's ``<left>--<right>.flowouX16.pkl`` (uint16-quantised
+PNG-in-pickle, ``mft_amd/flowou_codec.py``): a cache directory written by the
+reference can be loaded here and vice versa.  Like in the reference, an entry that went through
+the disk tier comes back quantised (16 bits over the channel's range), entries served from HBM or
+RAM are exact.
 """
 from __future__ import annotations
 
@@ -14,6 +17,8 @@ import shutil
 from pathlib import Path
 
 import torch
+
+SUFFIX = ".flowouX16.pkl"
 
 
 def _nbytes(tensors):
@@ -32,7 +37,7 @@ class FlowCache:
             self.cache_dir.mkdir(parents=True, exist_ok=True)
 
     def _path(self, left_id, right_id):
-        return self.cache_dir / f"{left_id}--{right_id}.flowou.pt"
+        return self.cache_dir / f"{left_id}--{right_id}{SUFFIX}"
 
     def ram_space_left(self):
         return max(self.max_RAM_MB * 1000000 - self.bytes_used, 0)
@@ -48,7 +53,7 @@ class FlowCache:
             return tuple(t.to(self.device) for t in self.ram_cache[key])
         if self.cache_dir is not None and self._path(*key).exists():
             try:
-                val = tuple(t.to(self.device) for t in torch.load(self._path(*key), map_location="cpu"))
+                val = self._load(self._path(*key))
                 self.write(left_id, right_id, *val)      # promote to the faster tiers
                 return val
             except Exception:
@@ -68,8 +73,17 @@ class FlowCache:
                 self.bytes_used += _nbytes(val)
             self.ram_cache[key] = val
         elif self.cache_dir is not None and not self._path(*key).exists():
-            torch.save(tuple(t.cpu() for t in val), self._path(*key))
+            self._save(self._path(*key), val)
         self.n_saved += 1
+
+    def _save(self, path, val):
+        from .flowou_codec import write_flowou_X16
+        self.cache_dir.mkdir(parents=True, exist_ok=True)
+        write_flowou_X16(path, *(t.to(self.device) for t in val))
+
+    def _load(self, path):
+        from .flowou_codec import read_flowou_X16
+        return read_flowou_X16(path, device=self.device)
 
     def clear(self, clear_disk=True):
         self.gpu_ram_cache.clear()
@@ -87,17 +101,17 @@ class FlowCache:
         for cache in (self.ram_cache, self.gpu_ram_cache):
             for key, val in cache.items():
                 if not self._path(*key).exists():
-                    torch.save(tuple(t.cpu() for t in val), self._path(*key))
+                    self._save(self._path(*key), val)
                     n += 1
         return n
 
     def load_from_disk(self):
         assert self.cache_dir is not None
         n = 0
-        for path in sorted(self.cache_dir.glob("*.flowou.pt")):
-            left_id, right_id = (int(x) for x in path.name[: -len(".flowou.pt")].split("--"))
+        for path in sorted(self.cache_dir.glob("*" + SUFFIX)):
+            left_id, right_id = (int(x) for x in path.name[: -len(SUFFIX)].split("--"))
             try:
-                val = tuple(t.to(self.device) for t in torch.load(path, map_location="cpu"))
+                val = self._load(path)
                 self.write(left_id, right_id, *val)
                 n += 1
             except Exception:

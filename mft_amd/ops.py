@@ -316,6 +316,41 @@ def chain_select(Ls, Rs, thr, want_chosen=False):
     return out + (chosen,)
 
 
+_quant_ws = {}
+
+
+def quantize_u16(x):
+    """One channel of a cache entry -> (uint16 tensor of x's shape, lohi float32[2] = (min, max)),
+    both on the device (``compress_channel`` of MFT/utils/io.py:495-506).  No host sync."""
+    lib = _lib.load()
+    if isinstance(x, torch.Tensor) and x.is_cuda:
+        x = x.contiguous()
+    _chk(x, "x")
+    if x.numel() == 0:
+        raise MftxError("quantize_u16: empty channel")
+    ws = _quant_ws.get(x.device)
+    if ws is None:
+        ws = _quant_ws[x.device] = torch.empty(lib.mftx_quantize_workspace_bytes(), dtype=torch.uint8, device=x.device)
+    q = torch.empty(x.shape, dtype=torch.uint16, device=x.device)
+    lohi = torch.empty(2, dtype=torch.float32, device=x.device)
+    check(lib.mftx_quantize_u16(x.data_ptr(), x.numel(), q.data_ptr(), lohi.data_ptr(), ws.data_ptr(), ws.numel(),
+                                _stream()), "mftx_quantize_u16")
+    return q, lohi
+
+
+def dequantize_u16(q, lo, hi):
+    """uint16 device tensor + the channel's (min, max) -> float32 (``decompress_channel``,
+    MFT/utils/io.py:548-551)."""
+    lib = _lib.load()
+    if isinstance(q, torch.Tensor) and q.is_cuda:
+        q = q.contiguous()
+    _chk(q, "q", torch.uint16)
+    x = torch.empty(q.shape, dtype=torch.float32, device=q.device)
+    check(lib.mftx_dequantize_u16(q.data_ptr(), q.numel(), float(lo), float(hi), x.data_ptr(), _stream()),
+          "mftx_dequantize_u16")
+    return x
+
+
 class RaftEngine:
     """Handle on the native refinement runtime (``mftx_raft_*``)."""
 

@@ -80,11 +80,29 @@ class FlowOUTrackingResult(object):
     # ---- IO (plain pickle of the three arrays; the reference's .flowouX16
     # codec, MFT/utils/io.py:495-563, is outside this tier's scope) ---------
     def write(self, path):
+        """``*.flowouX16.pkl`` -- the reference's uint16-quantised entry (MFT/results.py:61-65,
+        MFT/utils/io.py:179-198), quantised on the device; any other name: a plain fp32 pickle.
+        (The fixed-point ``.flowou.png`` and the ``.flowouX32`` variants are not rebuilt.)"""
+        from pathlib import Path
+        suffixes = Path(path).suffixes
+        if suffixes and suffixes[0] == ".flowouX16":
+            from .flowou_codec import write_flowou_X16
+            dev = self.flow.device if self.flow.is_cuda else "cuda"
+            write_flowou_X16(path, self.flow.to(dev), self.occlusion.to(dev), self.sigma.to(dev))
+            return
+        if suffixes and suffixes[0] in (".flowou", ".flowouX32"):
+            raise NotImplementedError(f"{suffixes[0]} entries are not supported, use .flowouX16.pkl")
         with open(path, "wb") as f:
             pickle.dump({k: getattr(self, k).detach().cpu().numpy() for k in ("flow", "occlusion", "sigma")}, f)
 
     @classmethod
     def read(cls, path):
+        """Counterpart of ``write``; like the reference (MFT/results.py:67-72) the result is on the host."""
+        from pathlib import Path
+        suffixes = Path(path).suffixes
+        if suffixes and suffixes[0] == ".flowouX16":
+            from .flowou_codec import read_flowou_X16
+            return FlowOUTrackingResult(*(t.cpu() for t in read_flowou_X16(path)))
         with open(path, "rb") as f:
             d = pickle.load(f)
         return FlowOUTrackingResult(torch.from_numpy(d["flow"]), torch.from_numpy(d["occlusion"]),

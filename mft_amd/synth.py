@@ -66,25 +66,38 @@ class SyntheticVideo:
     def __len__(self):
         return self.n_frames
 
-    def __getitem__(self, i):
-        if not 0 <= i < self.n_frames:
-            raise IndexError(i)
+    def camera(self, i):
+        """Frame i's camera: canvas = A @ (pixel - centre) + b  ->  (A (2,2), b (2,))."""
         H, W, S, ph = self.H, self.W, self._S, self._ph
         t = float(i)
-        # camera: sub-pixel drift, slow rotation and zoom
+        # sub-pixel drift, slow rotation and zoom
         tx = 0.08 * max(H, W) * np.sin(0.031 * t + ph[0]) + 0.37 * t * 0.1
         ty = 0.06 * max(H, W) * np.sin(0.023 * t + ph[1])
         ang = 0.10 * np.sin(0.017 * t + ph[2])
         zoom = 1.0 + 0.08 * np.sin(0.013 * t + ph[3])
         ca, sa = np.cos(ang) * zoom, np.sin(ang) * zoom
-        xs = ca * self._xx - sa * self._yy + S / 2 + tx
-        ys = sa * self._xx + ca * self._yy + S / 2 + ty
-        img = _sample_bilinear(self._canvas, xs, ys)
-        # occluder: textured square on its own trajectory
+        return np.array([[ca, -sa], [sa, ca]]), np.array([S / 2 + tx, S / 2 + ty])
+
+    def occluder(self, i):
+        """Frame i's occluding square: (x0, y0, side) in pixels (may stick out of the frame)."""
+        H, W, ph = self.H, self.W, self._ph
+        t = float(i)
         side = max(H, W) // 6
         cx = W / 2 + 0.3 * W * np.sin(0.05 * t + ph[4])
         cy = H / 2 + 0.3 * H * np.cos(0.04 * t + ph[5])
-        x0, y0 = int(round(cx - side / 2)), int(round(cy - side / 2))
+        return int(round(cx - side / 2)), int(round(cy - side / 2)), side
+
+    def __getitem__(self, i):
+        if not 0 <= i < self.n_frames:
+            raise IndexError(i)
+        H, W = self.H, self.W
+        (ca, msa), (sa, _) = self.camera(i)[0]
+        bx, by = self.camera(i)[1]
+        xs = ca * self._xx + msa * self._yy + bx
+        ys = sa * self._xx + ca * self._yy + by
+        img = _sample_bilinear(self._canvas, xs, ys)
+        # occluder: textured square on its own trajectory
+        x0, y0, side = self.occluder(i)
         xa, xb = max(x0, 0), min(x0 + side, W)
         ya, yb = max(y0, 0), min(y0 + side, H)
         if xb > xa and yb > ya:
@@ -94,6 +107,27 @@ class SyntheticVideo:
             patch = _sample_bilinear(self._occ, uu, vv)
             img[ya:yb, xa:xb] = 0.25 + 0.75 * patch[..., ::-1]
         return np.ascontiguousarray((img * 255.0 + 0.5).clip(0, 255).astype(np.uint8))
+
+    def ground_truth_tracks(self, points_xy, frame_q):
+        """Where the BACKGROUND points seen at ``points_xy`` (n, 2) in frame ``frame_q`` are in every
+        frame: ``tracks`` (n, n_frames, 2) xy pixels and ``occluded`` (n, n_frames) bool -- true
+        when the point is behind the occluding square or outside the frame.  (A point that sits on
+        the square in the query frame is tracked as the background behind it.)"""
+        pts = np.asarray(points_xy, np.float64).reshape(-1, 2)
+        ctr = np.array([self.W / 2, self.H / 2])
+        A, b = self.camera(frame_q)
+        canvas = (pts - ctr) @ A.T + b
+        tracks = np.zeros((len(pts), self.n_frames, 2))
+        occluded = np.zeros((len(pts), self.n_frames), bool)
+        for t in range(self.n_frames):
+            A, b = self.camera(t)
+            p = (canvas - b) @ np.linalg.inv(A).T + ctr
+            x0, y0, side = self.occluder(t)
+            behind = (p[:, 0] >= x0 - 0.5) & (p[:, 0] < x0 + side - 0.5) & (p[:, 1] >= y0 - 0.5) & (p[:, 1] < y0 + side - 0.5)
+            outside = (p[:, 0] < 0) | (p[:, 0] > self.W - 1) | (p[:, 1] < 0) | (p[:, 1] > self.H - 1)
+            tracks[:, t] = p
+            occluded[:, t] = behind | outside
+        return tracks, occluded
 
     def frames(self, start=0, stop=None):
         for i in range(start, self.n_frames if stop is None else stop):

@@ -451,3 +451,38 @@ class Tracker:
             if self.dir < 0 and m - max_delta < self.cur:
                 continue
             del self.memory[m]
+
+
+# ---------------------------------------------------------------------------
+# flow-cache codec -- MFT/utils/io.py:495-512 and :535-551
+# "parity unpinned" for the PNG container: cv2 is absent here, so the reference's writer cannot
+# be run; the arithmetic below restates compress_channel / u16_to_3u8 / data_3u8_to_u16 /
+# decompress_channel line by line in numpy, like the reference evaluates them.
+# ---------------------------------------------------------------------------
+def quantize_u16(xs):
+    """compress_channel (io.py:496-506): -> (uint16 array, lb float32, ub float32)."""
+    f_xs = np.float32(xs)
+    lb = np.amin(f_xs)
+    ub = np.amax(f_xs)
+    if np.abs(ub - lb) < 1e-8:
+        xs_01 = np.zeros_like(f_xs)
+    else:
+        xs_01 = (f_xs - lb) / (ub - lb)
+    return np.uint16(np.round(xs_01 * (2 ** 16 - 1))), lb, ub
+
+
+def dequantize_u16(compressed_xs, lb, ub):
+    """decompress_channel (io.py:548-551)."""
+    xs_01 = np.float32(compressed_xs) / (2 ** 16 - 1)
+    return (xs_01 * (ub - lb)) + lb
+
+
+def u16_to_bgr(xs):
+    """u16_to_3u8 (io.py:508-513): the (B, G, R) planes cv2.imencode is handed."""
+    return np.dstack((np.zeros_like(xs, np.uint8), np.uint8((xs & 0xFF00) >> 8), np.uint8(xs & 0x00FF)))
+
+
+def bgr_to_u16(xs):
+    """data_3u8_to_u16 (io.py:541-546)."""
+    b3, b2, b1 = np.dsplit(np.uint16(xs), 3)
+    return ((b2 << 8) | b1)[..., 0]

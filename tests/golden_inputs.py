@@ -91,3 +91,25 @@ def decode_id(img):
 def checksum(t):
     a = np.asarray(t, dtype=np.float64)
     return np.array([a.sum(), np.abs(a).sum(), (a * a).sum()], np.float64)
+
+
+def tapvid_inputs():
+    """Random TAP-Vid style ground truth and predictions: 2 videos x 12 tracks x 20 frames on the
+    256 x 256 raster (tracks = smooth random walks, ~25 % occluded, two never-visible tracks),
+    predictions = ground truth + noise of mixed magnitude, ~10 % occlusion flips."""
+    r = _rng(31)
+    b, n, T = 2, 12, 20
+    start = r.uniform(20, 236, size=(b, n, 1, 2))
+    steps = r.normal(0, 2.0, size=(b, n, T, 2))
+    gt_tracks = start + np.cumsum(steps, axis=2)
+    gt_occluded = r.random((b, n, T)) < 0.25
+    gt_occluded[:, 3] = True                     # never visible
+    gt_occluded[0, 0, :4] = True                 # first visible late
+    gt_occluded[1, 0, 0] = False
+    noise = r.normal(0, 1.0, size=(b, n, T, 2)) * r.choice([0.3, 1.5, 5.0, 20.0], size=(b, n, T, 1))
+    pred_tracks = gt_tracks + noise
+    flip = r.random((b, n, T)) < 0.10
+    pred_occluded = np.logical_xor(gt_occluded, flip)
+    frames = r.integers(0, 255, size=(T, 8, 8, 3), dtype=np.uint8)
+    return dict(gt_tracks=gt_tracks, gt_occluded=gt_occluded, pred_tracks=pred_tracks,
+                pred_occluded=pred_occluded, frames=frames)

@@ -237,3 +237,24 @@ def test_async_encode_is_bitwise_identical(weights_np):
         outs.append(res)
     for a, b in zip(*outs):
         assert torch.equal(a.flow, b.flow) and torch.equal(a.occlusion, b.occlusion) and torch.equal(a.sigma, b.sigma)
+
+
+def test_tapvid_runner_vs_oracle_tracker():
+    """the TAP-Vid per-sequence protocol (re-init per query frame, forward and backward
+    runs over one shared flow cache, point read-out) on the HIP tracker against the same protocol on
+    the oracle-backed CPU tracker, both fed the same stub flows."""
+    from mft_amd import tapvid
+    from mft_amd.io import FlowCache
+    import test_host_logic as hl
+    n = 14
+    video = [gi.id_image(i) for i in range(n)]
+    H, W = video[0].shape[:2]
+    rng = np.random.default_rng(5)
+    qp = np.stack([rng.choice([0, 5, 10], size=12), rng.integers(0, H, 12), rng.integers(0, W, 12)], axis=1)
+    out_hip = tapvid.run_sequence(make_tracker(StubFlower()), video, qp, "strided",
+                                  flow_cache=FlowCache(None), device=DEV)
+    out_cpu = tapvid.run_sequence(hl.make_tracker(hl.StubFlower()), video, qp, "strided",
+                                  flow_cache=FlowCache(None, device="cpu"))
+    d = np.abs(out_hip["tracks"] - out_cpu["tracks"]).max(-1)
+    assert (d < 1e-3 * 256 / min(H, W)).mean() > 0.99, float((d < 1e-3).mean())
+    assert (np.abs(out_hip["occluded"] - out_cpu["occluded"]) < 1e-4).mean() > 0.99

@@ -265,15 +265,33 @@ def test_delta_sharding_two_ranks_gloo(tmp_path):
         assert np.array_equal(r0[k], single[k]), k       # and equal to the unsharded run
 
 
-def test_flow_cache_tiers(tmp_path):
+def oracle_flow_cache():
+    """FlowCache whose disk tier quantises with the ORACLE instead of the HIP kernels (no GPU here);
+    the container code (pickle + PNG, C unfilter) is the product's."""
     from mft_amd.io import FlowCache
+    from mft_amd import flowou_codec as fc
+
+    class OracleCodecCache(FlowCache):
+        def _save(self, path, val):
+            planes = [val[0][0], val[0][1], val[1][0], val[2][0]]
+            fc.pack_flowou_X16(path, [O.quantize_u16(p.numpy()) for p in planes])
+
+        def _load(self, path):
+            fx, fy, oc, sg = (torch.from_numpy(O.dequantize_u16(q, lo, hi)) for q, lo, hi in fc.unpack_flowou_X16(path))
+            return torch.stack([fx, fy]), oc[None], sg[None]
+
+    return OracleCodecCache
+
+
+def test_flow_cache_tiers(tmp_path):
+    FlowCache = oracle_flow_cache()
     f = lambda v: (torch.full((2, 4, 4), float(v)), torch.zeros(1, 4, 4), torch.ones(1, 4, 4))  # noqa: E731
     one = 4 * 4 * 4 * 4                      # bytes of one (flow, occl, sigma) triple
     c = FlowCache(tmp_path / "c", max_RAM_MB=2 * one / 1e6, max_GPU_RAM_MB=one / 1e6, device="cpu")
     assert c.read(0, 1) == (None, None, None)
     for i in range(5):
         c.write(i, i + 1, *f(i))
-    assert len(c.gpu_ram_cache) == 1 and len(c.ram_cache) == 2 and len(list((tmp_path / "c").glob("*.pt"))) == 2
+    assert len(c.gpu_ram_cache) == 1 and len(c.ram_cache) == 2 and len(list((tmp_path / "c").glob("*.flowouX16.pkl"))) == 2
     for i in range(5):
         assert float(c.read(i, i + 1)[0][0, 0, 0]) == i
     assert c.backup_to_disk() == 3

@@ -229,10 +229,45 @@ def gen_e2e(model):
     print("sequence_raft.npz", sum(v.nbytes for v in out.values()) / 1e6, "MB")
 
 
+def gen_tapvid():
+    """TAP-Vid query samplers and metrics of the reference on seeded random tracks."""
+    for name in ("mediapy", "PIL", "PIL.Image"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["PIL"].Image = sys.modules["PIL.Image"]
+    from MFT.evaluation import tapvid_eval_stuff as tves
+    d = gi.tapvid_inputs()
+    out = {}
+    for mode in ("first", "strided"):
+        for v in range(2):
+            # per video: sample queries the reference's way, then score the predictions of the sampled tracks
+            occ, pts = d["gt_occluded"][v], d["gt_tracks"][v]
+            s = (tves.sample_queries_first(occ, pts, d["frames"]) if mode == "first"
+                 else tves.sample_queries_strided(occ, pts, d["frames"], query_stride=5))
+            for k in ("query_points", "target_points", "occluded", "trackgroup"):
+                out[f"{mode}_{v}_{k}"] = np.asarray(s[k])
+            tg = s["trackgroup"][0]
+            m = tves.compute_tapvid_metrics(s["query_points"], s["occluded"], s["target_points"],
+                                            d["pred_occluded"][v][tg][None], d["pred_tracks"][v][tg][None], mode)
+            for k, val in m.items():
+                out[f"{mode}_{v}_metric_{k}"] = np.asarray(val)
+        # and the batched call (both videos at once, all tracks, queries on frame 0)
+        q = np.zeros((2, d["gt_tracks"].shape[1], 3))
+        occ = d["gt_occluded"].copy()
+        occ[:, :, 0] = False
+        m = tves.compute_tapvid_metrics(q, occ, d["gt_tracks"], d["pred_occluded"], d["pred_tracks"], mode)
+        for k, val in m.items():
+            out[f"{mode}_batch_metric_{k}"] = np.asarray(val)
+    np.savez_compressed(OUT / "tapvid.npz", **out)
+    print("tapvid.npz", sum(v.nbytes for v in out.values()) / 1e3, "kB,", len(out), "arrays")
+
+
 if __name__ == "__main__":
     assert REF.exists(), "the reference is only mounted in the build container"
+    which = sys.argv[1:] or ["ops", "flow", "seq", "e2e", "tapvid"]
+    if which == ["tapvid"]:
+        gen_tapvid()
+        sys.exit(0)
     model = build_reference_model()
-    which = sys.argv[1:] or ["ops", "flow", "seq", "e2e"]
     if "ops" in which:
         gen_ops(model)
     if "flow" in which:
@@ -241,3 +276,5 @@ if __name__ == "__main__":
         gen_chain_and_sequence()
     if "e2e" in which:
         gen_e2e(model)
+    if "tapvid" in which:
+        gen_tapvid()
