@@ -62,8 +62,15 @@ struct ConvArgs {
     long long a_bstride, w_bstride, o_bstride;  // per batch element
     unsigned a0_bytes, a1_bytes, w_bytes;       // buffer extents (per batch element)
     float *hx; int ld_hx; float *z; float *rh;  // GRU epilogues
-    int ablate;               // tuning only (MFTX_CONV_ABLATE): 1 no global loads, 2 + no LDS staging, 3 + no LDS reads
 };
+
+// Tuning builds only (make ABLATE=n): 1 no global loads, 2 + no barriers, 3 + no LDS reads.  A
+// compile-time switch on purpose: as run-time branches around the ds_reads these made the compiler
+// lose count of the outstanding LDS operations and wait for ALL of them (lgkmcnt(0)) in front of
+// every MFMA group.
+#ifndef MFTX_ABLATE
+#define MFTX_ABLATE 0
+#endif
 
 __device__ __forceinline__ float act_fn(float v, int act) {
     switch (act) {
@@ -96,21 +103,26 @@ __device__ __forceinline__ void wait_vmcnt() {   // counted wait: leaves N LDS-D
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NS>
-__global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs p) {
+// Waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument):
+// left alone it spends registers freely in the pinned K loop and costs a resident workgroup.
+constexpr int min_waves(int wave_tiles) { return wave_tiles == 1 ? 5 : wave_tiles == 2 ? 3 : 2; }
+
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(64 * WM * WN, min_waves((BM / WM / 32) * (BN / WN / 32)))
+void conv_gemm_kernel(ConvArgs p) {
+    constexpr int NS = 2;                       // LDS ring of two K chunks (deeper rings were measured: no gain)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RPP = 8 * WM * WN;            // rows staged per pass: 8 per wave (one 1 KiB LDS-DMA)
     constexpr int RA = BM / RPP, RB = BN / RPP;
     static_assert(TM >= 1 && TN >= 1 && RA >= 1 && RB >= 1, "tile");
     static_assert(RPP % 16 == 0, "the chunk swizzle must not depend on the pass");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;                       // [NS][BM][LDK]  (ring of NS tiles)
+    float *As = smem;                       // [NS][BM][LDK]
     float *Bs = smem + NS * BM * LDK;       // [NS][BN][LDK]
-    constexpr int L = RA + RB;              // LDS-DMA instructions per thread per tile
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid = tid >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA destinations live in m0
     const int wm = wid / WN, wn = wid % WN;
     const int srow = tid >> 3;  // 0..RPP-1: staging row of this lane within an RPP-row group
     // this lane's LDS chunk (tid & 7) receives logical chunk (tid & 7) ^ swz(row); rows advance by
@@ -130,6 +142,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs p) {
     const int band = (tiles_m + 7) / 8;               // M tiles per XCD
     const int per_batch = band * tiles_n;              // virtual tiles per XCD per batch element
     const int n_virtual = 8 * per_batch * p.batch;
+    const int taps = p.kh * p.kw;
+    const int cpt = p.cin_pad / BK;          // K chunks per tap
+    const int T = taps * cpt;
+    const unsigned ktot_b = (unsigned)taps * p.cin_pad * 4u;
+    const int ctot = p.c0 + p.c1;
+    const int hw = p.h * p.wd;
+    // A tap's chunks form up to three RUNS inside which a chunk differs from the previous one only
+    // by +128 B in every offset: segment 0, segment 1 (second input tensor of a concatenation), and
+    // -- when the channel count is not a multiple of 32 -- the last, partly zero-filled chunk.
+    const int seg_cc = p.c1 > 0 ? p.c0 / BK : cpt;           // first chunk of segment 1
+    const int rag_cc = (ctot % BK) ? cpt - 1 : cpt;          // the ragged chunk, if any
+
+    const int a_row0 = wm * TM * 32 + (lane & 31);
+    const int b_row0 = wn * TN * 32 + (lane & 31);
+    const int khalf = lane >> 5;             // lanes 0-31: chunk 2kk, lanes 32-63: chunk 2kk+1
+    const int a_sw = (a_row0 >> 1) & 7, b_sw = (b_row0 >> 1) & 7;   // same for every 32-row step
+    // fragment addresses of the four 8-wide k groups (the XOR swizzle is not additive: one each)
+    const float *a_frag[4], *b_frag[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        a_frag[kk] = As + a_row0 * LDK + (((kk * 2 + khalf) ^ a_sw) * 4);
+        b_frag[kk] = Bs + b_row0 * LDK + (((kk * 2 + khalf) ^ b_sw) * 4);
+    }
+    // LDS-DMA destinations: wave `wid` fills rows [RPP i + 8 wid, +8) of each RPP-row group (1 KiB, lane-linear)
+    float *const a_dst = As + wid * 8 * LDK;
+    float *const b_dst = Bs + wid * 8 * LDK;
+
     for (int vt = blockIdx.x; vt < n_virtual; vt += gridDim.x) {
     const int xcd = vt & 7;
     const int q = vt >> 3;
@@ -152,7 +191,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs p) {
 
     // ---- per-thread staging coordinates
     int ay[RA], ax[RA], am[RA];              // input-grid origin of the row's window, and its image's first cell
-    const int hw = p.h * p.wd;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         const int m = m0 + srow + RPP * i;
@@ -167,53 +205,52 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs p) {
             ay[i] = -100000; ax[i] = -100000; am[i] = 0;
         }
     }
-    const int taps = p.kh * p.kw;
-    const int cpt = p.cin_pad / BK;          // K steps per tap
-    const int T = taps * cpt;
-    const unsigned ktot_b = (unsigned)taps * p.cin_pad * 4u;
-    const int ctot = p.c0 + p.c1;
-
-    unsigned woff[RB];                       // byte offsets into W, advance 128 B per K step
+    unsigned woff[RB];                       // byte offsets into W, +128 B per chunk (W is [n][tap][cin_pad])
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         const int n = n0 + srow + RPP * i;
         woff[i] = (n < p.w_rows) ? (unsigned)n * ktot_b + col4 * 4u : OOB;
     }
-    unsigned aoff0[RA], aoff1[RA];           // byte offsets of this tap's source cell in segment 0 / 1
-    int tap = 0, cc = 0;                     // position of the NEXT tile to fetch
-    auto set_tap = [&]() {
-        const int dy = tap / p.kw, dx = tap % p.kw;
+    unsigned acell[RA];                      // this tap's source cell of each row, or OOB (conv halo / M tail)
+    unsigned acur[RA];                       // byte offsets of the NEXT chunk to fetch, +128 B per chunk inside a run
+    __amdgpu_buffer_rsrc_t rA = rA0;
+    int tap = 0, cc = 0, left = 0;           // next chunk to fetch; chunks left in its run
+    auto next_run = [&]() {                  // (tap, cc) starts a run: offsets from scratch
+        if (cc == 0) {
+            const int dy = tap / p.kw, dx = tap - dy * p.kw;
 #pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const int yy = ay[i] + dy, xx = ax[i] + dx;
-            const bool ok = (yy >= 0) & (yy < p.hin) & (xx >= 0) & (xx < p.win);
-            const unsigned src = (unsigned)(am[i] + yy * p.win + xx);
-            aoff0[i] = ok ? (src * (unsigned)p.lda0 + col4) * 4u : OOB;
-            aoff1[i] = ok ? (src * (unsigned)p.lda1 + col4) * 4u : OOB;
+            for (int i = 0; i < RA; ++i) {
+                const int yy = ay[i] + dy, xx = ax[i] + dx;
+                const bool ok = (yy >= 0) & (yy < p.hin) & (xx >= 0) & (xx < p.win);
+                acell[i] = ok ? (unsigned)(am[i] + yy * p.win + xx) : OOB;
+            }
         }
+        const bool seg1 = cc >= seg_cc;      // wave-uniform
+        const bool ragged = cc >= rag_cc;
+        const unsigned lda = (unsigned)(seg1 ? p.lda1 : p.lda0);
+        const unsigned cb = (unsigned)(cc * BK - (seg1 ? p.c0 : 0)) * 4u;
+        const bool lane_ok = !ragged || cc * BK + col4 < ctot;     // ragged chunk: zero-fill beyond the last channel
+        rA = seg1 ? rA1 : rA0;
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+            acur[i] = (acell[i] != OOB && lane_ok) ? (acell[i] * lda + col4) * 4u + cb : OOB;
+        const int stop = ragged ? cpt : (seg1 ? rag_cc : (seg_cc < rag_cc ? seg_cc : rag_cc));
+        left = stop - cc;
     };
-    set_tap();
-
-    auto fetch = [&](int buf) {              // global -> LDS (DMA) for tile (tap, cc); then advance
-        const int cbase = cc * BK;
-        const bool seg1 = cbase >= p.c0;     // wave-uniform: c0 is a multiple of BK when c1 > 0
-        const unsigned cb = (unsigned)(seg1 ? cbase - p.c0 : cbase) * 4u;
-        const bool cok = cbase + col4 < ctot;  // ragged channel count: zero-fill the tail
-        const __amdgpu_buffer_rsrc_t rA = seg1 ? rA1 : rA0;
-        // wave `wid` fills rows [RPP i + 8 wid, +8) of each RPP-row group: 1 KiB, lane-linear
-        float *as = As + buf * BM * LDK + wid * 8 * LDK;
-        float *bs = Bs + buf * BN * LDK + wid * 8 * LDK;
+    auto fetch = [&](int buf) {              // global -> LDS (DMA) for the next chunk; then advance
+        if (left == 0) next_run();
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const unsigned off = (cok ? (seg1 ? aoff1[i] : aoff0[i]) : OOB) + cb;
-            buf_load_lds(rA, as + RPP * i * LDK, off);
+            buf_load_lds(rA, a_dst + buf * BM * LDK + RPP * i * LDK, acur[i]);
+            acur[i] += BK * 4u;              // an OOB offset stays out of range
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            buf_load_lds(rW, bs + RPP * i * LDK, woff[i]);
+            buf_load_lds(rW, b_dst + buf * BN * LDK + RPP * i * LDK, woff[i]);
             woff[i] += BK * 4u;
         }
-        if (++cc == cpt) { cc = 0; ++tap; if (tap < taps) set_tap(); }
+        --left;
+        if (++cc == cpt) { cc = 0; ++tap; }
     };
 
     f32x16 acc[TM][TN];
@@ -224,18 +261,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int a_row0 = wm * TM * 32 + (lane & 31);
-    const int b_row0 = wn * TN * 32 + (lane & 31);
-    const int khalf = lane >> 5;             // lanes 0-31: chunk 2kk, lanes 32-63: chunk 2kk+1
-    const int a_sw = (a_row0 >> 1) & 7, b_sw = (b_row0 >> 1) & 7;   // same for every 32-row step
     f32x4 fa[2][TM], fb[2][TN];              // register double buffer of MFMA fragments
     auto read_frags = [&](int buf, int kk, int slot) {
-        const float *as = As + buf * BM * LDK + a_row0 * LDK + (((kk * 2 + khalf) ^ a_sw) * 4);
-        const float *bs = Bs + buf * BN * LDK + b_row0 * LDK + (((kk * 2 + khalf) ^ b_sw) * 4);
+        if (MFTX_ABLATE >= 3) return;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const f32x4 *>(as + 32 * i * LDK);
+        for (int i = 0; i < TM; ++i)
+            fa[slot][i] = *reinterpret_cast<const f32x4 *>(a_frag[kk] + buf * BM * LDK + 32 * i * LDK);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const f32x4 *>(bs + 32 * j * LDK);
+        for (int j = 0; j < TN; ++j)
+            fb[slot][j] = *reinterpret_cast<const f32x4 *>(b_frag[kk] + buf * BN * LDK + 32 * j * LDK);
     };
     auto mma = [&](int slot) {
 #pragma unroll
@@ -246,39 +280,57 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvArgs p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i][s], fb[slot][j][s], acc[i][j], 0, 0, 0);
     };
-
-    // prologue: tiles 0 .. NS-2 in flight, tile 0 landed, first fragments -> slot 0
-#pragma unroll
-    for (int st = 0; st < NS - 1; ++st)
-        if (st < T) fetch(st);
-    if (T >= NS - 1) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
-    block_barrier();
-    read_frags(0, 0, 0);
-
-    int buf = 0, nbuf = (NS > 1) ? 1 : 0, fbuf = NS - 1;   // ring slots: current, next, the one to refill
-    for (int it = 0; it < T; ++it) {
-        const bool more = it + 1 < T;
-        // refill the slot every wave finished reading before the previous barrier; the DMA has
-        // NS-1 tiles of MFMA work to land
-        if (it + NS - 1 < T && p.ablate < 1) fetch(fbuf);
-        if (p.ablate < 3) read_frags(buf, 1, 1);
+    // One K chunk out of ring slot `buf` (compile-time after unrolling: every LDS address is a register
+    // plus an immediate).  The other slot was released by the barrier of the previous step, so its
+    // refill is issued first and has this whole step of MFMA work to land; fragments are double
+    // buffered in registers; the barrier is taken BEFORE the last k group's MFMAs and the next
+    // chunk's first fragments are read right behind it, hidden under those MFMAs.
+    // The order below is pinned with scheduling barriers: left alone, the compiler sinks every
+    // ds_read to just in front of the MFMAs that consume it (one register set instead of two) and
+    // the LDS latency shows four times per chunk -- invisible with five waves per SIMD, a third
+    // of the time with one (M = 4096, one flow pair per GPU).
+    auto step = [&](int buf, bool more) {
+        read_frags(buf, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
         mma(0);
-        if (p.ablate < 3) read_frags(buf, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && MFTX_ABLATE < 1) fetch(buf ^ 1);     // issue cost hidden under the 4 MFMAs just queued
+        read_frags(buf, 2, 0);
+        __builtin_amdgcn_sched_barrier(0);
         mma(1);
-        if (p.ablate < 3) read_frags(buf, 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(buf, 3, 1);
+        __builtin_amdgcn_sched_barrier(0);
         mma(0);
-        if (more && p.ablate < 2) {
-            // own LDS reads of `buf` done (lgkmcnt), own DMA of tile it+1 landed (counted vmcnt:
-            // the NS-2 younger tiles stay in flight), then every wave agrees (barrier)
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && MFTX_ABLATE < 2) {
+            // own LDS reads of `buf` done (lgkmcnt), own DMA of the next chunk landed (vmcnt), then
+            // every wave agrees (barrier)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (it + NS - 1 < T) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+            wait_vmcnt<0>();
             block_barrier();
         }
-        if (more && p.ablate < 3) read_frags(nbuf, 0, 0);   // next tile's first fragments, hidden under the last k group
+        if (more) read_frags(buf ^ 1, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         mma(1);
-        buf = nbuf;
-        nbuf = (nbuf + 1 == NS) ? 0 : nbuf + 1;
-        fbuf = (fbuf + 1 == NS) ? 0 : fbuf + 1;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // prologue: chunk 0 landed, first fragments -> slot 0
+    fetch(0);
+    wait_vmcnt<0>();
+    block_barrier();
+    read_frags(0, 0, 0);
+    int it = 0;
+    for (; it + 2 < T; it += 2) {
+        step(0, true);
+        step(1, true);
+    }
+    if (it + 1 < T) {
+        step(0, true);
+        step(1, false);
+    } else {
+        step(0, false);
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -332,11 +384,11 @@ static int num_cus() {
     return n;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int NS>
+template <int BM, int BN, int WM, int WN, int EPI>
 static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) {
-    constexpr size_t lds = (size_t)NS * (BM + BN) * LDK * sizeof(float);
+    constexpr size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
     static bool attr_set = false;
-    auto kern = conv_gemm_kernel<BM, BN, WM, WN, EPI, NS>;
+    auto kern = conv_gemm_kernel<BM, BN, WM, WN, EPI>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -345,8 +397,6 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) 
     }
     ConvArgs args = a;
     args.batch = batch;
-    static const int ablate = [] { const char *e = getenv("MFTX_CONV_ABLATE"); return e ? atoi(e) : 0; }();
-    args.ablate = ablate;
     // resident workgroups per CU: LDS-bound (160 KiB per CU), at most 4 (16 waves)
     constexpr int max_res = 16 / (WM * WN);     // at most 16 waves per CU
     constexpr int resident = (160 * 1024) / (int)lds < max_res ? (160 * 1024) / (int)lds : max_res;
@@ -359,17 +409,17 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) 
     return check_launch("conv_gemm");
 }
 
-// tile shapes: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x32.  The LDS ring depth NS is a template
-// parameter of the kernel; rings of 3 and 4 tiles (counted vmcnt) were measured and do not pay at
-// either M = 28672 or M = 4096 (tools/bench_conv.py), so only NS = 2 is instantiated.
+// tile shapes: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x32.  LDS rings of 3 and 4 chunks (counted
+// vmcnt) were measured twice and do not pay at either M = 28672 or M = 4096 (tools/bench_conv.py):
+// the ring is fixed at two chunks, which lets the K loop be unrolled over the slots.
 template <int EPI>
 static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) {
     switch (tile) {
-        case 0: return launch_cfg<128, 128, 2, 2, EPI, 2>(a, batch, s, cat);
-        case 1: return launch_cfg<128, 64, 2, 2, EPI, 2>(a, batch, s, cat);
-        case 2: return launch_cfg<64, 64, 2, 2, EPI, 2>(a, batch, s, cat);
-        case 4: return launch_cfg<64, 32, 2, 1, EPI, 2>(a, batch, s, cat);   // 2 waves: twice the tiles of 64x64
-        default: return launch_cfg<128, 32, 4, 1, EPI, 2>(a, batch, s, cat);
+        case 0: return launch_cfg<128, 128, 2, 2, EPI>(a, batch, s, cat);
+        case 1: return launch_cfg<128, 64, 2, 2, EPI>(a, batch, s, cat);
+        case 2: return launch_cfg<64, 64, 2, 2, EPI>(a, batch, s, cat);
+        case 4: return launch_cfg<64, 32, 2, 1, EPI>(a, batch, s, cat);   // 2 waves: twice the tiles of 64x64
+        default: return launch_cfg<128, 32, 4, 1, EPI>(a, batch, s, cat);
     }
 }
 
@@ -471,10 +521,10 @@ int launch_corr_volume(const float *f1, const float *f2, int P, int C, int N, fl
     a.a_bstride = (long long)N * C; a.w_bstride = (long long)N * C; a.o_bstride = (long long)N * N;
     a.a0_bytes = (unsigned)((long long)N * C * 4); a.a1_bytes = 0; a.w_bytes = a.a0_bytes;
     static const int forced = [] { const char *e = getenv("MFTX_CORR_TILE"); return e ? atoi(e) : -1; }();
-    if (forced == 2) return launch_cfg<64, 64, 2, 2, EPI_GENERIC, 2>(a, P, s, PC_CORR_VOLUME);
-    if (forced == 1) return launch_cfg<128, 64, 2, 2, EPI_GENERIC, 2>(a, P, s, PC_CORR_VOLUME);
-    if (N >= 1024) return launch_cfg<128, 128, 2, 2, EPI_GENERIC, 2>(a, P, s, PC_CORR_VOLUME);
-    return launch_cfg<64, 64, 2, 2, EPI_GENERIC, 2>(a, P, s, PC_CORR_VOLUME);
+    if (forced == 2) return launch_cfg<64, 64, 2, 2, EPI_GENERIC>(a, P, s, PC_CORR_VOLUME);
+    if (forced == 1) return launch_cfg<128, 64, 2, 2, EPI_GENERIC>(a, P, s, PC_CORR_VOLUME);
+    if (N >= 1024) return launch_cfg<128, 128, 2, 2, EPI_GENERIC>(a, P, s, PC_CORR_VOLUME);
+    return launch_cfg<64, 64, 2, 2, EPI_GENERIC>(a, P, s, PC_CORR_VOLUME);
 }
 
 }  // namespace mftx

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--h", type=int, default=64)
     ap.add_argument("--w", type=int, default=64)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default=None, help="substring of the layer name")
     args = ap.parse_args()
     P, h, w = args.P, args.h, args.w
     M = P * h * w
@@ -49,6 +50,8 @@ def main():
     tot_t = tot_f = 0.0
     print(f"M = {M} cells (P={P}, {h}x{w})")
     for name, cin, cout, kh, kw, calls in LAYERS:
+        if args.only and args.only not in name:
+            continue
         x = torch.randn(M, cin, device=dev)
         wt = ops.pack_conv_weight(torch.randn(cout, cin, kh, kw, device=dev) * 0.05)
         b = torch.randn(cout, device=dev)
