@@ -289,12 +289,11 @@ void conv_gemm_kernel(ConvArgs p) {
     // ds_read to just in front of the MFMAs that consume it (one register set instead of two) and
     // the LDS latency shows four times per chunk -- invisible with five waves per SIMD, a third
     // of the time with one (M = 4096, one flow pair per GPU).
-    auto step = [&](int buf, bool more) {
+    auto step = [&](int buf, bool more, bool more2) {
         read_frags(buf, 1, 1);
         __builtin_amdgcn_sched_barrier(0);
         mma(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (more && MFTX_ABLATE < 1) fetch(buf ^ 1);     // issue cost hidden under the 4 MFMAs just queued
         read_frags(buf, 2, 0);
         __builtin_amdgcn_sched_barrier(0);
         mma(1);
@@ -310,27 +309,35 @@ void conv_gemm_kernel(ConvArgs p) {
             wait_vmcnt<0>();
             block_barrier();
         }
+        // slot `buf` is free: refill it at once with the chunk after next -- its DMA has a whole
+        // step of MFMA work to land, and its issue hides under the MFMAs queued just above
+        if (more2 && MFTX_ABLATE < 1) fetch(buf);
         if (more) read_frags(buf ^ 1, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         mma(1);
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    // prologue: chunk 0 landed, first fragments -> slot 0
+    // prologue: chunks 0 and 1 in flight, chunk 0 landed, first fragments -> slot 0
     fetch(0);
-    wait_vmcnt<0>();
+    if (T > 1) { fetch(1); wait_vmcnt<RA + RB>(); } else { wait_vmcnt<0>(); }
     block_barrier();
     read_frags(0, 0, 0);
     int it = 0;
-    for (; it + 2 < T; it += 2) {
-        step(0, true);
-        step(1, true);
+    for (; it + 3 < T; it += 2) {
+        step(0, true, true);
+        step(1, true, true);
     }
-    if (it + 1 < T) {
-        step(0, true);
-        step(1, false);
+    // 1, 2 or 3 chunks left
+    if (it + 2 < T) {
+        step(0, true, true);
+        step(1, true, false);
+        step(0, false, false);
+    } else if (it + 1 < T) {
+        step(0, true, false);
+        step(1, false, false);
     } else {
-        step(0, false);
+        step(0, false, false);
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -397,9 +404,10 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) 
     }
     ConvArgs args = a;
     args.batch = batch;
-    // resident workgroups per CU: LDS-bound (160 KiB per CU), at most 4 (16 waves)
-    constexpr int max_res = 16 / (WM * WN);     // at most 16 waves per CU
-    constexpr int resident = (160 * 1024) / (int)lds < max_res ? (160 * 1024) / (int)lds : max_res;
+    // resident workgroups per CU: LDS-bound (160 KiB per CU), at most MFTX_CONV_RESIDENT_WAVES waves
+    static const int max_waves = [] { const char *e = getenv("MFTX_CONV_RESIDENT_WAVES"); return e ? atoi(e) : 16; }();
+    const int max_res = max_waves / (WM * WN);
+    const int resident = (160 * 1024) / (int)lds < max_res ? (160 * 1024) / (int)lds : max_res;
     const long long n_virtual = 8ll * cdiv(cdiv(a.M, BM), 8) * cdiv(a.N, BN) * batch;
     const long long slots = (long long)num_cus() * resident;
     dim3 grid((unsigned)(n_virtual < slots ? n_virtual : slots));
