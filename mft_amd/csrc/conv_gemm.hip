@@ -105,7 +105,10 @@ __device__ __forceinline__ void wait_vmcnt() {   // counted wait: leaves N LDS-D
 
 // Waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument):
 // left alone it spends registers freely in the pinned K loop and costs a resident workgroup.
-constexpr int min_waves(int wave_tiles) { return wave_tiles == 1 ? 5 : wave_tiles == 2 ? 3 : 2; }
+#ifndef MFTX_MINW1
+#define MFTX_MINW1 5
+#endif
+constexpr int min_waves(int wave_tiles) { return wave_tiles == 1 ? MFTX_MINW1 : wave_tiles == 2 ? 3 : 2; }
 
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(64 * WM * WN, min_waves((BM / WM / 32) * (BN / WN / 32)))

@@ -39,42 +39,79 @@ __global__ void enc_prep_kernel(const uint8_t *__restrict__ img, int H0, int W0,
     reinterpret_cast<float4 *>(out)[(long long)y * (Wp + 6) + xo] = v;
 }
 
-// per-channel partial sums over a slab of rows: x [rows][C] -> part [slabs][C][2] (sum, sum of squares; fp64)
+// per-channel partial sums over a slab of rows: x [rows][C] -> part [slabs][C][2] (sum, sum of squares; fp64).
+// A thread owns 4 consecutive channels (one 16-byte load per row) and every (256 / (C/4))-th row of the
+// slab; the row groups of a block are then summed in a fixed order.
 constexpr int IN_SLABS = 256;   // row slabs per map: enough workgroups to stream at HBM rate
 __global__ __launch_bounds__(256) void instnorm_partial_kernel(const float *__restrict__ x, int rows, int C,
                                                                double *__restrict__ part) {
-    __shared__ double sh[256][2];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int g = threadIdx.x >> 6;                    // 4 row groups per block
-    const int slab = blockIdx.y;
+    __shared__ double sh[256][8];
+    const int n4 = C >> 2;                             // float4 columns (C <= 256 -> n4 <= 64)
+    const int rpp = 256 / n4;                          // rows per pass
+    const int g = threadIdx.x / n4, c4 = threadIdx.x - g * n4;
+    const int slab = blockIdx.x;
     const int r0 = (int)((long long)rows * slab / IN_SLABS), r1 = (int)((long long)rows * (slab + 1) / IN_SLABS);
-    double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int r = r0 + g; r < r1; r += 4) {
-            const double v = (double)x[(long long)r * C + c];
-            s += v;
-            q += v * v;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (g < rpp) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        int r = r0 + g;
+        for (; r + 3 * rpp < r1; r += 4 * rpp) {       // four independent loads in flight
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = x4[(long long)(r + u * rpp) * n4 + c4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double d0 = v[u].x, d1 = v[u].y, d2 = v[u].z, d3 = v[u].w;
+                acc[0] += d0; acc[1] += d0 * d0; acc[2] += d1; acc[3] += d1 * d1;
+                acc[4] += d2; acc[5] += d2 * d2; acc[6] += d3; acc[7] += d3 * d3;
+            }
         }
-    sh[threadIdx.x][0] = s;
-    sh[threadIdx.x][1] = q;
+        for (; r < r1; r += rpp) {
+            const float4 v = x4[(long long)r * n4 + c4];
+            const double d0 = v.x, d1 = v.y, d2 = v.z, d3 = v.w;
+            acc[0] += d0; acc[1] += d0 * d0; acc[2] += d1; acc[3] += d1 * d1;
+            acc[4] += d2; acc[5] += d2 * d2; acc[6] += d3; acc[7] += d3 * d3;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sh[threadIdx.x][k] = acc[k];
     __syncthreads();
-    if (g == 0 && c < C) {
-        for (int k = 1; k < 4; ++k) { s += sh[threadIdx.x + 64 * k][0]; q += sh[threadIdx.x + 64 * k][1]; }
-        part[((long long)slab * C + c) * 2] = s;
-        part[((long long)slab * C + c) * 2 + 1] = q;
+    if (g == 0) {
+        for (int k = 1; k < rpp; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += sh[threadIdx.x + k * n4][j];
+        double *o = part + ((long long)slab * C + c4 * 4) * 2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = acc[j];
     }
 }
 
-// partial sums -> per-channel (mean, rstd), in a fixed order (deterministic)
-__global__ void instnorm_finalize_kernel(const double *__restrict__ part, int rows, int C, float *__restrict__ stat) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// partial sums -> per-channel (mean, rstd), in a fixed order (deterministic): a block owns 16 channels,
+// 16 threads per channel each add every 16th slab, then one thread per channel adds the 16 sums
+__global__ __launch_bounds__(256) void instnorm_finalize_kernel(const double *__restrict__ part, int rows, int C,
+                                                                float *__restrict__ stat) {
+    __shared__ double sh[16][16][2];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s = 0.0, q = 0.0;
-    for (int k = 0; k < IN_SLABS; ++k) { s += part[((long long)k * C + c) * 2]; q += part[((long long)k * C + c) * 2 + 1]; }
-    const double m = s / rows;
-    const double var = q / rows - m * m;               // biased variance, as nn.InstanceNorm2d
-    stat[2 * c] = (float)m;
-    stat[2 * c + 1] = (float)(1.0 / sqrt((var > 0 ? var : 0.0) + 1e-5));
+    if (c < C) {
+#pragma unroll
+        for (int k = 0; k < IN_SLABS / 16; ++k) {
+            const double2 v = *reinterpret_cast<const double2 *>(part + ((long long)(g + 16 * k) * C + c) * 2);
+            s += v.x;
+            q += v.y;
+        }
+    }
+    sh[g][cl][0] = s;
+    sh[g][cl][1] = q;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        for (int k = 1; k < 16; ++k) { s += sh[k][cl][0]; q += sh[k][cl][1]; }
+        const double m = s / rows;
+        const double var = q / rows - m * m;           // biased variance, as nn.InstanceNorm2d
+        stat[2 * c] = (float)m;
+        stat[2 * c + 1] = (float)(1.0 / sqrt((var > 0 ? var : 0.0) + 1e-5));
+    }
 }
 
 // y = relu((x - mean) * rstd)            [mode 0]
@@ -201,12 +238,12 @@ struct Enc {
     int norm(float *x, int rows, int C, int mode, const float *res = nullptr) {
         {
             ProfScope prof(PC_ENC_NORM, s, 4.0 * rows * C);
-            hipLaunchKernelGGL(instnorm_partial_kernel, dim3(cdiv(C, 64), IN_SLABS), dim3(256), 0, s, x, rows, C, ws.part);
+            hipLaunchKernelGGL(instnorm_partial_kernel, dim3(IN_SLABS), dim3(256), 0, s, x, rows, C, ws.part);
         }
         TRY(check_launch("instnorm_partial"));
         {
             ProfScope prof(PC_ENC_NORM, s, 0);
-            hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, ws.part, rows, C, ws.stat);
+            hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, ws.part, rows, C, ws.stat);
         }
         TRY(check_launch("instnorm_finalize"));
         const long long n4 = (long long)rows * C / 4;
