@@ -64,7 +64,7 @@ struct ConvArgs {
     float *hx; int ld_hx; float *z; float *rh;  // GRU epilogues
 };
 
-// Tuning builds only (make ABLATE=n): 1 no global loads, 2 + no barriers, 3 + no LDS reads.  A
+// Tuning builds only (-DMFTX_ABLATE=n): 1 no global loads, 2 + no barriers, 3 + no LDS reads; 4 no W loads, 5 no A loads.  A
 // compile-time switch on purpose: as run-time branches around the ds_reads these made the compiler
 // lose count of the outstanding LDS operations and wait for ALL of them (lgkmcnt(0)) in front of
 // every MFMA group.
@@ -244,12 +244,12 @@ void conv_gemm_kernel(ConvArgs p) {
         if (left == 0) next_run();
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            buf_load_lds(rA, a_dst + buf * BM * LDK + RPP * i * LDK, acur[i]);
+            if (MFTX_ABLATE != 5) buf_load_lds(rA, a_dst + buf * BM * LDK + RPP * i * LDK, acur[i]);
             acur[i] += BK * 4u;              // an OOB offset stays out of range
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            buf_load_lds(rW, b_dst + buf * BN * LDK + RPP * i * LDK, woff[i]);
+            if (MFTX_ABLATE != 4) buf_load_lds(rW, b_dst + buf * BN * LDK + RPP * i * LDK, woff[i]);
             woff[i] += BK * 4u;
         }
         --left;
@@ -266,7 +266,7 @@ void conv_gemm_kernel(ConvArgs p) {
 
     f32x4 fa[2][TM], fb[2][TN];              // register double buffer of MFMA fragments
     auto read_frags = [&](int buf, int kk, int slot) {
-        if (MFTX_ABLATE >= 3) return;
+        if (MFTX_ABLATE == 3) return;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
             fa[slot][i] = *reinterpret_cast<const f32x4 *>(a_frag[kk] + buf * BM * LDK + 32 * i * LDK);
@@ -305,7 +305,7 @@ void conv_gemm_kernel(ConvArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         mma(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (more && MFTX_ABLATE < 2) {
+        if (more && MFTX_ABLATE != 2 && MFTX_ABLATE != 3) {
             // own LDS reads of `buf` done (lgkmcnt), own DMA of the next chunk landed (vmcnt), then
             // every wave agrees (barrier)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -314,7 +314,7 @@ void conv_gemm_kernel(ConvArgs p) {
         }
         // slot `buf` is free: refill it at once with the chunk after next -- its DMA has a whole
         // step of MFMA work to land, and its issue hides under the MFMAs queued just above
-        if (more2 && MFTX_ABLATE < 1) fetch(buf);
+        if (more2 && (MFTX_ABLATE < 1 || MFTX_ABLATE > 3)) fetch(buf);
         if (more) read_frags(buf ^ 1, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         mma(1);
