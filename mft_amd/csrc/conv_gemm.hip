@@ -64,7 +64,7 @@ struct ConvArgs {
     float *hx; int ld_hx; float *z; float *rh;  // GRU epilogues
 };
 
-// Tuning builds only (-DMFTX_ABLATE=n): 1 no global loads, 2 + no barriers, 3 + no LDS reads; 4 no W loads, 5 no A loads.  A
+// Tuning builds only (-DMFTX_ABLATE=n): 1 no global loads, 2 + no barriers, 3 + no LDS reads; 4 no W loads, 5 no A loads, 6 A loads for every fifth chunk only.  A
 // compile-time switch on purpose: as run-time branches around the ds_reads these made the compiler
 // lose count of the outstanding LDS operations and wait for ALL of them (lgkmcnt(0)) in front of
 // every MFMA group.
@@ -244,7 +244,8 @@ void conv_gemm_kernel(ConvArgs p) {
         if (left == 0) next_run();
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            if (MFTX_ABLATE != 5) buf_load_lds(rA, a_dst + buf * BM * LDK + RPP * i * LDK, acur[i]);
+            if (MFTX_ABLATE != 5 && (MFTX_ABLATE != 6 || cc % 5 == 0))
+                buf_load_lds(rA, a_dst + buf * BM * LDK + RPP * i * LDK, acur[i]);
             acur[i] += BK * 4u;              // an OOB offset stays out of range
         }
 #pragma unroll
@@ -312,12 +313,14 @@ void conv_gemm_kernel(ConvArgs p) {
             wait_vmcnt<0>();
             block_barrier();
         }
-        // slot `buf` is free: refill it at once with the chunk after next -- its DMA has a whole
-        // step of MFMA work to land, and its issue hides under the MFMAs queued just above
-        if (more2 && (MFTX_ABLATE < 1 || MFTX_ABLATE > 3)) fetch(buf);
         if (more) read_frags(buf ^ 1, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         mma(1);
+        __builtin_amdgcn_sched_barrier(0);
+        // slot `buf` is free since the barrier: refill it with the chunk after next -- the DMA issue
+        // (the slowest instructions of the loop) runs under the four MFMAs just queued, and the data
+        // has most of a step to land
+        if (more2 && (MFTX_ABLATE < 1 || MFTX_ABLATE > 3)) fetch(buf);
         __builtin_amdgcn_sched_barrier(0);
     };
 
