@@ -140,15 +140,40 @@ def cpu_baseline(args, vid):
     for i in range(1, 33):              # steady-state memory ring without paying for 32 frames
         tr.memory[i] = dict(img=vid[i], result=ident)
     tr.cur = 32
+    first_meta = None
     with torch.no_grad():
         t0 = time.perf_counter()
         for i in range(33, 33 + n):
             meta = tr.track(vid[i])
             assert len(meta.pairs) == 7
+            first_meta = first_meta or meta
         dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{n} steady-state frames (7 flow pairs x {args.iters} iters + chain + select each) of the same "
-                      f"{H}x{W} synthetic video; oracle/mft_oracle.py on torch CPU ops, {dt:.1f} s"}
+                      f"{H}x{W} synthetic video; oracle/mft_oracle.py on torch CPU ops, {dt:.1f} s"}, first_meta
+
+
+def track_parity(args, vid, oracle_meta):
+    """One full MFT.track() step of the HIP path from the same state the cpu_baseline leg gave the
+    oracle (frames 1..32 in memory with identity results, frame 33 arriving: 7 flow pairs, 7 chains,
+    selection) against the oracle's result for that frame -- the oracle work is the baseline's."""
+    from mft_amd.results import FlowOUTrackingResult
+    tracker, _ = build_tracker(args, sharded=False)
+    tracker.init(vid[0])
+    H, W = vid[0].shape[:2]
+    for i in range(1, 33):
+        tracker.memory[i] = {"img": vid[i], "result": FlowOUTrackingResult.identity((H, W), device="cuda")}
+    tracker.current_frame_i = 32
+    got = tracker.track(vid[33]).result
+    flow, occl, sigma = (t.cpu() for t in (got.flow, got.occlusion, got.sigma))
+    rf, ro, rs = oracle_meta.result
+    same = (tracker.last_chosen.cpu().long() == oracle_meta.chosen.long())
+    epe = (flow - rf).pow(2).sum(0).sqrt()
+    return {"track_flow_epe_px": epe.mean().item(),
+            "track_flow_epe_px_where_same_delta": epe[same].mean().item(),
+            "track_chosen_delta_agreement": same.float().mean().item(),
+            "track_occlusion_max_abs_where_same_delta": (occl - ro).abs()[0][same].max().item(),
+            "track_sigma_max_rel_where_same_delta": ((sigma - rs).abs() / rs.clamp_min(1e-6))[0][same].max().item()}
 
 
 def flow_epe_vs_oracle(args, tracker, vid):
@@ -271,8 +296,11 @@ def main():
             result["parity"] = flow_epe_vs_oracle(args, tracker, host_frames)
             log(f"parity vs oracle: {result.get('parity')}")
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args, host_frames)
+            result["cpu_baseline"], oracle_meta = cpu_baseline(args, host_frames)
             log("cpu baseline done")
+            if not args.no_parity:
+                result.setdefault("parity", {}).update(track_parity(args, host_frames, oracle_meta))
+                log(f"track() parity vs oracle: {result['parity']}")
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
