@@ -42,7 +42,8 @@ constexpr int BK = 32;
 constexpr int LDK = BK;                  // LDS row (floats): unpadded, XOR-swizzled 16-byte chunks
 constexpr unsigned OOB = 0x80000000u;    // buffer offset that is out of range for every operand (< 2 GiB)
 
-enum Epi { EPI_GENERIC = 0, EPI_RELU = 1, EPI_GRU_ZR = 2, EPI_GRU_Q = 3 };
+enum Epi { EPI_GENERIC = 0, EPI_RELU = 1, EPI_GRU_ZR = 2, EPI_GRU_Q = 3,
+           EPI_VOLUME = 4 };   // = generic; its own instance so that profiles can tell the correlation volume apart
 
 struct ConvArgs {
     const float *a0, *a1;
@@ -71,6 +72,16 @@ struct ConvArgs {
 #ifndef MFTX_ABLATE
 #define MFTX_ABLATE 0
 #endif
+
+// Gate non-linearities of the GRU epilogues on the hardware exponential (v_exp_f32, ~1 ulp) and
+// reciprocal: 16 values per lane and tile, where libm's expf / tanhf cost ~7 % of the q-gate kernel.
+// Absolute error < 2e-7 on outputs in (-1, 1) -- four orders below the parity tolerance; the same
+// code runs for every tile shape and batch, so results stay independent of both.
+__device__ __forceinline__ float fast_sigmoid(float s) { return __frcp_rn(1.f + __expf(-s)); }
+__device__ __forceinline__ float fast_tanh(float s) {
+    const float t = __expf(-2.f * fabsf(s));            // in (0, 1]: no overflow
+    return copysignf((1.f - t) * __frcp_rn(1.f + t), s);
+}
 
 __device__ __forceinline__ float act_fn(float v, int act) {
     switch (act) {
@@ -365,11 +376,11 @@ void conv_gemm_kernel(ConvArgs p) {
                 if constexpr (EPI == EPI_RELU) {
                     out[(long long)m * p.ldo + n] = fmaxf(s, 0.f) * p.out_scale;
                 } else if constexpr (EPI == EPI_GRU_ZR) {   // [z | r] gates; r is folded into r*h
-                    const float v = 1.f / (1.f + expf(-s));
+                    const float v = fast_sigmoid(s);
                     if (n < 128) p.z[(long long)m * 128 + n] = v;
                     else p.rh[(long long)m * 128 + (n - 128)] = v * p.hx[(long long)m * p.ld_hx + (n - 128)];
                 } else if constexpr (EPI == EPI_GRU_Q) {    // candidate q, h <- (1-z) h + z q
-                    const float v = tanhf(s);
+                    const float v = fast_tanh(s);
                     const float zz = p.z[(long long)m * 128 + n];
                     float *hp = p.hx + (long long)m * p.ld_hx + n;
                     *hp = (1.f - zz) * (*hp) + zz * v;
@@ -432,7 +443,6 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
         case 0: return launch_cfg<128, 128, 2, 2, EPI>(a, batch, s, cat);
         case 1: return launch_cfg<128, 64, 2, 2, EPI>(a, batch, s, cat);
         case 2: return launch_cfg<64, 64, 2, 2, EPI>(a, batch, s, cat);
-        case 4: return launch_cfg<64, 32, 2, 1, EPI>(a, batch, s, cat);   // 2 waves: twice the tiles of 64x64
         default: return launch_cfg<128, 32, 4, 1, EPI>(a, batch, s, cat);
     }
 }
@@ -440,14 +450,14 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
 static int pick_tile(const ConvArgs &a, int batch) {
     // debug/tuning override: MFTX_CONV_TILE=0..3
     static const int forced = [] { const char *e = getenv("MFTX_CONV_TILE"); return e ? atoi(e) : -1; }();
-    if (forced >= 0 && forced <= 4) return forced;
+    if (forced >= 0 && forced <= 3) return forced;
     // Measured on MI355X (tools/bench_conv.py, M = 7 x 4096 and 4096): the 64x64
-    // tile (4 workgroups per CU, LDS-bound) wins or ties on every layer -- more
-    // resident waves hide the LDS-DMA latency better than bigger tiles save on
-    // operand re-reads -- except for N = 192 (convc2), where 128x64 avoids a
-    // half-empty column tile.  N <= 32 (only reached when the small-N VALU
-    // kernel does not apply) gets the 128x32 tile.  A two-wave 64x32 tile (twice
-    // the tiles, better CU balance for N = 128) was measured and loses 20 %.
+    // tile (4 workgroups per CU) wins or ties on every layer -- 7 x 2^k rows tile
+    // the 256 CUs more evenly in small tiles than bigger tiles save on operand
+    // re-reads -- except for N = 192 (convc2), where 128x64 avoids a half-empty
+    // column tile.  N <= 32 (only reached when the small-N VALU kernel does not
+    // apply) gets the 128x32 tile.  A two-wave 64x32 tile (twice the tiles) was
+    // measured and loses 20 %.
     (void)batch;
     if (a.N <= 32) return 3;
     if (a.N > 128 && a.N % 128 == 64 && a.M >= 16384) return 1;   // at small M the extra tiles of 64x64 win
@@ -534,11 +544,9 @@ int launch_corr_volume(const float *f1, const float *f2, int P, int C, int N, fl
     a.act = 0; a.out_scale = 1.0f / sqrtf((float)C);
     a.a_bstride = (long long)N * C; a.w_bstride = (long long)N * C; a.o_bstride = (long long)N * N;
     a.a0_bytes = (unsigned)((long long)N * C * 4); a.a1_bytes = 0; a.w_bytes = a.a0_bytes;
-    static const int forced = [] { const char *e = getenv("MFTX_CORR_TILE"); return e ? atoi(e) : -1; }();
-    if (forced == 2) return launch_cfg<64, 64, 2, 2, EPI_GENERIC>(a, P, s, PC_CORR_VOLUME);
-    if (forced == 1) return launch_cfg<128, 64, 2, 2, EPI_GENERIC>(a, P, s, PC_CORR_VOLUME);
-    if (N >= 1024) return launch_cfg<128, 128, 2, 2, EPI_GENERIC>(a, P, s, PC_CORR_VOLUME);
-    return launch_cfg<64, 64, 2, 2, EPI_GENERIC>(a, P, s, PC_CORR_VOLUME);
+    // measured (tools/bench_corr.py): 128x64 beats 128x128 by 3 % at 64x64 cells and 5 % at 136x240, 64x64 ties it
+    if (N >= 1024) return launch_cfg<128, 64, 2, 2, EPI_VOLUME>(a, P, s, PC_CORR_VOLUME);
+    return launch_cfg<64, 64, 2, 2, EPI_VOLUME>(a, P, s, PC_CORR_VOLUME);
 }
 
 }  // namespace mftx
