@@ -133,7 +133,8 @@ def cpu_baseline(args, vid):
     torch.set_num_threads(cores)
     sd = {k: torch.from_numpy(v) for k, v in make_weights(0).items()}
     n = args.cpu_frames
-    tr = O.Tracker(lambda l, r, li, ri: O.compute_flow(sd, li, ri, args.iters))
+    stages = {}
+    tr = O.Tracker(lambda l, r, li, ri: O.compute_flow(sd, li, ri, args.iters, timers=stages), timers=stages)
     tr.init(vid[0])
     H, W = vid[0].shape[:2]
     ident = (torch.zeros(2, H, W), torch.zeros(1, H, W), torch.zeros(1, H, W))
@@ -150,7 +151,9 @@ def cpu_baseline(args, vid):
         dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{n} steady-state frames (7 flow pairs x {args.iters} iters + chain + select each) of the same "
-                      f"{H}x{W} synthetic video; oracle/mft_oracle.py on torch CPU ops, {dt:.1f} s"}, first_meta
+                      f"{H}x{W} synthetic video; oracle/mft_oracle.py on torch CPU ops, {dt:.1f} s",
+            "s_per_frame": dt / n,
+            "stage_s_per_frame": {k: v / n for k, v in stages.items()}}, first_meta
 
 
 def track_parity(args, vid, oracle_meta):

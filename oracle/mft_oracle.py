@@ -295,34 +295,58 @@ def convex_upsample(x, mask, mult):
 # a2: RAFT forward in test mode (core/raft.py:97-259)
 # ---------------------------------------------------------------------------
 
-def raft_refine(sd, fmap1, fmap2, net, inp, iters, flow_init=None, trace=None):
+class _Stage:
+    """`with _Stage(timers, key):` adds the wall time of the block to timers[key] (bench.py's
+    per-stage split of the CPU baseline); a no-op when timers is None."""
+
+    def __init__(self, timers, key):
+        self.timers, self.key = timers, key
+
+    def __enter__(self):
+        if self.timers is not None:
+            import time
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        if self.timers is not None:
+            import time
+            self.timers[self.key] = self.timers.get(self.key, 0.0) + time.perf_counter() - self.t0
+
+
+def raft_refine(sd, fmap1, fmap2, net, inp, iters, flow_init=None, trace=None, timers=None):
     """The iterative part of RAFT.forward, from feature maps onwards."""
     _, _, h, w = fmap1.shape
-    pyr = corr_pyramid(corr_volume(fmap1, fmap2))
+    with _Stage(timers, "corr_volume_pyramid"):
+        pyr = corr_pyramid(corr_volume(fmap1, fmap2))
     coords0 = pixel_grid(h, w)[None]
     coords1 = coords0.clone()
     if flow_init is not None:
         coords1 = coords1 + flow_init
     for itr in range(iters):
-        corr = corr_lookup(pyr, coords1)
+        with _Stage(timers, "corr_lookup"):
+            corr = corr_lookup(pyr, coords1)
         flow = coords1 - coords0
-        net, mask, delta, motion = update_block(sd, net, inp, corr, flow)
+        with _Stage(timers, "update_block"):
+            net, mask, delta, motion = update_block(sd, net, inp, corr, flow)
         coords1 = coords1 + delta
         if trace is not None:
             trace.append(dict(corr=corr, net=net, delta=delta, coords1=coords1))
     flow_lr = coords1 - coords0
-    occl, unc = ou_block(sd, net, inp, corr, flow_lr, delta, motion)
-    return dict(flow=convex_upsample(flow_lr, mask, 8.0),
-                occlusion=convex_upsample(occl, mask, 1.0),
-                uncertainty=convex_upsample(unc, mask, 1.0),
-                coords=flow_lr)
+    with _Stage(timers, "ou_block"):
+        occl, unc = ou_block(sd, net, inp, corr, flow_lr, delta, motion)
+    with _Stage(timers, "convex_upsample"):
+        return dict(flow=convex_upsample(flow_lr, mask, 8.0),
+                    occlusion=convex_upsample(occl, mask, 1.0),
+                    uncertainty=convex_upsample(unc, mask, 1.0),
+                    coords=flow_lr)
 
 
-def raft_forward(sd, image1, image2, iters=12, flow_init=None):
-    fmap1 = features(sd, image1)
-    fmap2 = features(sd, image2)
-    net, inp = context(sd, image1)
-    return raft_refine(sd, fmap1, fmap2, net, inp, iters, flow_init)
+def raft_forward(sd, image1, image2, iters=12, flow_init=None, timers=None):
+    with _Stage(timers, "encoders"):
+        fmap1 = features(sd, image1)
+        fmap2 = features(sd, image2)
+        net, inp = context(sd, image1)
+    return raft_refine(sd, fmap1, fmap2, net, inp, iters, flow_init, timers=timers)
 
 
 def postprocess(pred, H0, W0):
@@ -333,11 +357,11 @@ def postprocess(pred, H0, W0):
     return flow, occl, sigma
 
 
-def compute_flow(sd, src_img, dst_img, iters=12):
+def compute_flow(sd, src_img, dst_img, iters=12, timers=None):
     """RAFTWrapper.compute_flow(mode='flow') (MFT/raft.py:30-73) ->
     flow[2,H,W], occlusion[1,H,W], sigma[1,H,W]."""
     H0, W0 = src_img.shape[:2]
-    pred = raft_forward(sd, preprocess(src_img), preprocess(dst_img), iters)
+    pred = raft_forward(sd, preprocess(src_img), preprocess(dst_img), iters, timers=timers)
     return postprocess(pred, H0, W0)
 
 
@@ -400,10 +424,11 @@ class Tracker:
     left_img, right_img) -> (flow, occl, sigma)`` so tests can plug in either
     the oracle RAFT or recorded flows."""
 
-    def __init__(self, flow_fn, deltas=(np.inf, 1, 2, 4, 8, 16, 32), occlusion_threshold=0.02):
+    def __init__(self, flow_fn, deltas=(np.inf, 1, 2, 4, 8, 16, 32), occlusion_threshold=0.02, timers=None):
         self.flow_fn = flow_fn
         self.deltas = list(deltas)
         self.thr = occlusion_threshold
+        self.timers = timers            # optional {stage: seconds} accumulator (bench.py)
 
     def init(self, img, start_frame_i=0, time_direction=1):
         H, W = img.shape[:2]
@@ -429,11 +454,13 @@ class Tracker:
             if left in used:
                 continue
             R = self.flow_fn(left, self.cur, self.memory[left]["img"], img)
-            cands[d] = chain(self.memory[left]["result"], R)
+            with _Stage(self.timers, "chain"):
+                cands[d] = chain(self.memory[left]["result"], R)
             used.append(left)
             pairs.append((left, self.cur))
         order = sorted(cands.keys(), key=lambda d: 0 if np.isinf(d) else d)
-        flow, occ, sig, idx = select([cands[d] for d in order], self.thr)
+        with _Stage(self.timers, "select"):
+            flow, occ, sig, idx = select([cands[d] for d in order], self.thr)
         self.memory[self.cur] = dict(img=img, result=(flow, occ, sig))
         self._cleanup()
         return SimpleNamespace(result=(flow, occ, sig), chosen=idx, pairs=pairs,
