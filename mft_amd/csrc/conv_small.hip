@@ -6,20 +6,20 @@
 // VALU kernel: one wave walks a horizontal strip of cells; lane l owns channels
 // 4l..4l+3, keeps its 9 x N x 4 weights in registers for the whole strip, slides
 // a 3x3 window of float4 activations along the row (3 new loads per cell instead
-// of 9) and reduces the N partial sums across the wave with DPP-free xor shuffles.
-// Reads are 1 KiB-coalesced per (row, column); traffic is ~3x the input map.
+// of 9) and reduces the N partial sums across the wave with xor shuffles.
+// Reads are 1 KiB-coalesced per (row, column); traffic is 3 (len + 2) / len x the input map.
 #include "common.h"
 #include "profile.h"
+#include <cstdlib>
 
 namespace mftx {
 
-constexpr int SN_STRIP = 16;   // cells per wave
 
 template <int N>
 __global__ __launch_bounds__(256) void conv3x3_small_kernel(const float *__restrict__ x, int ldx,
                                                             const float *__restrict__ wpk,   // [>=N][9][256]
                                                             const float *__restrict__ bias, float *__restrict__ out,
-                                                            int ldo, int P, int h, int w, int strips_per_row) {
+                                                            int ldo, int P, int h, int w, int strip_len, int strips_per_row) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);          // global wave id
     const int total = P * h * strips_per_row;
@@ -28,8 +28,8 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const float *__restr
     const int rowid = gw / strips_per_row;                        // img*h + y
     const int y = rowid % h;
     const long long img_base = (long long)(rowid / h) * h * w;
-    const int x0 = strip * SN_STRIP;
-    const int x1 = min(x0 + SN_STRIP, w);
+    const int x0 = strip * strip_len;
+    const int x1 = min(x0 + strip_len, w);
 
     float4 wt[9][N];
 #pragma unroll
@@ -85,13 +85,20 @@ bool conv_small_applicable(const mftx_conv_desc &d) {
 }
 
 int launch_conv_small(const mftx_conv_desc &d, hipStream_t s) {
-    const int strips = cdiv(d.w, SN_STRIP);
+    // Cells per wave: a wave walks its strip serially (3 loads of latency per cell), so the strip is as
+    // short as it takes to put ~8 waves on every SIMD -- 16 cells at P = 7 left 1.75 waves per SIMD and
+    // the kernel latency-bound; shorter strips re-read more halo columns (3 x (len + 2) / len).
+    static const int forced = [] { const char *e = getenv("MFTX_SMALL_STRIP"); return e ? atoi(e) : 0; }();
+    const long long cells = (long long)d.P * d.h * d.w;
+    int strip_len = forced > 0 ? forced : (int)(cells / 8192);
+    strip_len = strip_len < 2 ? 2 : (strip_len > 16 ? 16 : strip_len);
+    const int strips = cdiv(d.w, strip_len);
     const int waves = d.P * d.h * strips;
     dim3 grid(cdiv(waves, 4));
     ProfScope prof(PC_CONV_SMALL, s, 2.0 * d.P * d.h * d.w * d.N * 9.0 * 256.0);
 #define SN_LAUNCH(NN)                                                                                              \
     hipLaunchKernelGGL(conv3x3_small_kernel<NN>, grid, dim3(256), 0, s, d.a0, d.lda0, d.wpk, d.bias, d.out, d.ldo, \
-                       d.P, d.h, d.w, strips)
+                       d.P, d.h, d.w, strip_len, strips)
     switch (d.N) {
         case 1: SN_LAUNCH(1); break;
         case 2: SN_LAUNCH(2); break;
