@@ -358,8 +358,13 @@ void conv_gemm_kernel(ConvArgs p) {
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // Two phases per 32x32 tile: every global read first (addend, z, h), then the arithmetic and the
+    // stores.  Interleaved per element, the compiler must assume that a store aliases the next
+    // element's loads and serialises 16 x (load - wait - store - wait): ~10 us per tile, fully
+    // exposed when a CU has a single tile (one flow pair per GPU).
     const int col_l = lane & 31;
     const int row_h = 4 * (lane >> 5);
+    const bool pre_add = p.addend != nullptr && p.residual_mode == 0;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * TN * 32 + j * 32 + col_l;
@@ -367,27 +372,40 @@ void conv_gemm_kernel(ConvArgs p) {
         const float bias = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            float add[16], aux0[16], aux1[16];       // addend; z / h (GRU)
+            const int mb = m0 + wm * TM * 32 + i * 32 + row_h;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                add[r] = aux0[r] = aux1[r] = 0.f;
+                if (!n_ok || m >= p.M) continue;
+                if (pre_add || p.residual_mode == 1) add[r] = p.addend[(long long)m * p.ld_addend + n];
+                if constexpr (EPI == EPI_GRU_ZR) {
+                    if (n >= 128) aux1[r] = p.hx[(long long)m * p.ld_hx + (n - 128)];
+                } else if constexpr (EPI == EPI_GRU_Q) {
+                    aux0[r] = p.z[(long long)m * 128 + n];
+                    aux1[r] = p.hx[(long long)m * p.ld_hx + n];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = mb + (r & 3) + 8 * (r >> 2);
                 if (!n_ok || m >= p.M) continue;
                 float s = acc[i][j][r] + bias;
-                if (p.addend != nullptr && p.residual_mode == 0) s += p.addend[(long long)m * p.ld_addend + n];
+                if (pre_add) s += add[r];
                 if constexpr (EPI == EPI_RELU) {
-                    out[(long long)m * p.ldo + n] = fmaxf(s, 0.f) * p.out_scale;
+                    out[m * p.ldo + n] = fmaxf(s, 0.f) * p.out_scale;
                 } else if constexpr (EPI == EPI_GRU_ZR) {   // [z | r] gates; r is folded into r*h
                     const float v = fast_sigmoid(s);
-                    if (n < 128) p.z[(long long)m * 128 + n] = v;
-                    else p.rh[(long long)m * 128 + (n - 128)] = v * p.hx[(long long)m * p.ld_hx + (n - 128)];
+                    if (n < 128) p.z[m * 128 + n] = v;
+                    else p.rh[m * 128 + (n - 128)] = v * aux1[r];
                 } else if constexpr (EPI == EPI_GRU_Q) {    // candidate q, h <- (1-z) h + z q
                     const float v = fast_tanh(s);
-                    const float zz = p.z[(long long)m * 128 + n];
-                    float *hp = p.hx + (long long)m * p.ld_hx + n;
-                    *hp = (1.f - zz) * (*hp) + zz * v;
+                    p.hx[m * p.ld_hx + n] = (1.f - aux0[r]) * aux1[r] + aux0[r] * v;
                 } else {
                     float v = act_fn(s, p.act) * p.out_scale;
-                    if (p.residual_mode == 1) v = fmaxf(v + p.addend[(long long)m * p.ld_addend + n], 0.f);
-                    out[(long long)m * p.ldo + n] = v;
+                    if (p.residual_mode == 1) v = fmaxf(v + add[r], 0.f);
+                    out[m * p.ldo + n] = v;
                 }
             }
         }
