@@ -117,7 +117,7 @@ __device__ __forceinline__ void wait_vmcnt() {   // counted wait: leaves N LDS-D
 // Waves per SIMD the register allocator must leave room for (second __launch_bounds__ argument):
 // left alone it spends registers freely in the pinned K loop and costs a resident workgroup.
 #ifndef MFTX_MINW1
-#define MFTX_MINW1 5
+#define MFTX_MINW1 4      // 128 registers: nothing spills; 5 (96 registers, spills in the GRU epilogues) measures 0.5 % slower
 #endif
 constexpr int min_waves(int wave_tiles) { return wave_tiles == 1 ? MFTX_MINW1 : wave_tiles == 2 ? 3 : 2; }
 

@@ -85,13 +85,12 @@ bool conv_small_applicable(const mftx_conv_desc &d) {
 }
 
 int launch_conv_small(const mftx_conv_desc &d, hipStream_t s) {
-    // Cells per wave: a wave walks its strip serially (3 loads of latency per cell), so the strip is as
-    // short as it takes to put ~8 waves on every SIMD -- 16 cells at P = 7 left 1.75 waves per SIMD and
-    // the kernel latency-bound; shorter strips re-read more halo columns (3 x (len + 2) / len).
+    // Cells per wave (measured, tools/bench_small.py): 16 at 7 pairs (20.5 us; 3 -> 24.1 us: the halo
+    // columns of short strips are re-read), 8 when one or two pairs leave the chip short of waves
+    // (13.7 -> 9.9 us at one pair).
     static const int forced = [] { const char *e = getenv("MFTX_SMALL_STRIP"); return e ? atoi(e) : 0; }();
     const long long cells = (long long)d.P * d.h * d.w;
-    int strip_len = forced > 0 ? forced : (int)(cells / 8192);
-    strip_len = strip_len < 2 ? 2 : (strip_len > 16 ? 16 : strip_len);
+    const int strip_len = forced > 0 ? forced : (cells >= 16384 ? 16 : 8);
     const int strips = cdiv(d.w, strip_len);
     const int waves = d.P * d.h * strips;
     dim3 grid(cdiv(waves, 4));

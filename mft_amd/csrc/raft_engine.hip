@@ -64,8 +64,16 @@ __global__ __launch_bounds__(128) void convf1_kernel(const float *__restrict__ c
     const float b = bias[co];
 #pragma unroll
     for (int t = 0; t < F1_CELLS; ++t) acc[t] = b;
+    // this output channel's 14 weights of filter row ky are loaded one row ahead (register double
+    // buffer): taken inside the row loop their L2 latency showed 7 times per strip
+    float wc[14], wn[14];
+#pragma unroll
+    for (int q = 0; q < 14; ++q) wc[q] = w98[q * 128 + co];
 #pragma unroll 1
     for (int ky = 0; ky < 7; ++ky) {
+        const int kyn = ky < 6 ? ky + 1 : 6;
+#pragma unroll
+        for (int q = 0; q < 14; ++q) wn[q] = w98[(kyn * 14 + q) * 128 + co];
         // the whole patch row goes to registers once (11 broadcast ds_read_b128), then 7 x 16 x 2 FMAs
         float row[44];
 #pragma unroll
@@ -75,12 +83,13 @@ __global__ __launch_bounds__(128) void convf1_kernel(const float *__restrict__ c
         }
 #pragma unroll
         for (int kx = 0; kx < 7; ++kx) {
-            const float w0 = w98[((ky * 7 + kx) * 2 + 0) * 128 + co];
-            const float w1 = w98[((ky * 7 + kx) * 2 + 1) * 128 + co];
+            const float w0 = wc[2 * kx], w1 = wc[2 * kx + 1];
 #pragma unroll
             for (int t = 0; t < F1_CELLS; ++t)
                 acc[t] += w0 * row[2 * (t + kx)] + w1 * row[2 * (t + kx) + 1];
         }
+#pragma unroll
+        for (int q = 0; q < 14; ++q) wc[q] = wn[q];
     }
 #pragma unroll
     for (int t = 0; t < F1_CELLS; ++t) {
