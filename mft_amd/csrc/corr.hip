@@ -25,12 +25,35 @@ __global__ __launch_bounds__(256) void corr_pool_kernel(const float *__restrict_
     float *d1 = lvl1 + row * (long long)h1 * w1;
     float *d2 = lvl2 + row * (long long)h2 * w2;
     float *d3 = lvl3 + row * (long long)h3 * w3;
-    for (int i = threadIdx.x; i < h1 * w1; i += blockDim.x) {
-        const int y = i / w1, x = i - y * w1;
-        const float *p = src + (2 * y) * w + 2 * x;
-        const float v = (((p[0] + p[1]) + p[w]) + p[w + 1]) * 0.25f;
-        s1[i] = v;
-        d1[i] = v;
+    // four outputs per thread and trip: all eight 8-byte loads first, then the stores (a store between
+    // two loads makes the compiler drain vmcnt before the second load's data can be used)
+    for (int i0 = threadIdx.x; i0 < h1 * w1; i0 += 4 * blockDim.x) {
+        float2 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * blockDim.x;
+            a[u] = b[u] = make_float2(0.f, 0.f);
+            if (i < h1 * w1) {
+                const int y = i / w1, x = i - y * w1;
+                const float *p = src + (2 * y) * w + 2 * x;       // even offset: 8-byte aligned when w is even
+                if ((w & 1) == 0) {
+                    a[u] = *reinterpret_cast<const float2 *>(p);
+                    b[u] = *reinterpret_cast<const float2 *>(p + w);
+                } else {
+                    a[u] = make_float2(p[0], p[1]);
+                    b[u] = make_float2(p[w], p[w + 1]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * blockDim.x;
+            if (i < h1 * w1) {
+                const float v = (((a[u].x + a[u].y) + b[u].x) + b[u].y) * 0.25f;
+                s1[i] = v;
+                d1[i] = v;
+            }
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < h2 * w2; i += blockDim.x) {
