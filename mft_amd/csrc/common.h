@@ -45,7 +45,7 @@ struct GruEpilogue {
 };
 int launch_conv_gru(const mftx_conv_desc &d, const GruEpilogue &g, hipStream_t s);
 bool conv_small_applicable(const mftx_conv_desc &d);
-int launch_conv_small(const mftx_conv_desc &d, hipStream_t s);
+int launch_conv_small(const mftx_conv_desc &d, hipStream_t s, float *accum = nullptr, int ld_accum = 0);
 int launch_corr_volume(const float *f1, const float *f2, int P, int C, int N, float *lvl0, hipStream_t s);
 int launch_corr_pool(const float *lvl0, int rows, int h, int w, float *lvl1, float *lvl2, float *lvl3, hipStream_t s);
 int launch_corr_lookup(const float *const lvl[4], const float *coords, int P, int h, int w,

@@ -19,7 +19,8 @@ template <int N>
 __global__ __launch_bounds__(256) void conv3x3_small_kernel(const float *__restrict__ x, int ldx,
                                                             const float *__restrict__ wpk,   // [>=N][9][256]
                                                             const float *__restrict__ bias, float *__restrict__ out,
-                                                            int ldo, int P, int h, int w, int strip_len, int strips_per_row) {
+                                                            int ldo, int P, int h, int w, int strip_len, int strips_per_row,
+                                                            float *__restrict__ accum, int ld_accum) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);          // global wave id
     const int total = P * h * strips_per_row;
@@ -37,7 +38,14 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const float *__restr
 #pragma unroll
         for (int n = 0; n < N; ++n)
             wt[t][n] = *reinterpret_cast<const float4 *>(wpk + ((long long)n * 9 + t) * 256 + lane * 4);
-    const float bb = (bias != nullptr && lane < N) ? bias[lane] : 0.f;   // lane n writes output channel n
+    // lane t * N + n keeps output channel n of the strip's cell t: one store pass after the loop (a store
+    // inside it would sit between the loads of consecutive cells and drain vmcnt every time)
+    const float bb = bias != nullptr ? bias[lane % N] : 0.f;
+    float keep = 0.f;
+    const bool mine = lane < (x1 - x0) * N;
+    const long long my_cell = img_base + (long long)y * w + x0 + lane / N;
+    // the value to accumulate into is fetched now, so that its latency is gone by the end of the strip
+    const float old = (mine && accum != nullptr) ? accum[my_cell * ld_accum + lane % N] : 0.f;
 
     struct Col { float4 r0, r1, r2; };
     const bool y0ok = y - 1 >= 0, y2ok = y + 1 < h;
@@ -68,14 +76,15 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const float *__restr
             for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
             acc[n] = a;
         }
-        if (lane < N) {
-            float v = acc[0];
 #pragma unroll
-            for (int n = 1; n < N; ++n) v = (lane == n) ? acc[n] : v;
-            out[(img_base + (long long)y * w + xc) * ldo + lane] = v + bb;
-        }
+        for (int n = 0; n < N; ++n)
+            if (lane == (xc - x0) * N + n) keep = acc[n] + bb;
         c0 = c1;
         c1 = c2;
+    }
+    if (mine) {
+        out[my_cell * ldo + lane % N] = keep;
+        if (accum != nullptr) accum[my_cell * ld_accum + lane % N] = old + keep;   // coords1 += delta_flow (core/raft.py:184)
     }
 }
 
@@ -84,7 +93,9 @@ bool conv_small_applicable(const mftx_conv_desc &d) {
            d.lda0 % 4 == 0;
 }
 
-int launch_conv_small(const mftx_conv_desc &d, hipStream_t s) {
+// accum (optional, [cells][ld_accum]): the N outputs are also added to it -- the flow head's last layer
+// updates coords1 in the same pass instead of a separate add kernel.
+int launch_conv_small(const mftx_conv_desc &d, hipStream_t s, float *accum, int ld_accum) {
     // Cells per wave (measured, tools/bench_small.py): 16 at 7 pairs (20.5 us; 3 -> 24.1 us: the halo
     // columns of short strips are re-read), 8 when one or two pairs leave the chip short of waves
     // (13.7 -> 9.9 us at one pair).
@@ -97,7 +108,7 @@ int launch_conv_small(const mftx_conv_desc &d, hipStream_t s) {
     ProfScope prof(PC_CONV_SMALL, s, 2.0 * d.P * d.h * d.w * d.N * 9.0 * 256.0);
 #define SN_LAUNCH(NN)                                                                                              \
     hipLaunchKernelGGL(conv3x3_small_kernel<NN>, grid, dim3(256), 0, s, d.a0, d.lda0, d.wpk, d.bias, d.out, d.ldo, \
-                       d.P, d.h, d.w, strip_len, strips)
+                       d.P, d.h, d.w, strip_len, strips, accum, ld_accum)
     switch (d.N) {
         case 1: SN_LAUNCH(1); break;
         case 2: SN_LAUNCH(2); break;

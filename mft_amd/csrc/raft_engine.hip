@@ -102,12 +102,6 @@ __global__ __launch_bounds__(128) void convf1_kernel(const float *__restrict__ c
     }
 }
 
-// coords1 += delta_flow (core/raft.py:184)
-__global__ void add_delta_kernel(float *coords1, const float *__restrict__ delta, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) coords1[i] += delta[i];
-}
-
 // OU input [net128 | inp128 | corr324 | flow2 | delta2 | motion128] = 712
 // (core/update.py:197), flow = coords1 - grid AFTER the last update
 // (core/raft.py:199-206); also emits flow_lr for the upsampler.
@@ -309,13 +303,12 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         }
         // flow head (core/update.py:6-14) and coordinate update (core/raft.py:184)
         TRY(launch_conv(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, W[W_FH1], W[B_FH1], ws.fh, 256, P, h, w, 256, 3, 3, 1), s));
-        TRY(launch_conv(conv_desc(ws.fh, 256, 256, nullptr, 0, 0, W[W_FH2], W[B_FH2], ws.delta, 2, P, h, w, 2, 3, 3, 0), s));
+        // last layer of the flow head, fused with coords1 += delta_flow (core/raft.py:184)
         {
-            ProfScope prof(PC_GLUE, s, 0);
-            hipLaunchKernelGGL(add_delta_kernel, dim3((unsigned)((2ll * M + 255) / 256)), dim3(256), 0, s, ws.coords1,
-                               ws.delta, 2ll * M);
+            const mftx_conv_desc fh2 = conv_desc(ws.fh, 256, 256, nullptr, 0, 0, W[W_FH2], W[B_FH2], ws.delta, 2, P, h, w, 2, 3, 3, 0);
+            if (!conv_small_applicable(fh2)) return fail(MFTX_E_STATE, "raft_refine: flow-head layer does not fit the small-N kernel");
+            TRY(launch_conv_small(fh2, s, ws.coords1, 2));
         }
-        TRY(check_launch("add_delta"));
         if (!last) continue;
         // The upsampling mask is consumed only after the last iteration in test
         // mode (core/raft.py:190-196,234-239), so it is computed once.
