@@ -162,6 +162,47 @@ class FlowOUTrackingResult(object):
             out.append(F.grid_sample(t.to(dev).to(torch.float32)[None], normed, align_corners=True)[0, :, 0, :])
         return tuple(out)
 
+    def warp_forward(self, img, mask=None, border=None):
+        """Forward-splat ``img`` (H, W, ...) along the flow: every (unmasked) source pixel spreads its value
+        over the four pixels around its destination with bilinear weights (destination and corners
+        clamped into the image), and each output pixel is the weight-normalised sum of what reached it --
+        MFT/results.py:190-248 with MFT/utils/interpolation.py:234-309.  Pixels nothing reached are 0, or
+        ``border``.  Returns a numpy array like the reference.  (Visualisation helper: torch ops on
+        whatever device the flow lives on; not part of the tracking path.)"""
+        dev = self.flow.device
+        H, W = self.H, self.W
+        assert tuple(img.shape[:2]) == (H, W)
+        vals = torch.as_tensor(np.asarray(img) if not isinstance(img, torch.Tensor) else img).to(dev)
+        extra = vals.shape[2:]
+        vals = vals.reshape(H * W, -1)
+        vmin, vmax = vals.min(), vals.max()
+        dst = (_grid(H, W, dev) + self.flow.to(torch.float32)).reshape(2, H * W)
+        if mask is not None:
+            keep = torch.as_tensor(np.asarray(mask) if not isinstance(mask, torch.Tensor) else mask).to(dev).reshape(-1).bool()
+            dst, vals = dst[:, keep], vals[keep]
+        x, y = dst[0], dst[1]
+        x0, y0 = torch.floor(x).long(), torch.floor(y).long()
+        x1, y1 = x0 + 1, y0 + 1
+        x, y = x.clamp(0, W - 1), y.clamp(0, H - 1)
+        x0, x1 = x0.clamp(0, W - 1), x1.clamp(0, W - 1)
+        y0, y1 = y0.clamp(0, H - 1), y1.clamp(0, H - 1)
+        wx0, wx1 = x1.float() - x, x - x0.float()
+        wy0, wy1 = y1.float() - y, y - y0.float()
+        idx = torch.cat((y0 * W + x0, y1 * W + x0, y0 * W + x1, y1 * W + x1))
+        wts = torch.cat((wx0 * wy0, wx0 * wy1, wx1 * wy0, wx1 * wy1))[:, None]
+        vals = vals.to(wts.dtype) if not vals.is_floating_point() else vals
+        accum = torch.zeros((H * W, vals.shape[1]), dtype=vals.dtype, device=dev)
+        accum = accum.index_put((idx,), vals.repeat(4, 1) * wts.to(vals.dtype), accumulate=True)
+        counts = torch.zeros((H * W, 1), dtype=wts.dtype, device=dev).index_put((idx,), wts, accumulate=True)
+        hit = counts[:, 0] > 0
+        out = accum.clone()
+        out[hit] /= counts[hit].to(out.dtype)
+        eps = 5e-3
+        assert out.min() >= min(float(vmin), 0) - eps and out.max() <= max(float(vmax), 0) + eps
+        if border is not None:
+            out[~hit] = border
+        return out.reshape(H, W, *extra).cpu().numpy()
+
     def invalid_mask(self):
         """(H, W) bool, True where the flow points outside the image
         (MFT/results.py:250-265)."""

@@ -113,3 +113,19 @@ def tapvid_inputs():
     frames = r.integers(0, 255, size=(T, 8, 8, 3), dtype=np.uint8)
     return dict(gt_tracks=gt_tracks, gt_occluded=gt_occluded, pred_tracks=pred_tracks,
                 pred_occluded=pred_occluded, frames=frames)
+
+
+def results_api_inputs():
+    """A FlowOU result on a 40 x 56 frame (smooth flow that leaves the frame on two sides), an image to warp,
+    a mask, and query points incl. out-of-frame and integral ones."""
+    H, W = 40, 56
+    r = _rng(41)
+    flow = smooth_field(r, 2, H, W, cells=3, amp=6.0)
+    flow[:, :, :6] -= 9.0                       # far left columns leave the frame
+    occl = (r.random((1, H, W)) * 0.3).astype(np.float32)
+    sigma = (0.2 + r.random((1, H, W))).astype(np.float32)
+    img = r.random((H, W, 3)).astype(np.float32)
+    mask = r.random((H, W)) < 0.7
+    pts = np.array([[0.0, 0.0], [3.25, 7.5], [55.0, 39.0], [-2.0, 4.0], [60.5, 10.0], [27.0, 20.0], [10.75, 38.6]],
+                   np.float32)
+    return dict(flow=flow.astype(np.float32), occl=occl, sigma=sigma, img=img, mask=mask, pts=pts)

@@ -229,6 +229,22 @@ def gen_e2e(model):
     print("sequence_raft.npz", sum(v.nbytes for v in out.values()) / 1e6, "MB")
 
 
+def gen_results_api():
+    """FlowOUTrackingResult's point-query and warping methods (MFT/results.py:116-265) on seeded inputs."""
+    d = gi.results_api_inputs()
+    res = FlowOUTrackingResult(T(d["flow"]), T(d["occl"]), T(d["sigma"]))
+    out = {}
+    out["warp_forward"] = res.warp_forward(torch.from_numpy(d["img"]))
+    out["warp_forward_masked"] = res.warp_forward(torch.from_numpy(d["img"]), mask=d["mask"], border=-1.0)
+    out["warp_forward_points"] = N(res.warp_forward_points(T(d["pts"])))
+    f, o, s_ = res.sample(T(d["pts"]))
+    out["sample_flow"], out["sample_occl"], out["sample_sigma"] = N(f), N(o), N(s_)
+    out["warp_backward"] = N(res.warp_backward(torch.from_numpy(d["img"]).permute(2, 0, 1).contiguous()))
+    out["invalid_mask"] = res.invalid_mask().numpy()
+    np.savez_compressed(OUT / "results_api.npz", **out)
+    print("results_api.npz", sum(v.nbytes for v in out.values()) / 1e3, "kB")
+
+
 def gen_tapvid():
     """TAP-Vid query samplers and metrics of the reference on seeded random tracks."""
     for name in ("mediapy", "PIL", "PIL.Image"):
@@ -263,9 +279,12 @@ def gen_tapvid():
 
 if __name__ == "__main__":
     assert REF.exists(), "the reference is only mounted in the build container"
-    which = sys.argv[1:] or ["ops", "flow", "seq", "e2e", "tapvid"]
-    if which == ["tapvid"]:
-        gen_tapvid()
+    which = sys.argv[1:] or ["ops", "flow", "seq", "e2e", "tapvid", "results"]
+    if set(which) <= {"tapvid", "results"}:
+        if "tapvid" in which:
+            gen_tapvid()
+        if "results" in which:
+            gen_results_api()
         sys.exit(0)
     model = build_reference_model()
     if "ops" in which:
@@ -278,3 +297,5 @@ if __name__ == "__main__":
         gen_e2e(model)
     if "tapvid" in which:
         gen_tapvid()
+    if "results" in which:
+        gen_results_api()
