@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--own-stream", action="store_true", help="run on a non-default stream (graph capture needs one)")
     a = ap.parse_args()
     conf = load_config(REPO / "configs" / "MFT_cfg.py")
     fc = conf.flow_config
@@ -38,6 +39,8 @@ def main():
     vid = SyntheticVideo(a.size, a.size, n_frames=8, seed=0)
     frames = [vid[i] for i in range(8)]
     lib = _lib.load()
+    if a.own_stream:
+        torch.cuda.set_stream(torch.cuda.Stream())
     for P in a.P:
         lefts = [(i, frames[i]) for i in range(P)]
         right = (7, frames[7])
