@@ -1,0 +1,107 @@
+"""Randomised parity of the HBM-bound kernels against the oracle over ragged shapes and awkward
+values (hypothesis, fixed seed database off): chain / select / chain_select, the correlation lookup and
+the convex upsampler.  Sizes are kept small -- the point is shape and value coverage (odd sizes, flows
+that leave the frame, ties, everything occluded, thresholds hit exactly), not throughput."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle import mft_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SET = settings(max_examples=25, deadline=None, derandomize=True,
+               suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+
+
+def rand_result(rng, H, W, spread):
+    flow = (rng.standard_normal((2, H, W)) * spread).astype(np.float32)
+    occl = rng.choice([0.0, 0.01, 0.02, 0.020000001, 0.5, 1.0], size=(1, H, W)).astype(np.float32)
+    sigma = rng.choice([0.25, 0.5, 0.5, 1.0, 3.0], size=(1, H, W)).astype(np.float32)     # ties on purpose
+    return flow, occl, sigma
+
+
+def dev3(t):
+    return tuple(torch.from_numpy(x).to(DEV) for x in t)
+
+
+def cpu3(t):
+    return tuple(torch.from_numpy(x) for x in t)
+
+
+@SET
+@given(H=st.integers(2, 41), W=st.integers(2, 53), K=st.integers(1, 7), seed=st.integers(0, 10_000),
+       spread=st.sampled_from([0.3, 3.0, 40.0]))
+def test_chain_select_random(H, W, K, seed, spread):
+    from mft_amd import ops
+    rng = np.random.default_rng(seed)
+    Ls = [rand_result(rng, H, W, spread) for _ in range(K)]
+    Rs = [rand_result(rng, H, W, spread) for _ in range(K)]
+    thr = 0.02
+    chained = [ops.chain(dev3(l), dev3(r)) for l, r in zip(Ls, Rs)]
+    for c, l, r in zip(chained, Ls, Rs):
+        ref = O.chain(cpu3(l), cpu3(r))
+        scale = 1.0 + spread
+        assert (c[0].cpu() - ref[0]).abs().max() < 2e-5 * scale
+        assert (c[1].cpu() - ref[1]).abs().max() < 1e-6 and (c[2].cpu() - ref[2]).abs().max() < 2e-6
+    # selection is exact given identical candidates, fused == unfused bit for bit
+    f1, o1, s1, c1 = ops.select(chained, thr, want_chosen=True)
+    of, oo, os_, oi = O.select([tuple(t.cpu() for t in c) for c in chained], thr)
+    assert torch.equal(c1.cpu().long(), oi) and torch.equal(f1.cpu(), of)
+    assert torch.equal(o1.cpu(), oo) and torch.equal(s1.cpu(), os_)
+    f2, o2, s2, c2 = ops.chain_select([dev3(l) for l in Ls], [dev3(r) for r in Rs], thr, want_chosen=True)
+    assert torch.equal(f1, f2) and torch.equal(o1, o2) and torch.equal(s1, s2) and torch.equal(c1, c2)
+
+
+@SET
+@given(h=st.integers(16, 25), w=st.integers(16, 29), P=st.integers(1, 3), seed=st.integers(0, 10_000),
+       spread=st.sampled_from([0.5, 6.0, 60.0]))
+def test_lookup_random(h, w, P, seed, spread):
+    # (h, w >= 16: a pyramid level of size 1 makes the reference's own coordinate normalisation divide by zero)
+    from mft_amd import ops
+    rng = np.random.default_rng(seed)
+    N = h * w
+    vol = torch.from_numpy(rng.standard_normal((P, N, h, w)).astype(np.float32))
+    ys, xs = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+    coords = np.stack([xs, ys])[None] + (rng.standard_normal((P, 2, h, w)) * spread).astype(np.float32)
+    coords[:, :, 0, 0] = np.array([xs[0, 0], ys[0, 0]])[None]          # exactly integral
+    coords = torch.from_numpy(coords.astype(np.float32))
+    got = []
+    levels = None
+    for p in range(P):
+        pyr = O.corr_pyramid(vol[p].reshape(N, 1, h, w))
+        ref = O.corr_lookup(pyr, coords[p:p + 1])                       # [1, 324, h, w]
+        got.append(ref[0].permute(1, 2, 0).reshape(N, 324))
+        lv = [l.reshape(N, -1) for l in pyr]
+        levels = [lv] if levels is None else levels + [lv]
+    lv_dev = [torch.stack([levels[p][l] for p in range(P)]).to(DEV).contiguous() for l in range(4)]
+    cpm = coords.permute(0, 2, 3, 1).reshape(P, N, 2).contiguous().to(DEV)
+    out = ops.corr_lookup(lv_dev, cpm, h, w).cpu()
+    ref = torch.stack(got)
+    assert (out.reshape(P, N, 324) - ref).abs().max() < 2e-4
+
+
+@SET
+@given(h=st.integers(2, 9), w=st.integers(2, 11), pads=st.tuples(st.integers(0, 3), st.integers(0, 4), st.integers(0, 3),
+                                                                 st.integers(0, 4)), seed=st.integers(0, 10_000))
+def test_convex_upsample_random(h, w, pads, seed):
+    from mft_amd import ops
+    rng = np.random.default_rng(seed)
+    N = h * w
+    flow = rng.standard_normal((1, 2, h, w)).astype(np.float32) * 3
+    ou = rng.standard_normal((1, 3, h, w)).astype(np.float32)
+    mask = rng.standard_normal((1, 576, h, w)).astype(np.float32) * 2
+    T = torch.from_numpy
+    pm = lambda x: T(x)[0].permute(1, 2, 0).reshape(N, -1).contiguous().to(DEV)     # noqa: E731
+    ou4 = torch.zeros(N, 4, device=DEV)
+    ou4[:, :3] = pm(ou)
+    f, o, s = ops.convex_upsample(pm(flow), ou4, pm(mask), 1, h, w, pads=pads)
+    pl, pr, pt, pb = pads
+    H0, W0 = 8 * h - pt - pb, 8 * w - pl - pr
+    rf = O.convex_upsample(T(flow), T(mask), 8.0)[0, :, pt:pt + H0, pl:pl + W0]
+    ro = torch.softmax(O.convex_upsample(T(ou[:, :2]), T(mask), 1.0), dim=1)[0, 1:2, pt:pt + H0, pl:pl + W0]
+    rs = torch.sqrt(torch.exp(O.convex_upsample(T(ou[:, 2:3]), T(mask), 1.0)))[0, :, pt:pt + H0, pl:pl + W0]
+    assert f.shape == (1, 2, H0, W0)
+    assert (f[0].cpu() - rf).abs().max() < 1e-4 and (o[0].cpu() - ro).abs().max() < 1e-5
+    assert ((s[0].cpu() - rs).abs() / rs).max() < 1e-4
