@@ -105,3 +105,37 @@ def test_convex_upsample_random(h, w, pads, seed):
     assert f.shape == (1, 2, H0, W0)
     assert (f[0].cpu() - rf).abs().max() < 1e-4 and (o[0].cpu() - ro).abs().max() < 1e-5
     assert ((s[0].cpu() - rs).abs() / rs).max() < 1e-4
+
+
+@settings(max_examples=120, deadline=None, derandomize=True,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(c0=st.integers(1, 96).map(lambda v: 4 * v), two=st.booleans(), c1=st.integers(1, 48).map(lambda v: 4 * v),
+       cout=st.integers(1, 300), k=st.sampled_from([(1, 1), (3, 3), (1, 5), (5, 1), (7, 1), (3, 1)]),
+       P=st.integers(1, 3), h=st.integers(3, 19), w=st.integers(3, 23),
+       act=st.sampled_from([None, "relu", "sigmoid", "tanh"]), with_addend=st.booleans(), seed=st.integers(0, 10_000))
+def test_conv2d_random(c0, two, c1, cout, k, P, h, w, act, with_addend, seed):
+    """The implicit-GEMM conv over ragged channel counts (K chunks partly zero-filled), one or two input
+    segments (the first a multiple of 32 channels, as the C ABI demands), every kernel shape of the update
+    block and encoders, all epilogues, M and N tails -- against torch's conv2d."""
+    import torch.nn.functional as F
+    from mft_amd import ops
+    kh, kw = k
+    if two:
+        c0 = max(32, (c0 // 32) * 32)
+    cin = c0 + (c1 if two else 0)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(P, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, kh, kw, generator=g) * (2.0 / (cin * kh * kw)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    lin = F.conv2d(x, wt, b, padding=(kh // 2, kw // 2))
+    add = torch.randn(P, cout, h, w, generator=g) if with_addend else None
+    if add is not None:
+        lin = lin + add
+    ref = {None: lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}[act](lin)
+    pm = lambda t: t.permute(0, 2, 3, 1).reshape(P * h * w, -1).contiguous().to(DEV)      # noqa: E731
+    xa = pm(x[:, :c0])
+    xb = pm(x[:, c0:]) if two else None
+    out = ops.conv2d(xa, ops.pack_conv_weight(wt.to(DEV)), b.to(DEV), P, h, w, cout, kh, kw, act=act, x2=xb,
+                     addend=pm(add) if add is not None else None)
+    got = out.reshape(P, h, w, cout).permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max() < 3e-5 * max(1.0, float(lin.abs().max()))
