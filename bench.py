@@ -229,11 +229,15 @@ def main():
     log(f"{n_frames} frames resident in HBM; host cores {host_cores()} (cpu_count {os.cpu_count()})")
     tracker, conf = build_tracker(args, sharded=world > 1)
     tracker.init(frames[0])
+    torch.cuda.synchronize()
+    t_ramp = time.perf_counter()
     for i in range(1, 1 + args.warmup):
         tracker.track(frames[i])
         if i in (1, 2, 8, 33):
             torch.cuda.synchronize()
             log(f"warm-up frame {i} done ({len(tracker.last_pairs)} pairs)")
+    torch.cuda.synchronize()
+    t_ramp = time.perf_counter() - t_ramp      # frames 1..W: 1 -> 7 flow pairs per frame, first-use set-up included
 
     def fence():
         torch.cuda.synchronize()
@@ -273,6 +277,8 @@ def main():
                                    f"{args.iters} RAFT iters, seeded synthetic weights (BASELINE.json configs[1])",
                        "parallelism": "single GPU" if world == 1 else f"delta-sharded x{world} + all-gather",
                        "frames_resident_in_hbm": True},
+            "ramp": {"frames": args.warmup, "fps": args.warmup / t_ramp,
+                     "note": "untimed warm-up, frames 1..W after init: the number of flow pairs grows from 1 to 7"},
         }
         dom = kernels.get("conv_gemm")
         if dom:
