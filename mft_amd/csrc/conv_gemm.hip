@@ -121,13 +121,22 @@ __device__ __forceinline__ void wait_vmcnt() {   // counted wait: leaves N LDS-D
 #endif
 constexpr int min_waves(int wave_tiles) { return wave_tiles == 1 ? MFTX_MINW1 : wave_tiles == 2 ? 3 : 2; }
 
-template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(64 * WM * WN, min_waves((BM / WM / 32) * (BN / WN / 32)))
+// MT = 32: each wave owns 32x32 outputs per MFMA tile (v_mfma_f32_32x32x2_f32).  MT = 16: 16x16 outputs
+// (v_mfma_f32_16x16x4_f32), for small M: a 32x64 workgroup tile still keeps 8 waves -- every SIMD -- busy,
+// so M x N splits into twice or four times as many workgroups when 64x64 tiles would leave CUs idle (one
+// flow pair per GPU: 64 row tiles; the N = 128 layers reach 128 of 256 CUs).  Fed the k sequence the 32x32x2
+// form consumes -- (k, k+4, k+1, k+5), (k+2, k+6, k+3, k+7) across its four lane groups -- the 16x16x4
+// form rounds bit-identically (both are sequential fmaf chains; tools/micro/mfma_order.hip), so the
+// tile choice still does not show in the results.
+template <int BM, int BN, int WM, int WN, int EPI, int MT = 32>
+__global__ __launch_bounds__(64 * WM * WN, min_waves((BM / WM / MT) * (BN / WN / MT)))
 void conv_gemm_kernel(ConvArgs p) {
     constexpr int NS = 2;                       // LDS ring of two K chunks (deeper rings were measured: no gain)
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int TM = BM / WM / MT, TN = BN / WN / MT;
+    constexpr int NR = MT == 32 ? 16 : 4;       // accumulator registers per MFMA tile
     constexpr int RPP = 8 * WM * WN;            // rows staged per pass: 8 per wave (one 1 KiB LDS-DMA)
-    constexpr int RA = BM / RPP, RB = BN / RPP;
+    constexpr int RA = (BM + RPP - 1) / RPP, RB = (BN + RPP - 1) / RPP;   // (a small tile leaves some waves without A rows)
+    static_assert(MT == 32 || MT == 16, "MFMA tile");
     static_assert(TM >= 1 && TN >= 1 && RA >= 1 && RB >= 1, "tile");
     static_assert(RPP % 16 == 0, "the chunk swizzle must not depend on the pass");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -168,9 +177,13 @@ void conv_gemm_kernel(ConvArgs p) {
     const int seg_cc = p.c1 > 0 ? p.c0 / BK : cpt;           // first chunk of segment 1
     const int rag_cc = (ctot % BK) ? cpt - 1 : cpt;          // the ragged chunk, if any
 
-    const int a_row0 = wm * TM * 32 + (lane & 31);
-    const int b_row0 = wn * TN * 32 + (lane & 31);
-    const int khalf = lane >> 5;             // lanes 0-31: chunk 2kk, lanes 32-63: chunk 2kk+1
+    const int a_row0 = wm * TM * MT + (lane & (MT - 1));
+    const int b_row0 = wn * TN * MT + (lane & (MT - 1));
+    // 16-byte chunk of an 8-wide k group this lane reads: MT = 32: lanes 0-31 chunk 2kk, lanes 32-63 chunk
+    // 2kk+1, all four values used; MT = 16: lane group g = lane >> 4 reads chunk 2kk + (g & 1) and uses
+    // elements (g >> 1) and (g >> 1) + 2 of it
+    const int khalf = MT == 32 ? lane >> 5 : (lane >> 4) & 1;
+    const bool hi_pair = MT == 16 && (lane >> 5) != 0;
     const int a_sw = (a_row0 >> 1) & 7, b_sw = (b_row0 >> 1) & 7;   // same for every 32-row step
     // fragment addresses of the four 8-wide k groups (the XOR swizzle is not additive: one each)
     const float *a_frag[4], *b_frag[4];
@@ -208,7 +221,7 @@ void conv_gemm_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         const int m = m0 + srow + RPP * i;
-        if (m < p.M) {
+        if (m < p.M && srow + RPP * i < BM) {
             const int img = m / hw;
             const int rem = m - img * hw;
             const int oy = rem / p.wd;
@@ -223,7 +236,7 @@ void conv_gemm_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         const int n = n0 + srow + RPP * i;
-        woff[i] = (n < p.w_rows) ? (unsigned)n * ktot_b + col4 * 4u : OOB;
+        woff[i] = (n < p.w_rows && srow + RPP * i < BN) ? (unsigned)n * ktot_b + col4 * 4u : OOB;
     }
     unsigned acell[RA];                      // this tap's source cell of each row, or OOB (conv halo / M tail)
     unsigned acur[RA];                       // byte offsets of the NEXT chunk to fetch, +128 B per chunk inside a run
@@ -255,45 +268,61 @@ void conv_gemm_kernel(ConvArgs p) {
         if (left == 0) next_run();
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            if (MFTX_ABLATE != 5 && (MFTX_ABLATE != 6 || cc % 5 == 0))
+            if (MFTX_ABLATE != 5 && (MFTX_ABLATE != 6 || cc % 5 == 0) && (BM % RPP == 0 || wid * 8 + RPP * i < BM))
                 buf_load_lds(rA, a_dst + buf * BM * LDK + RPP * i * LDK, acur[i]);
             acur[i] += BK * 4u;              // an OOB offset stays out of range
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            if (MFTX_ABLATE != 4) buf_load_lds(rW, b_dst + buf * BN * LDK + RPP * i * LDK, woff[i]);
+            if (MFTX_ABLATE != 4 && (BN % RPP == 0 || wid * 8 + RPP * i < BN))
+                buf_load_lds(rW, b_dst + buf * BN * LDK + RPP * i * LDK, woff[i]);
             woff[i] += BK * 4u;
         }
         --left;
         if (++cc == cpt) { cc = 0; ++tap; }
     };
 
-    f32x16 acc[TM][TN];
+    typedef float acc_t __attribute__((ext_vector_type(NR)));
+    acc_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < NR; ++r) acc[i][j][r] = 0.f;
 
     f32x4 fa[2][TM], fb[2][TN];              // register double buffer of MFMA fragments
     auto read_frags = [&](int buf, int kk, int slot) {
         if (MFTX_ABLATE == 3) return;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-            fa[slot][i] = *reinterpret_cast<const f32x4 *>(a_frag[kk] + buf * BM * LDK + 32 * i * LDK);
+            fa[slot][i] = *reinterpret_cast<const f32x4 *>(a_frag[kk] + buf * BM * LDK + MT * i * LDK);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-            fb[slot][j] = *reinterpret_cast<const f32x4 *>(b_frag[kk] + buf * BN * LDK + 32 * j * LDK);
+            fb[slot][j] = *reinterpret_cast<const f32x4 *>(b_frag[kk] + buf * BN * LDK + MT * j * LDK);
     };
     auto mma = [&](int slot) {
+        if constexpr (MT == 32) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i][s], fb[slot][j][s], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][i][s], fb[slot][j][s], acc[i][j], 0, 0, 0);
+        } else {
+            // two instructions per 8-wide k group: lane groups (0,1,2,3) supply k = (0,4,1,5), then (2,6,3,7)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float a = hi_pair ? fa[slot][i][2 * s + 1] : fa[slot][i][2 * s];
+                        const float b = hi_pair ? fb[slot][j][2 * s + 1] : fb[slot][j][2 * s];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i][j], 0, 0, 0);
+                    }
+        }
     };
     // One K chunk out of ring slot `buf` (compile-time after unrolling: every LDS address is a register
     // plus an immediate).  The other slot was released by the barrier of the previous step, so its
@@ -337,7 +366,13 @@ void conv_gemm_kernel(ConvArgs p) {
 
     // prologue: chunks 0 and 1 in flight, chunk 0 landed, first fragments -> slot 0
     fetch(0);
-    if (T > 1) { fetch(1); wait_vmcnt<RA + RB>(); } else { wait_vmcnt<0>(); }
+    if (T > 1) {
+        fetch(1);
+        // chunk 0 landed, chunk 1 may fly -- counted per lane, so only when every wave issues all RA + RB loads
+        if constexpr (BM % RPP == 0 && BN % RPP == 0) wait_vmcnt<RA + RB>(); else wait_vmcnt<0>();
+    } else {
+        wait_vmcnt<0>();
+    }
     block_barrier();
     read_frags(0, 0, 0);
     int it = 0;
@@ -362,21 +397,23 @@ void conv_gemm_kernel(ConvArgs p) {
     // stores.  Interleaved per element, the compiler must assume that a store aliases the next
     // element's loads and serialises 16 x (load - wait - store - wait): ~10 us per tile, fully
     // exposed when a CU has a single tile (one flow pair per GPU).
-    const int col_l = lane & 31;
-    const int row_h = 4 * (lane >> 5);
+    // MT = 32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), r < 16;  MT = 16: col = lane & 15, row = 4 (lane >> 4) + r, r < 4
+    const int col_l = lane & (MT - 1);
+    const int row_h = MT == 32 ? 4 * (lane >> 5) : 4 * (lane >> 4);
+    auto row_of = [](int r) { return MT == 32 ? (r & 3) + 8 * (r >> 2) : r; };
     const bool pre_add = p.addend != nullptr && p.residual_mode == 0;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * TN * 32 + j * 32 + col_l;
+        const int n = n0 + wn * TN * MT + j * MT + col_l;
         const bool n_ok = n < p.N;
         const float bias = (p.bias != nullptr && n_ok) ? p.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            float add[16], aux0[16], aux1[16];       // addend; z / h (GRU)
-            const int mb = m0 + wm * TM * 32 + i * 32 + row_h;
+            float add[NR], aux0[NR], aux1[NR];       // addend; z / h (GRU)
+            const int mb = m0 + wm * TM * MT + i * MT + row_h;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
+            for (int r = 0; r < NR; ++r) {
+                const int m = mb + row_of(r);
                 add[r] = aux0[r] = aux1[r] = 0.f;
                 if (!n_ok || m >= p.M) continue;
                 if (pre_add || p.residual_mode == 1) add[r] = p.addend[(long long)m * p.ld_addend + n];
@@ -388,8 +425,8 @@ void conv_gemm_kernel(ConvArgs p) {
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = mb + (r & 3) + 8 * (r >> 2);
+            for (int r = 0; r < NR; ++r) {
+                const long long m = mb + row_of(r);
                 if (!n_ok || m >= p.M) continue;
                 float s = acc[i][j][r] + bias;
                 if (pre_add) s += add[r];
@@ -426,11 +463,11 @@ static int num_cus() {
     return n;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int MT = 32>
 static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) {
     constexpr size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
     static bool attr_set = false;
-    auto kern = conv_gemm_kernel<BM, BN, WM, WN, EPI>;
+    auto kern = conv_gemm_kernel<BM, BN, WM, WN, EPI, MT>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -461,6 +498,7 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
         case 0: return launch_cfg<128, 128, 2, 2, EPI>(a, batch, s, cat);
         case 1: return launch_cfg<128, 64, 2, 2, EPI>(a, batch, s, cat);
         case 2: return launch_cfg<64, 64, 2, 2, EPI>(a, batch, s, cat);
+        case 5: return launch_cfg<32, 32, 2, 2, EPI, 16>(a, batch, s, cat);    // 4 waves of 16x16: four times the workgroups of 64x64
         default: return launch_cfg<128, 32, 4, 1, EPI>(a, batch, s, cat);
     }
 }
@@ -468,7 +506,7 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
 static int pick_tile(const ConvArgs &a, int batch) {
     // debug/tuning override: MFTX_CONV_TILE=0..3
     static const int forced = [] { const char *e = getenv("MFTX_CONV_TILE"); return e ? atoi(e) : -1; }();
-    if (forced >= 0 && forced <= 3) return forced;
+    if ((forced >= 0 && forced <= 3) || forced == 5) return forced;
     // Measured on MI355X (tools/bench_conv.py, M = 7 x 4096 and 4096): the 64x64
     // tile (4 workgroups per CU) wins or ties on every layer -- 7 x 2^k rows tile
     // the 256 CUs more evenly in small tiles than bigger tiles save on operand
@@ -479,6 +517,14 @@ static int pick_tile(const ConvArgs &a, int batch) {
     (void)batch;
     if (a.N <= 32) return 3;
     if (a.N > 128 && a.N % 128 == 64 && a.M >= 16384) return 1;   // at small M the extra tiles of 64x64 win
+    // Very small M x N (one flow pair per GPU, N = 64: 64 tiles of 64x64 for 256 CUs): 32x32 tiles of four
+    // 16x16-MFMA waves spread the same outputs over four times as many workgroups -- same results, bit for
+    // bit.  Measured at M = 4096 (tools/bench_conv.py): N = 64 25.5 -> 18.9 us; already at N = 128 the
+    // 16x16 form loses (27.5 -> 29 us; a 32x64 tile of 8 waves 47.6 -> 81 us at N = 192): per MFMA cycle it
+    // needs four times the LDS fragment traffic and twice the LDS-DMA pieces of the 32x32 form.
+    static const bool small_off = getenv("MFTX_CONV_NO16") != nullptr;
+    const long long t64 = (long long)cdiv(a.M, 64) * cdiv(a.N, 64);
+    if (!small_off && t64 * 4 <= num_cus()) return 5;
     return 2;
 }
 

@@ -406,3 +406,23 @@ def test_raft_engine_argument_errors(ops_mod, weights_np):
     # the happy path still works after the failures
     flow, occl, sigma = eng.refine(f, f, n, n, h, w, 2)
     assert bool(torch.isfinite(flow).all()) and float(occl.min()) >= 0 and float(sigma.min()) >= 0
+
+
+def test_conv_tile_shapes_bitwise(tmp_path):
+    """Every tile shape -- 128x128, 128x64, 64x64 on v_mfma_f32_32x32x2_f32 and the 32x32 tile of
+    v_mfma_f32_16x16x4_f32 waves used for very small M x N -- gives the same bits: the reduction order
+    is a property of the kernel, not of the tiling (the 1-vs-N GPU equality relies on it)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    worker = Path(__file__).with_name("tile_worker.py")
+    outs = {}
+    for tile in (0, 1, 2, 5):
+        f = tmp_path / f"t{tile}.npy"
+        env = dict(os.environ, MFTX_CONV_TILE=str(tile))
+        res = subprocess.run([sys.executable, str(worker), str(f)], env=env, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs[tile] = np.load(f)
+    for tile in (0, 1, 5):
+        assert np.array_equal(outs[tile], outs[2]), tile
