@@ -4,6 +4,8 @@
 // host round trips, batched over P image pairs (M = P*h*w cells).
 #include "common.h"
 #include "profile.h"
+#include "motion_front.h"
+#include <cstdlib>
 #include <new>
 
 namespace mftx {
@@ -29,76 +31,27 @@ __global__ void init_state_kernel(const float *__restrict__ net, const float *__
     }
 }
 
-// convf1: 7x7 conv over the 2-channel flow (= coords1 - grid), 2 -> 128, ReLU
-// (core/update.py:147,154).  K = 98 is too thin for MFMA: direct VALU kernel,
-// one thread per output channel, 16 cells of one row per block, flow patch in LDS.
-// Also drops flow into channels 382..383 of hx (motion_features' tail,
-// core/update.py:160).
-constexpr int F1_CELLS = 16;
-__global__ __launch_bounds__(128) void convf1_kernel(const float *__restrict__ coords1,
-                                                     const float *__restrict__ w98,   // [98][128]
-                                                     const float *__restrict__ bias, float *__restrict__ flo1,
-                                                     float *__restrict__ hx, int h, int w, int strips_per_row) {
-    // flow patch of the strip: 7 rows x (16 + 6) cells x (fx, fy), rows padded to 48 floats
-    __shared__ __attribute__((aligned(16))) float patch[7][48];
-    const int strip = blockIdx.x % strips_per_row;
-    const int rowid = blockIdx.x / strips_per_row;   // img*h + y
-    const int y = rowid % h;
-    const long long img_base = (long long)(rowid / h) * h * w;
-    const int x0 = strip * F1_CELLS;
-    for (int i = threadIdx.x; i < 7 * (F1_CELLS + 6); i += blockDim.x) {
-        const int r = i / (F1_CELLS + 6), c = i - r * (F1_CELLS + 6);
-        const int yy = y + r - 3, xx = x0 + c - 3;
-        float fx = 0.f, fy = 0.f;
-        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
-            const long long cell = img_base + (long long)yy * w + xx;
-            fx = coords1[2 * cell] - (float)xx;
-            fy = coords1[2 * cell + 1] - (float)yy;
-        }
-        patch[r][2 * c] = fx;
-        patch[r][2 * c + 1] = fy;
-    }
-    __syncthreads();
-    const int co = threadIdx.x;
-    float acc[F1_CELLS];
-    const float b = bias[co];
-#pragma unroll
-    for (int t = 0; t < F1_CELLS; ++t) acc[t] = b;
-    // this output channel's 14 weights of filter row ky are loaded one row ahead (register double
-    // buffer): taken inside the row loop their L2 latency showed 7 times per strip
-    float wc[14], wn[14];
-#pragma unroll
-    for (int q = 0; q < 14; ++q) wc[q] = w98[q * 128 + co];
-#pragma unroll 1
-    for (int ky = 0; ky < 7; ++ky) {
-        const int kyn = ky < 6 ? ky + 1 : 6;
-#pragma unroll
-        for (int q = 0; q < 14; ++q) wn[q] = w98[(kyn * 14 + q) * 128 + co];
-        // the whole patch row goes to registers once (11 broadcast ds_read_b128), then 7 x 16 x 2 FMAs
-        float row[44];
-#pragma unroll
-        for (int q = 0; q < 11; ++q) {
-            const float4 v = *reinterpret_cast<const float4 *>(&patch[ky][4 * q]);
-            row[4 * q] = v.x; row[4 * q + 1] = v.y; row[4 * q + 2] = v.z; row[4 * q + 3] = v.w;
-        }
-#pragma unroll
-        for (int kx = 0; kx < 7; ++kx) {
-            const float w0 = wc[2 * kx], w1 = wc[2 * kx + 1];
-#pragma unroll
-            for (int t = 0; t < F1_CELLS; ++t)
-                acc[t] += w0 * row[2 * (t + kx)] + w1 * row[2 * (t + kx) + 1];
-        }
-#pragma unroll
-        for (int q = 0; q < 14; ++q) wc[q] = wn[q];
-    }
-#pragma unroll
-    for (int t = 0; t < F1_CELLS; ++t) {
-        const int x = x0 + t;
-        if (x < w) {
-            const long long cell = img_base + (long long)y * w + x;
-            flo1[cell * 128 + co] = fmaxf(acc[t], 0.f);
-            if (co < 2) hx[cell * 384 + 382 + co] = patch[3][2 * (t + 3) + co];
-        }
+// two strips per 256-thread block
+__global__ __launch_bounds__(256) void convf1_kernel(ConvF1Args q) {
+    __shared__ __attribute__((aligned(16))) float patch[2][7][48];
+    const int half = threadIdx.x >> 7;
+    convf1_strip(q, blockIdx.x * 2 + half, patch[half], threadIdx.x & 127);
+}
+
+// Lookup and convf1 read nothing but coords1 and the pyramid / the weights, and they stress different
+// parts of the chip (HBM gathers vs VALU): one launch carries both, block types interleaved in the ratio
+// of their counts so that every CU holds both kinds at once.  Used by the refinement loop; the per-kernel
+// timing pass and the per-op export launch them separately.
+__global__ __launch_bounds__(256) void lookup_convf1_kernel(LookupArgs lp, ConvF1Args q, int lookup_blocks, int f1_blocks) {
+    __shared__ __attribute__((aligned(16))) float patch[2][7][48];
+    const int total = lookup_blocks + f1_blocks;
+    const int b = blockIdx.x;
+    const int f_lo = (int)((long long)b * f1_blocks / total), f_hi = (int)((long long)(b + 1) * f1_blocks / total);
+    if (f_hi > f_lo) {
+        const int half = threadIdx.x >> 7;
+        convf1_strip(q, f_lo * 2 + half, patch[half], threadIdx.x & 127);
+    } else {
+        lookup_block_body<2>(lp, b - f_lo, lookup_blocks);
     }
 }
 
@@ -281,16 +234,27 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     const int strips = cdiv(w, F1_CELLS);
     for (int it = 0; it < iters; ++it) {
         const bool last = (it == iters - 1);
-        TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, 324, s));
+        // correlation lookup and the first layer of the flow branch: both need only coords1 -> one launch
+        // (separately when every kernel is being timed, or with MFTX_RAFT_NOFUSE)
+        {
+            const ConvF1Args f1{ws.coords1, W[W_CONVF1], W[B_CONVF1], ws.flo1, ws.hx, h, w, strips, P * h * strips};
+            const int f1_blocks = cdiv(f1.n_strips, 2);
+            static const bool nofuse = getenv("MFTX_RAFT_NOFUSE") != nullptr;
+            if (prof_enabled() || nofuse) {
+                TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, 324, s));
+                ProfScope prof(PC_CONVF1, s, 2.0 * M * 128 * 98);
+                hipLaunchKernelGGL(convf1_kernel, dim3(f1_blocks), dim3(256), 0, s, f1);
+            } else {
+                const LookupArgs la = make_lookup_args(lv, ws.coords1, P, h, w, ws.corr, 324);
+                const int lookup_blocks = cdiv(cdiv(la.cells, 2), LK_WAVES);
+                hipLaunchKernelGGL(lookup_convf1_kernel, dim3(lookup_blocks + f1_blocks), dim3(256), 0, s, la, f1,
+                                   lookup_blocks, f1_blocks);
+            }
+            TRY(check_launch("lookup + convf1"));
+        }
         // motion encoder (core/update.py:152-160)
         TRY(launch_conv(conv_desc(ws.corr, 324, 324, nullptr, 0, 0, W[W_CONVC1], W[B_CONVC1], ws.cor1, 256, P, h, w, 256, 1, 1, 1), s));
         TRY(launch_conv(conv_desc(ws.cor1, 256, 256, nullptr, 0, 0, W[W_CONVC2], W[B_CONVC2], ws.corflo, 256, P, h, w, 192, 3, 3, 1), s));
-        {
-            ProfScope prof(PC_CONVF1, s, 2.0 * M * 128 * 98);
-            hipLaunchKernelGGL(convf1_kernel, dim3(P * h * strips), dim3(128), 0, s, ws.coords1, W[W_CONVF1],
-                               W[B_CONVF1], ws.flo1, ws.hx, h, w, strips);
-        }
-        TRY(check_launch("convf1"));
         TRY(launch_conv(conv_desc(ws.flo1, 128, 128, nullptr, 0, 0, W[W_CONVF2], W[B_CONVF2], ws.corflo + 192, 256, P, h, w, 64, 3, 3, 1), s));
         TRY(launch_conv(conv_desc(ws.corflo, 256, 256, nullptr, 0, 0, W[W_CONV], W[B_CONV], ws.hx + 256, 384, P, h, w, 126, 3, 3, 1), s));
         // SepConvGRU (core/update.py:108-123): horizontal 1x5 then vertical 5x1
