@@ -35,6 +35,7 @@ inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 
 // ---- kernel launchers shared between the per-op exports and the RAFT engine
 int launch_conv(const mftx_conv_desc &d, hipStream_t s);
+int launch_conv_pair(const mftx_conv_desc &a, const mftx_conv_desc &b, hipStream_t s);   // two independent ReLU convs, one launch
 // conv whose epilogue is a GRU gate (see conv_gemm.hip)
 struct GruEpilogue {
     int mode;          // 1: z|r gates  2: candidate + blend

@@ -254,8 +254,14 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         }
         // motion encoder (core/update.py:152-160)
         TRY(launch_conv(conv_desc(ws.corr, 324, 324, nullptr, 0, 0, W[W_CONVC1], W[B_CONVC1], ws.cor1, 256, P, h, w, 256, 1, 1, 1), s));
-        TRY(launch_conv(conv_desc(ws.cor1, 256, 256, nullptr, 0, 0, W[W_CONVC2], W[B_CONVC2], ws.corflo, 256, P, h, w, 192, 3, 3, 1), s));
-        TRY(launch_conv(conv_desc(ws.flo1, 128, 128, nullptr, 0, 0, W[W_CONVF2], W[B_CONVF2], ws.corflo + 192, 256, P, h, w, 64, 3, 3, 1), s));
+        // second layers of the two branches, independent of each other: one launch (core/update.py:153,155)
+        {
+            static const bool nopair = getenv("MFTX_RAFT_NOPAIR") != nullptr;
+            const mftx_conv_desc c2 = conv_desc(ws.cor1, 256, 256, nullptr, 0, 0, W[W_CONVC2], W[B_CONVC2], ws.corflo, 256, P, h, w, 192, 3, 3, 1);
+            const mftx_conv_desc f2 = conv_desc(ws.flo1, 128, 128, nullptr, 0, 0, W[W_CONVF2], W[B_CONVF2], ws.corflo + 192, 256, P, h, w, 64, 3, 3, 1);
+            if (nopair) { TRY(launch_conv(c2, s)); TRY(launch_conv(f2, s)); }
+            else TRY(launch_conv_pair(c2, f2, s));
+        }
         TRY(launch_conv(conv_desc(ws.corflo, 256, 256, nullptr, 0, 0, W[W_CONV], W[B_CONV], ws.hx + 256, 384, P, h, w, 126, 3, 3, 1), s));
         // SepConvGRU (core/update.py:108-123): horizontal 1x5 then vertical 5x1
         for (int pass = 0; pass < 2; ++pass) {
