@@ -117,7 +117,8 @@ def profiled_traffic():
         if line.startswith("#") or "conv_gemm_kernel" not in line:
             continue
         name, launches, _fetch, fetch_x2, write = line.rsplit(",", 4)     # the kernel name contains commas
-        if "<128, 128," in name or name.rstrip().endswith(", 4>"):         # correlation volume (EPI_VOLUME; 128x128 before r1h)
+        import re
+        if "<128, 128," in name or re.search(r"<\d+, \d+, \d+, \d+, 4(, \d+)?>", name):   # correlation volume (EPI_VOLUME = 4; 128x128 before r1h)
             continue
         tot += float(launches) * (float(fetch_x2) + float(write)) * 1e6
         n += float(launches)
