@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
 """Benchmark of the MFT hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 40
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...                      (re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one MFT.track() of a 512x512 frame with the reference configuration
-(deltas {inf,1,2,4,8,16,32}, 12 RAFT iterations, occlusion threshold 0.02;
-BASELINE.json configs[1]) on a seeded synthetic video with seeded synthetic
-weights (no dataset / checkpoint in this environment).  Warm-up defaults to 40
-frames so that all seven deltas are live in the timed region.  Frames are
-resident in HBM before the timed region and results stay on the device; the
-PCIe-inclusive rate (numpy frames in, CPU results out) is reported separately
-as "host_io_fps".  For N > 1 the per-frame flow deltas are sharded over ranks
-(one RCCL all-gather per frame), i.e. strong scaling of one video.
+A "step" is one tracked 512x512 frame with the reference configuration (deltas {inf,1,2,4,8,16,32},
+12 RAFT iterations, occlusion threshold 0.02; BASELINE.json configs[1]) on a seeded synthetic video
+with seeded synthetic weights (no dataset / checkpoint in this environment).
+
+Steady state.  The seven deltas are all live only from frame 33 on (MFT/MFT.py:74-91: delta 32 reaches
+back to frame 1 there), so whatever --warmup is, an UNTIMED pre-roll tracks frames until every warm-up
+and timed frame has 7 flow pairs; the pair count is recorded inside the timed loop (min / mean / max in
+`config.workload` and `pairs_per_frame`) and the run fails rather than mislabel a ramp as steady state.
+
+Frames are resident in HBM before the timed region and results stay on the device; the PCIe-inclusive
+rate (numpy frames in, CPU results out) is reported separately as "host_io_fps".  For N > 1 the
+(frame, delta) flow computations of a look-ahead window of frames are sharded over the ranks
+(mft_amd/dist.py): strong scaling of one video, `value` = frames of that one video per second.
 
 Rank 0 prints ONE JSON line (see DESIGN.md section "Measurement").
 """
@@ -21,6 +26,9 @@ import argparse
 import ctypes as C
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -39,6 +47,8 @@ CATS = ["corr_volume_gemm", "corr_pool", "corr_lookup", "conv_gemm", "convf1", "
         "chain_select", "conv_small_n", "encoder_instnorm"]
 FLOP_CATS = {0, 3, 4, 8}
 VALU_CATS = {4, 8}
+FULL_PAIRS = 7                  # flow pairs per frame once every delta is live
+FIRST_FULL_FRAME = 33           # first frame index with FULL_PAIRS pairs (forward tracking from frame 0)
 _T0 = time.time()
 
 
@@ -55,35 +65,40 @@ def host_cores():
 
 
 def oracle_threads():
-    """Threads for the CPU oracle legs: all host cores up to 32 (the torch CPU ops
-    of this small-batch workload stop scaling well before that)."""
+    """Threads for the CPU oracle legs.  The oracle is torch CPU ops on one 512x512 pair at a time
+    (M = 4096 rows per GEMM): it stops scaling long before a 256-core host is full -- the sweep in
+    profiles/r2_cpu_thread_sweep.txt (tools/cpu_thread_sweep.py) is fastest at 32-64 threads -- so the
+    default is min(host cores, 32); MFT_ORACLE_THREADS overrides."""
     return max(1, min(host_cores(), int(os.environ.get("MFT_ORACLE_THREADS", "32"))))
 
 
 def build_tracker(args, sharded):
     from mft_amd.config import load_config
     conf = load_config(REPO / "configs" / "MFT_cfg.py")
-    conf.flow_config.synthetic_weights_seed = 0
+    conf.flow_config.model = None                   # no checkpoint in this environment: explicit opt-in to
+    conf.flow_config.synthetic_weights_seed = 0     # seeded synthetic weights
     conf.flow_config.flow_iters = args.iters
     conf.flow_config.async_encode = not args.sync_encode
-    conf.flow_config.torch_encoders = args.torch_encoders
     conf.keep_result_on_device = True
     conf.delta_sharding = sharded
     return conf.tracker_class(conf), conf
 
 
 def profile_pass(tracker, frames, first, steps):
-    """Same steps again with HIP-event brackets around every kernel launch.  Frames are encoded on the
-    main stream here so that every kernel is timed alone (in the timed region the encoders of frame
-    t+1 overlap frame t on a side stream, which would stretch the bracketed intervals)."""
+    """Same kind of steps again (steady state, 7 pairs each) with HIP-event brackets around every kernel
+    launch.  Frames are encoded on the main stream here so that every kernel is timed alone (in the
+    timed region the encoders of frame t+1 overlap frame t on a side stream, which would stretch the
+    bracketed intervals)."""
     from mft_amd import _lib
     lib = _lib.load()
     enc_stream = getattr(tracker.flower, "_enc_stream", None)
     tracker.flower._enc_stream = None
     torch.cuda.synchronize()
     lib.mftx_profile_begin()
+    pairs = []
     for i in range(first, first + steps):
         tracker.track(frames[i])
+        pairs.append(len(tracker.last_pairs))
     tracker.flower._enc_stream = enc_stream
     n = len(CATS)
     ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
@@ -103,7 +118,7 @@ def profile_pass(tracker, frames, first, steps):
         if "achieved" in d:
             d["frac"] = d["achieved"] / d["peak"]
         out[name] = d
-    return out
+    return out, pairs
 
 
 def profiled_traffic():
@@ -114,12 +129,11 @@ def profiled_traffic():
         return None, None
     tot = n = 0.0
     for line in files[-1].read_text().splitlines():
-        if line.startswith("#") or "conv_gemm_kernel" not in line:
+        if line.startswith("#") or "conv_gemm" not in line:
             continue
         name, launches, _fetch, fetch_x2, write = line.rsplit(",", 4)     # the kernel name contains commas
-        import re
-        if "<128, 128," in name or re.search(r"<\d+, \d+, \d+, \d+, 4(, \d+)?>", name):   # correlation volume (EPI_VOLUME = 4; 128x128 before r1h)
-            continue
+        if "volume" in name or "<128, 128," in name or re.search(r"<\d+, \d+, \d+, \d+, 4(, \d+)?>", name):
+            continue                                 # the correlation volume GEMM is its own category
         tot += float(launches) * (float(fetch_x2) + float(write)) * 1e6
         n += float(launches)
     return (tot / n if n else None), files[-1].name
@@ -147,12 +161,13 @@ def cpu_baseline(args, vid):
         t0 = time.perf_counter()
         for i in range(33, 33 + n):
             meta = tr.track(vid[i])
-            assert len(meta.pairs) == 7
+            assert len(meta.pairs) == FULL_PAIRS
             first_meta = first_meta or meta
         dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": n / dt, "unit": "frames/s", "cores": cores, "host_cores": host_cores(), "kind": "port",
             "sample": f"{n} steady-state frames (7 flow pairs x {args.iters} iters + chain + select each) of the same "
-                      f"{H}x{W} synthetic video; oracle/mft_oracle.py on torch CPU ops, {dt:.1f} s",
+                      f"{H}x{W} synthetic video; oracle/mft_oracle.py on torch CPU ops, {cores} threads "
+                      f"(thread sweep: profiles/r2_cpu_thread_sweep.txt), {dt:.1f} s",
             "s_per_frame": dt / n,
             "stage_s_per_frame": {k: v / n for k, v in stages.items()}}, first_meta
 
@@ -193,127 +208,180 @@ def flow_epe_vs_oracle(args, tracker, vid):
             "sigma_max_rel": ((extra["sigma"].cpu() - ref[2]).abs() / ref[2]).max().item()}
 
 
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` started as ONE process: run the same command as N ranks."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    log(f"--gpus {n} without a launcher: re-executing as {' '.join(cmd[1:8])} ...")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def run_frames(tracker, frames, first, count, window):
+    """Track frames[first : first + count]; with `window` > 1 in look-ahead windows (multi-GPU).
+    -> pairs per frame."""
+    pairs = []
+    if window <= 1:
+        for i in range(first, first + count):
+            tracker.track(frames[i])
+            pairs.append(len(tracker.last_pairs))
+        return pairs
+    i = first
+    while i < first + count:
+        n = min(window, first + count - i)
+        tracker.track_window(frames[i: i + n])
+        pairs += [len(tracker._plan(k)) for k in range(i, i + n)]
+        i += n
+    return pairs
+
+
 def main():
     import faulthandler
     faulthandler.dump_traceback_later(240, repeat=True, file=sys.stderr)   # show where a stuck run is stuck
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--iters", type=int, default=12)
-    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--window", type=int, default=0,
+                    help="multi-GPU look-ahead window in frames (0 = 3 x gpus; 1 = per-frame delta sharding)")
+    ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size EPE check against the CPU oracle")
+    ap.add_argument("--no-host-io", action="store_true")
     ap.add_argument("--sync-encode", action="store_true", help="encode frames on the main stream")
-    ap.add_argument("--torch-encoders", action="store_true", help="PyTorch-ROCm/MIOpen encoders instead of the native ones")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the multi-GPU code path (windows, RCCL all-gathers) even with one rank (testing)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(respawn_under_torchrun(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                         f"--nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
+        if "MASTER_ADDR" not in os.environ:          # --force-sharded started without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    window = (args.window if args.window > 0 else 3 * world) if sharded else 1
 
     from mft_amd.synth import SyntheticVideo
-    n_frames = 1 + args.warmup + 2 * args.steps + 8
+    preroll = max(0, FIRST_FULL_FRAME - 1 - args.warmup)          # untimed: frames 1 .. preroll
+    n_io = 0 if (args.no_host_io or world > 1 or args.force_sharded) else max(4, args.steps // 2)
+    n_prof = 0 if args.no_profile else args.steps
+    n_frames = 1 + preroll + args.warmup + args.steps + n_prof + n_io
     vid = SyntheticVideo(args.height, args.width, n_frames=max(n_frames, 48), seed=0)
     host_frames = [vid[i] for i in range(n_frames)]
     frames = [torch.from_numpy(f).cuda() for f in host_frames]      # resident in HBM
 
-    log(f"{n_frames} frames resident in HBM; host cores {host_cores()} (cpu_count {os.cpu_count()})")
-    tracker, conf = build_tracker(args, sharded=world > 1)
+    log(f"{n_frames} frames resident in HBM; host cores {host_cores()} (cpu_count {os.cpu_count()}); "
+        f"pre-roll {preroll} + warm-up {args.warmup} + {args.steps} timed frames")
+    tracker, conf = build_tracker(args, sharded=("force" if args.force_sharded and world == 1 else sharded))
     tracker.init(frames[0])
     torch.cuda.synchronize()
     t_ramp = time.perf_counter()
-    for i in range(1, 1 + args.warmup):
-        tracker.track(frames[i])
-        if i in (1, 2, 8, 33):
-            torch.cuda.synchronize()
-            log(f"warm-up frame {i} done ({len(tracker.last_pairs)} pairs)")
+    ramp_pairs = run_frames(tracker, frames, 1, preroll, window)
     torch.cuda.synchronize()
-    t_ramp = time.perf_counter() - t_ramp      # frames 1..W: 1 -> 7 flow pairs per frame, first-use set-up included
+    t_ramp = time.perf_counter() - t_ramp      # frames 1..preroll: 1 -> 7 flow pairs per frame, first-use set-up included
+    warm_pairs = run_frames(tracker, frames, 1 + preroll, args.warmup, window)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize()
 
-    first = 1 + args.warmup
+    first = 1 + preroll + args.warmup
     fence()
     t0 = time.perf_counter()
-    for i in range(first, first + args.steps):
-        tracker.track(frames[i])
+    timed_pairs = run_frames(tracker, frames, first, args.steps, window)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    log(f"timed region: {args.steps} steps in {dt:.3f} s, pairs/frame min {min(timed_pairs)} max {max(timed_pairs)}")
+    if min(timed_pairs + warm_pairs) != FULL_PAIRS or max(timed_pairs) != FULL_PAIRS:
+        raise SystemExit(f"timed region is not the 7-pair steady state: warm-up {warm_pairs}, timed {timed_pairs}")
 
-    log(f"timed region: {args.steps} steps in {dt:.3f} s")
-    kernels = {}
-    if not args.no_profile:
-        kernels = profile_pass(tracker, frames, first + args.steps, args.steps)
+    kernels, prof_pairs = {}, []
+    if n_prof and not sharded:
+        kernels, prof_pairs = profile_pass(tracker, frames, first + args.steps, n_prof)
         torch.cuda.synchronize()
+        if min(prof_pairs) != FULL_PAIRS:
+            raise SystemExit(f"profile pass left the steady state: {prof_pairs}")
 
     result = None
     if rank == 0:
         fps = args.steps / dt
-        K = len(tracker.last_pairs)
         result = {
             "metric": "tracked frames/sec at 512x512, 12 RAFT iters; flow EPE vs reference",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"MFT.track on synthetic {args.height}x{args.width} video, deltas "
-                                   f"[inf,1,2,4,8,16,32] ({K} flow pairs/frame in the timed region), "
-                                   f"{args.iters} RAFT iters, seeded synthetic weights (BASELINE.json configs[1])",
-                       "parallelism": "single GPU" if world == 1 else f"delta-sharded x{world} + all-gather",
-                       "frames_resident_in_hbm": True},
-            "ramp": {"frames": args.warmup, "fps": args.warmup / t_ramp,
-                     "note": "untimed warm-up, frames 1..W after init: the number of flow pairs grows from 1 to 7"},
+                                   f"[inf,1,2,4,8,16,32], {min(timed_pairs)}/{np.mean(timed_pairs):.2f}/{max(timed_pairs)} "
+                                   f"(min/mean/max) flow pairs per timed frame, {args.iters} RAFT iters, seeded "
+                                   f"synthetic weights (BASELINE.json configs[1])",
+                       "parallelism": "single GPU" if not sharded else
+                       f"(frame, delta) units of a {window}-frame look-ahead window sharded x{world}, "
+                       f"feature + FlowOU all-gather over RCCL, replicated chain/select",
+                       "frames_resident_in_hbm": True, "preroll_frames": preroll,
+                       "first_timed_frame": first},
+            "pairs_per_frame": {"warmup": warm_pairs, "timed_min": min(timed_pairs), "timed_max": max(timed_pairs),
+                                "timed_mean": float(np.mean(timed_pairs)), "profile_pass_min": min(prof_pairs, default=None)},
+            "ramp": {"frames": preroll, "fps": (preroll / t_ramp) if preroll else None,
+                     "pairs": ramp_pairs,
+                     "note": "untimed pre-roll, frames 1..P after init: the number of flow pairs grows from 1 to 7"},
         }
         dom = kernels.get("conv_gemm")
         if dom:
+            traffic, source = profiled_traffic()
             result["roofline"] = {"kernel": "conv_gemm_kernel (fp32 MFMA implicit GEMM: update block + OU heads)",
                                   "bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"],
-                                  "unit": "TFLOP/s", "frac": dom["frac"], "traffic": profiled_traffic()[0],
-                                  "traffic_source": profiled_traffic()[1],
+                                  "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
+                                  "traffic_source": source,
                                   "avg_launch_us": dom["avg_us"], "flops_per_launch": dom["work_per_launch"]}
             result["kernels"] = kernels
-    if world == 1 and rank == 0:
-        # PCIe-inclusive variant of the same loop: numpy frames in, CPU results out
-        conf.keep_result_on_device = False
-        n_io = max(4, args.steps // 2)
-        base = first + 2 * args.steps
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(base, min(base + n_io, n_frames)):
-            tracker.track(host_frames[i])
-        torch.cuda.synchronize()
-        result["host_io_fps"] = (min(base + n_io, n_frames) - base) / (time.perf_counter() - t0)
-        log("host-io pass done")
+    if not sharded and rank == 0:
+        if n_io:
+            # PCIe-inclusive variant of the same loop: numpy frames in, CPU results out
+            conf.keep_result_on_device = False
+            base = first + args.steps + n_prof
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(base, base + n_io):
+                tracker.track(host_frames[i])
+            torch.cuda.synchronize()
+            result["host_io_fps"] = n_io / (time.perf_counter() - t0)
+            log("host-io pass done")
         torch.set_num_threads(oracle_threads())
         if not args.no_parity:
-            result["parity"] = flow_epe_vs_oracle(args, tracker, host_frames)
+            result["parity"] = flow_epe_vs_oracle(args, tracker, vid)
             log(f"parity vs oracle: {result.get('parity')}")
         if not args.no_cpu_baseline:
-            result["cpu_baseline"], oracle_meta = cpu_baseline(args, host_frames)
+            result["cpu_baseline"], oracle_meta = cpu_baseline(args, vid)
             log("cpu baseline done")
             if not args.no_parity:
-                result.setdefault("parity", {}).update(track_parity(args, host_frames, oracle_meta))
+                result.setdefault("parity", {}).update(track_parity(args, vid, oracle_meta))
                 log(f"track() parity vs oracle: {result['parity']}")
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,8 +1,8 @@
 """Flow plugin configuration -- same fields as the reference's
-``configs/flow/RAFTou_kubric_huber_split_nonoccl.py``.  ``model`` may point to a
-reference checkpoint (``module.``-prefixed state_dict); when the file is absent
-(it is not distributed with this build) ``synthetic_weights_seed`` selects the
-seeded stand-in weights."""
+``configs/flow/RAFTou_kubric_huber_split_nonoccl.py``.  ``model`` points to a reference
+checkpoint (``module.``-prefixed state_dict); like in the reference a missing file is an error.
+The checkpoint is not distributed with this build: benchmarks and tests opt in to seeded
+stand-in weights explicitly with ``model = None`` + ``synthetic_weights_seed = <int>``."""
 from pathlib import Path
 
 from mft_amd.config import AttrDict, Config
@@ -14,7 +14,6 @@ def get_config():
     conf.of_class = RAFTWrapper
     conf.raft_params = AttrDict(occlusion_module="separate_with_uncertainty", small=False, mixed_precision=False)
     conf.model = "checkpoints/raft-things-sintel-kubric-splitted-occlusion-uncertainty-non-occluded-base-sintel.pth"
-    conf.synthetic_weights_seed = 0
     conf.flow_iters = 12
     conf.name = Path(__file__).stem
     return conf

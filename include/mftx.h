@@ -116,11 +116,13 @@ size_t mftx_raft_workspace_bytes(int P, int h, int w);
  * mftx_raft_refine they hold the intermediates of the last iteration (tests). */
 int mftx_raft_workspace_layout(int P, int h, int w, size_t *offsets, int n);
 /* fmap1/fmap2: [P][h*w][256]; net, inp: [P][h*w][128] (tanh / relu already
- * applied).  Outputs are planar and UNPADDED: flow [P][2][H0][W0], occl
+ * applied).  flow_init (optional, may be NULL): [P*h*w][2] initial flow at 1/8
+ * resolution, added to the start coordinates (core/raft.py:153-154).  Outputs are planar and UNPADDED: flow [P][2][H0][W0], occl
  * [P][1][H0][W0] (softmax channel 1), sigma [P][1][H0][W0] (sqrt(exp(u))), with
  * H0 = 8h - pad_top - pad_bottom etc.  flow_lr (optional) [P*h*w][2]. */
 int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters,
                      const float *fmap1, const float *fmap2, const float *net, const float *inp,
+                     const float *flow_init,
                      int pad_left, int pad_right, int pad_top, int pad_bottom,
                      float *flow, float *occl, float *sigma, float *flow_lr,
                      void *workspace, size_t workspace_bytes, void *stream);

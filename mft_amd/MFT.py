@@ -13,8 +13,9 @@ What changed underneath (same results):
   * the 7 x ``chain_results`` + stack / max / gather selection is one fused HIP
     kernel (``mftx_chain_select``);
   * with ``torch.distributed`` initialised and ``C.delta_sharding`` set, the
-    pairs are sharded over ranks and reassembled with one all-gather
-    (``mft_amd/dist.py``).
+    (frame, delta) flow computations of a frame (``track``) or of a look-ahead
+    window of frames (``track_window``) are sharded over ranks and reassembled
+    with an all-gather (``mft_amd/dist.py``).
 Python remains the owner of the delta bookkeeping, the memory ring and the cache.
 """
 from __future__ import annotations
@@ -76,19 +77,23 @@ class MFT():
         self.template_img = img.copy() if hasattr(img, "copy") else img.clone()
         self.last_pairs = []
         self.last_chosen = None
+        self._window_ids = set()
         if self.C.delta_sharding:
-            from .dist import DeltaSharder
-            self.sharder = DeltaSharder.from_environment()
+            from .dist import WindowSharder
+            self.sharder = WindowSharder.from_environment()
         meta = SimpleNamespace()
         meta.result = self.memory[self.start_frame_i]['result'].clone().cpu()
         return meta
 
     # ----------------------------------------------------------------- track
-    def _plan(self):
-        """Delta bookkeeping of MFT/MFT.py:74-91: [(delta, left_id, use_cache)]."""
+    def _plan(self, frame_i=None):
+        """Delta bookkeeping of MFT/MFT.py:74-91 for frame ``frame_i`` (default: the current one):
+        [(delta, left_id, use_cache)] in selection order."""
+        if frame_i is None:
+            frame_i = self.current_frame_i
         plan, used = [], []
         for delta in self.C.deltas:
-            left_id = self.current_frame_i - delta * self.time_direction
+            left_id = frame_i - delta * self.time_direction
             if self.is_before_start(left_id):
                 if np.isinf(delta):
                     left_id = self.start_frame_i
@@ -104,41 +109,62 @@ class MFT():
         plan.sort(key=lambda e: 0 if np.isinf(e[0]) else e[0])
         return plan
 
+    def _sharded(self):
+        return self.sharder is not None and (self.sharder.world_size > 1 or self.C.delta_sharding == "force")
+
     def track(self, input_img, debug=False, **kwargs):
         """Track one frame (MFT/MFT.py:55-154)."""
-        meta = SimpleNamespace()
-        self.current_frame_i += self.time_direction
-        right_id = self.current_frame_i
-        plan = self._plan()
-        self.last_pairs = [(left_id, right_id) for _, left_id, _ in plan]
+        if self._sharded():
+            return self.sharder.track_window(self, [input_img])[0]
+        frame_i = self.current_frame_i + self.time_direction
+        plan = self._plan(frame_i)
+        rights = self._flows_for(plan, frame_i, input_img)
+        lefts = [self.memory[left_id]['result'].planes() for _, left_id, _ in plan]
+        return self._finish_frame(frame_i, input_img, plan, lefts, [r.planes() for r in rights])
 
-        if self.sharder is not None and (self.sharder.world_size > 1 or self.C.delta_sharding == "force"):
-            flow, occl, sigma, chosen = self.sharder.track_step(self, plan, input_img)
-        else:
-            rights = self._flows_for(plan, input_img, range(len(plan)))
-            lefts = [self.memory[left_id]['result'].planes() for _, left_id, _ in plan]
-            flow, occl, sigma, chosen = self.backend.chain_select(lefts, [r.planes() for r in rights],
-                                                                  self.C.occlusion_threshold)
+    def track_window(self, imgs):
+        """Track the next ``len(imgs)`` frames and return their metas in order.  Same results as calling
+        ``track`` on each; with ``C.delta_sharding`` and several ranks the (frame, delta) flow
+        computations of the whole window are sharded over the GPUs (``mft_amd/dist.py``)."""
+        imgs = list(imgs)
+        if self._sharded() and imgs:
+            return self.sharder.track_window(self, imgs)
+        return [self.track(img) for img in imgs]
+
+    def _finish_frame(self, frame_i, input_img, plan, lefts, rights):
+        """Chain every candidate onto its stored (template -> left) result, pick the best per pixel
+        (MFT/MFT.py:104-143), store the frame and clean the ring."""
+        meta = SimpleNamespace()
+        flow, occl, sigma, chosen = self.backend.chain_select(lefts, rights, self.C.occlusion_threshold)
         # invalid flows are already marked occluded inside the selection kernel
         result = FlowOUTrackingResult(flow, occl, sigma, validate=False)
+        self.current_frame_i = frame_i
+        self.last_pairs = [(left_id, frame_i) for _, left_id, _ in plan]
         self.last_chosen = chosen
-
         if self.C.keep_result_on_device:
-            meta.result = result
+            meta.result = result.clone()       # a copy: the consumer may move it in place (meta.result.cpu())
         else:
             meta.result = result.clone().cpu()
-
-        self.memory[self.current_frame_i] = {'img': input_img, 'result': result}
+        self.memory[frame_i] = {'img': input_img, 'result': result}
         self.cleanup_memory()
         return meta
 
-    def _flows_for(self, plan, input_img, indices):
-        """FlowOU (left -> current) for plan[i], i in indices: cache first, then
-        one batched flow computation for everything that is missing."""
-        right_id = self.current_frame_i
+    def _flows_for_pairs(self, pairs):
+        """[(left_id, left_img, right_id, right_img)] -> [(flow, occl, sigma)], one batched engine pass
+        when the flow plugin offers one, else the reference's per-pair call (MFT/MFT.py:223-225)."""
+        if hasattr(self.flower, "compute_pairs"):
+            return self.flower.compute_pairs(pairs)
+        res = []
+        for _, left_img, _, right_img in pairs:
+            f, extra = self.flower.compute_flow(left_img, right_img, mode='flow', init_flow=None)
+            res.append((f, extra['occlusion'], extra['sigma']))
+        return res
+
+    def _flows_for(self, plan, right_id, input_img):
+        """FlowOU (left -> right_id) for every entry of ``plan``: cache first, then one batched flow
+        computation for everything that is missing."""
         out, missing = {}, []
-        for i in indices:
-            _, left_id, use_cache = plan[i]
+        for i, (_, left_id, use_cache) in enumerate(plan):
             got = None
             if use_cache and self.flow_cache is not None:
                 try:
@@ -152,21 +178,14 @@ class MFT():
             else:
                 out[i] = got
         if missing:
-            if hasattr(self.flower, "compute_flow_many"):
-                res = self.flower.compute_flow_many(
-                    [(plan[i][1], self.memory[plan[i][1]]['img']) for i in missing], (right_id, input_img))
-            else:  # any reference-style plugin
-                res = []
-                for i in missing:
-                    f, extra = self.flower.compute_flow(self.memory[plan[i][1]]['img'], input_img, mode='flow',
-                                                        init_flow=None)
-                    res.append((f, extra['occlusion'], extra['sigma']))
+            res = self._flows_for_pairs([(plan[i][1], self.memory[plan[i][1]]['img'], right_id, input_img)
+                                         for i in missing])
             for i, (f, o, s) in zip(missing, res):
                 _, left_id, use_cache = plan[i]
                 if self.flow_cache is not None and use_cache:
                     self.flow_cache.write(left_id, right_id, f, o, s)
                 out[i] = FlowOUTrackingResult(f, o, s, validate=False)
-        return [out[i] for i in indices]
+        return [out[i] for i in range(len(plan))]
 
     # --------------------------------------------------------------- memory
     def cleanup_memory(self):
@@ -183,8 +202,8 @@ class MFT():
             if self.time_direction < 0 and mem_frame_i - max_delta < self.current_frame_i:
                 continue
             del self.memory[mem_frame_i]
-        if hasattr(self.flower, "retain"):
-            self.flower.retain(self.memory.keys())
+        if hasattr(self.flower, "retain"):      # features of a look-ahead window's frames stay until they are tracked
+            self.flower.retain(set(self.memory.keys()) | self._window_ids)
 
     def is_before_start(self, frame_i):
         return ((self.time_direction > 0 and frame_i < self.start_frame_i) or

@@ -16,8 +16,9 @@ namespace mftx {
 
 // hx[m] = [net | inp | (motion: filled later)], coords1 = pixel grid
 // (core/raft.py:146-151; coords_grid core/utils/utils.py:115-118)
-__global__ void init_state_kernel(const float *__restrict__ net, const float *__restrict__ inp, float *hx,
-                                  float *coords1, int M, int h, int w) {
+__global__ void init_state_kernel(const float *__restrict__ net, const float *__restrict__ inp,
+                                  const float *__restrict__ flow_init, float *hx, float *coords1, int M, int h,
+                                  int w) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over M*64 float4 slots
     if (i >= (long long)M * 64) return;
     const int m = (int)(i >> 6), q = (int)(i & 63);
@@ -26,8 +27,13 @@ __global__ void init_state_kernel(const float *__restrict__ net, const float *__
     reinterpret_cast<float4 *>(hx + (long long)m * 384)[q] = v;
     if (q == 0) {
         const int rem = m % (h * w);
-        coords1[2 * (long long)m] = (float)(rem % w);
-        coords1[2 * (long long)m + 1] = (float)(rem / w);
+        float cx = (float)(rem % w), cy = (float)(rem / w);
+        if (flow_init != nullptr) {                 // coords1 = coords0 + flow_init (core/raft.py:153-154)
+            cx += flow_init[2 * (long long)m];
+            cy += flow_init[2 * (long long)m + 1];
+        }
+        coords1[2 * (long long)m] = cx;
+        coords1[2 * (long long)m + 1] = cy;
     }
 }
 
@@ -189,7 +195,8 @@ static mftx_conv_desc conv_desc(const float *a0, int lda0, int c0, const float *
 }
 
 extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, const float *fmap1,
-                                const float *fmap2, const float *net, const float *inp, int pad_left,
+                                const float *fmap2, const float *net, const float *inp, const float *flow_init,
+                                int pad_left,
                                 int pad_right, int pad_top, int pad_bottom, float *flow, float *occl,
                                 float *sigma, float *flow_lr_out, void *workspace, size_t workspace_bytes,
                                 void *stream) {
@@ -219,7 +226,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         const long long slots = (long long)M * 64;
         ProfScope prof(PC_GLUE, s, 0);
         hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, net, inp,
-                           ws.hx, ws.coords1, M, h, w);
+                           flow_init, ws.hx, ws.coords1, M, h, w);
         TRY(check_launch("init_state"));
     }
     // The gate convolutions are linear in their input [h | inp | motion] and `inp` does not change

@@ -1,70 +1,183 @@
-"""Delta-sharded multi-GPU tracking (the reference has no
-distributed path at all).
+"""Multi-GPU tracking: (frame, delta) units of a look-ahead window sharded over ranks
+(the reference has no distributed path at all).
 
-One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI;
-"gloo" in the CPU tests).  The K <= 7 candidates of a frame -- (left_id ->
-current) flow + its chain onto the stored (template -> left_id) result -- are
-independent units (``MFT/MFT.py:74-107``, ``flow_init`` is always None):
+One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI; "gloo" in the CPU
+tests).  A *unit* is one (left_id -> frame) FlowOU computation.  Units
+never depend on tracker state -- RAFT sees only the two images, ``flow_init`` is always None
+(``MFT/MFT.py:96-102``) -- so the 7 L units of L consecutive frames are all independent:
 
-  rank r computes units {i : i mod G == r}  (flow, then chain, locally)
-  one all-gather of [slots, 4, H, W] fp32 per rank (flow2 | occl | sigma)
-  every rank runs the identical selection over the K gathered candidates
+  1. window frames are encoded once, by their owner rank (frame j -> rank j mod G), and the
+     features (fmap | net | inp, 8.4 MB per 512x512 frame) are all-gathered: no rank re-encodes
+     a frame another rank already encoded;
+  2. the units, in (frame, selection-order) order, are cut into G contiguous, equally sized
+     shares (sizes differ by at most one); every rank runs its share through the native RAFT
+     engine in batches of up to 7 pairs -- the batch size at which the conv GEMMs reach their
+     single-GPU rate (``profiles/r1k_bench_pairs.txt``) -- whatever G is;
+  3. ONE all-gather of the raw FlowOU planes (flow2 | occl | sigma, 16 B per pixel and unit;
+     the last slot of a short share is simply not read -- nothing is zero-filled);
+  4. every rank runs the fused chain + select kernel for the window's frames IN FRAME ORDER
+     (frame t's chains read ``memory[t - delta]``), so ``tracker.memory`` stays replicated and
+     bitwise equal on all ranks, and equal to the single-GPU tracker: the unit results do not
+     depend on how they are batched (``test_batch_invariance_bitwise``) and chain + select is the
+     very kernel the single-GPU path runs.
 
-so ``tracker.memory`` stays replicated and bitwise equal on all ranks and no
-other collective is needed.  Each rank encodes the new frame itself (a few
-hundred microseconds) rather than waiting for a broadcast.  Payload per rank per
-frame: slots * 16 * H * W bytes (4.19 MB per slot at 512x512); on xGMI's
-point-to-point mesh that is far below one RAFT pass, so the exchange is a
-single collective, not a bucketed/overlapped pipeline.
+L = 1 is the online mode (``MFT.track``): the <= 7 units of the current frame are split over the
+ranks, which caps the speed-up at the per-rank batch efficiency (a share of one pair runs the GEMMs
+at about half their rate).  L >= G is the offline mode (``MFT.track_window``): every rank always
+has full batches, results come back L frames at a time.
+
+Payloads per window at 512x512: features L x 8.4 MB, FlowOU 7 L x 4.19 MB (L = 16: 134 MB +
+470 MB gathered, i.e. 17 + 59 MB sent per rank at G = 8) against ~16 ms of RAFT per 7 units --
+two collectives per window, not a bucketed/overlapped pipeline.
 """
 from __future__ import annotations
+
+from types import SimpleNamespace
 
 import torch
 import torch.distributed as dist
 
 
-def shard_indices(K: int, world_size: int, rank: int):
-    """Units of this rank: round-robin over the selection order [inf, 1, 2, ...]."""
-    return list(range(rank, K, world_size))
+def split_units(n_units: int, world_size: int):
+    """Contiguous, balanced shares: [(offset, count)] per rank; counts differ by at most one."""
+    base, extra = divmod(n_units, world_size)
+    out, off = [], 0
+    for r in range(world_size):
+        cnt = base + (1 if r < extra else 0)
+        out.append((off, cnt))
+        off += cnt
+    return out
 
 
-def slots_per_rank(K: int, world_size: int) -> int:
-    return -(-K // world_size)
+def frame_owner(j: int, world_size: int) -> int:
+    """Rank that encodes the j-th frame of a window."""
+    return j % world_size
 
 
-class DeltaSharder:
+class WindowSharder:
+    #: pairs per engine call (the single-GPU tracker's batch at steady state)
+    MAX_BATCH = 7
+
     def __init__(self, group=None):
         if not dist.is_initialized():
             raise RuntimeError("delta_sharding needs an initialised torch.distributed process group")
         self.group = group
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
+        self.stats = {"windows": 0, "units": 0, "my_units": 0, "encoded": 0}
 
     @classmethod
     def from_environment(cls):
         return cls()
 
-    def track_step(self, tracker, plan, input_img):
-        """Sharded equivalent of chain_select over ``plan``; returns
-        (flow, occl, sigma, chosen) identical on every rank."""
-        K, G, r = len(plan), self.world_size, self.rank
-        mine = shard_indices(K, G, r)
-        S = slots_per_rank(K, G)
+    # ------------------------------------------------------------------ collectives
+    def _all_gather(self, send: torch.Tensor) -> torch.Tensor:
+        """[S, ...] per rank -> [G, S, ...] (rank-major)."""
+        recv = torch.empty((self.world_size,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+        dist.all_gather_into_tensor(recv.view(self.world_size * send.shape[0], *send.shape[1:]), send,
+                                    group=self.group)
+        return recv
+
+    # ------------------------------------------------------------------ features
+    def _exchange_features(self, tracker, frame_ids, imgs):
+        """Encode each window frame on its owner and all-gather (fmap | net | inp); afterwards the
+        flow plugin's per-frame cache holds every window frame on every rank."""
+        flower = tracker.flower
+        G, L = self.world_size, len(frame_ids)
+        if not hasattr(flower, "encode_packed"):
+            return                                   # reference-style plugin: nothing to exchange
+        if L < G:
+            return                                   # fewer frames than ranks: everyone encodes what it needs
+        slots = -(-L // G)
+        mine = [j for j in range(L) if frame_owner(j, G) == self.rank]
+        send = None
+        for s, j in enumerate(mine):
+            packed, geom = flower.encode_packed(imgs[j])          # [N, 512]
+            if send is None:
+                send = torch.empty((slots,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+            send[s] = packed
+            self.stats["encoded"] += 1
+        if send is None:                              # cannot happen for L >= G, kept for clarity
+            packed, geom = flower.encode_packed(imgs[0])
+            send = torch.empty((slots,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+        recv = self._all_gather(send)                 # [G, slots, N, 512]
+        for j in range(L):
+            flower.adopt_packed(frame_ids[j], recv[frame_owner(j, G), j // G], imgs[j])
+
+    # ------------------------------------------------------------------ the window
+    def track_window(self, tracker, imgs):
+        """Track ``imgs`` (the next L frames); returns their metas in order.  Identical results and
+        tracker state on every rank."""
+        G, r = self.world_size, self.rank
+        L = len(imgs)
+        d = tracker.time_direction
+        frame_ids = [tracker.current_frame_i + d * (j + 1) for j in range(L)]
+        window_img = dict(zip(frame_ids, imgs))
+
+        def img_of(fid):
+            return window_img[fid] if fid in window_img else tracker.memory[fid]['img']
+
+        plans = [tracker._plan(fid) for fid in frame_ids]
+        units = [(j, k) for j, plan in enumerate(plans) for k in range(len(plan))]
+        shares = split_units(len(units), G)
+        off, cnt = shares[r]
+        slots = max(c for _, c in shares)
+
+        tracker._window_ids = set(frame_ids)
+        self._exchange_features(tracker, frame_ids, imgs)
+
+        # ---- my share, in engine batches
         H, W = tracker.img_H, tracker.img_W
-        rights = tracker._flows_for(plan, input_img, mine) if mine else []
-        dev = tracker.memory[tracker.start_frame_i]['result'].flow.device
-        send = torch.zeros(S, 4, H, W, dtype=torch.float32, device=dev)
-        for slot, (i, right) in enumerate(zip(mine, rights)):
-            left = tracker.memory[plan[i][1]]['result']
-            f, o, s = tracker.backend.chain(left.planes(), right.planes())
-            send[slot, 0:2] = f
-            send[slot, 2:3] = o
-            send[slot, 3:4] = s
-        recv = torch.empty(G * S, 4, H, W, dtype=torch.float32, device=dev)   # rank-major concatenation
-        dist.all_gather_into_tensor(recv, send, group=self.group)
-        recv = recv.view(G, S, 4, H, W)
-        cands = []
-        for i in range(K):                      # unit i lives on rank i % G, slot i // G
-            c = recv[i % G, i // G]
-            cands.append((c[0:2], c[2:3], c[3:4]))
-        return tracker.backend.select(cands, tracker.C.occlusion_threshold)
+        dev = tracker.device
+        send = torch.empty(max(slots, 1), 4, H, W, dtype=torch.float32, device=dev)
+        mine = units[off: off + cnt]
+        for b0 in range(0, cnt, self.MAX_BATCH):
+            batch = mine[b0: b0 + self.MAX_BATCH]
+            pairs = []
+            for j, k in batch:
+                left_id = plans[j][k][1]
+                pairs.append((left_id, img_of(left_id), frame_ids[j], imgs[j]))
+            for s, (f, o, sg) in enumerate(tracker._flows_for_pairs(pairs)):
+                slot = send[b0 + s]
+                slot[0:2].copy_(f)
+                slot[2:3].copy_(o)
+                slot[3:4].copy_(sg)
+        recv = self._all_gather(send)                 # [G, slots, 4, H, W]
+        self.stats["windows"] += 1
+        self.stats["units"] += len(units)
+        self.stats["my_units"] += cnt
+
+        owner_slot = {}
+        for rr, (o, c) in enumerate(shares):
+            for s in range(c):
+                owner_slot[o + s] = (rr, s)
+
+        # ---- replicated chain + select, frame by frame
+        metas, u = [], 0
+        for j, fid in enumerate(frame_ids):
+            plan = plans[j]
+            lefts, rights = [], []
+            for k in range(len(plan)):
+                rr, s = owner_slot[u]
+                u += 1
+                c = recv[rr, s]
+                rights.append((c[0:2], c[2:3], c[3:4]))
+                lefts.append(tracker.memory[plan[k][1]]['result'].planes())
+            if j == L - 1:
+                tracker._window_ids = set()
+            metas.append(tracker._finish_frame(fid, imgs[j], plan, lefts, rights))
+        return metas
+
+
+# the per-frame mode of round 1 is the L = 1 window
+DeltaSharder = WindowSharder
+
+
+def shard_indices(K: int, world_size: int, rank: int):
+    """Units of ``rank`` among the K units of one frame (L = 1): a contiguous share."""
+    off, cnt = split_units(K, world_size)[rank]
+    return list(range(off, off + cnt))
+
+
+def make_meta(result):
+    return SimpleNamespace(result=result)

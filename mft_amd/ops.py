@@ -169,21 +169,28 @@ class EncoderEngine:
         except Exception:
             pass
 
-    def forward(self, img_u8: torch.Tensor):
-        """img_u8: uint8 [H0, W0, 3] BGR on the device -> pixel-major maps at 1/8 resolution."""
+    def forward(self, img_u8: torch.Tensor, out=None):
+        """img_u8: uint8 [H0, W0, 3] BGR on the device -> pixel-major maps at 1/8 resolution.
+        out: optional pre-allocated (out0, out1) to write into (contiguous [h*w, C] views)."""
         lib = _lib.load()
         H0, W0 = img_u8.shape[:2]
         h, w = -(-H0 // 8), -(-W0 // 8)
         need = lib.mftx_encoder_workspace_bytes(H0, W0)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        if self.instance_norm:
+        if out is not None:
+            outs = out
+            want = ((h * w, 256), None) if self.instance_norm else ((h * w, 128), (h * w, 128))
+            for t, shp in zip(outs, want):
+                if shp is not None and (t is None or tuple(t.shape) != shp):
+                    raise MftxError(f"encoder output must be {shp}")
+        elif self.instance_norm:
             outs = (torch.empty(h * w, 256, dtype=torch.float32, device=self.device), None)
         else:
             outs = (torch.empty(h * w, 128, dtype=torch.float32, device=self.device),
                     torch.empty(h * w, 128, dtype=torch.float32, device=self.device))
-        check(lib.mftx_encoder_forward(self._h, _chk(img_u8, "img", torch.uint8), H0, W0, outs[0].data_ptr(),
-                                       outs[1].data_ptr() if outs[1] is not None else None,
+        check(lib.mftx_encoder_forward(self._h, _chk(img_u8, "img", torch.uint8), H0, W0, _chk(outs[0], "out0"),
+                                       _chk(outs[1], "out1") if outs[1] is not None else None,
                                        self._ws.data_ptr(), self._ws.numel(), _stream()), "mftx_encoder_forward")
         return outs
 
@@ -325,6 +332,8 @@ def quantize_u16(x):
     lib = _lib.load()
     if isinstance(x, torch.Tensor) and x.is_cuda:
         x = x.contiguous()
+        if x.data_ptr() % 16:        # a plane sliced out of a batched result: the kernels load 16 bytes per lane
+            x = x.clone()
     _chk(x, "x")
     if x.numel() == 0:
         raise MftxError("quantize_u16: empty channel")
@@ -344,6 +353,8 @@ def dequantize_u16(q, lo, hi):
     lib = _lib.load()
     if isinstance(q, torch.Tensor) and q.is_cuda:
         q = q.contiguous()
+        if q.data_ptr() % 16:
+            q = q.clone()
     _chk(q, "q", torch.uint16)
     x = torch.empty(q.shape, dtype=torch.float32, device=q.device)
     check(lib.mftx_dequantize_u16(q.data_ptr(), q.numel(), float(lo), float(hi), x.data_ptr(), _stream()),
@@ -389,9 +400,10 @@ class RaftEngine:
         n = P * h * w * cols
         return self._ws[off: off + 4 * n].view(torch.float32).reshape(P * h * w, cols)
 
-    def refine(self, fmap1, fmap2, net, inp, h, w, iters, pads=(0, 0, 0, 0), want_flow_lr=False):
+    def refine(self, fmap1, fmap2, net, inp, h, w, iters, pads=(0, 0, 0, 0), want_flow_lr=False, flow_init=None):
         """fmap1/fmap2 [P, h*w, 256], net/inp [P, h*w, 128] pixel-major ->
-        flow [P,2,H0,W0], occl [P,1,H0,W0], sigma [P,1,H0,W0] (+ flow_lr [P,h*w,2])."""
+        flow [P,2,H0,W0], occl [P,1,H0,W0], sigma [P,1,H0,W0] (+ flow_lr [P,h*w,2]).
+        flow_init: optional [P, h*w, 2] initial flow at 1/8 resolution (core/raft.py:153-154)."""
         lib = _lib.load()
         P = fmap1.shape[0]
         pl, pr, pt, pb = pads
@@ -401,9 +413,13 @@ class RaftEngine:
         occl = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev)
         sigma = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev)
         flow_lr = torch.empty(P, h * w, 2, dtype=torch.float32, device=dev) if want_flow_lr else None
+        if flow_init is not None and tuple(flow_init.shape) != (P, h * w, 2):
+            raise MftxError("flow_init must be [P, h*w, 2]")
         ws = self.workspace(P, h, w)
         check(lib.mftx_raft_refine(self._h, P, h, w, iters, _chk(fmap1, "fmap1"), _chk(fmap2, "fmap2"),
-                                   _chk(net, "net"), _chk(inp, "inp"), pl, pr, pt, pb,
+                                   _chk(net, "net"), _chk(inp, "inp"),
+                                   _chk(flow_init, "flow_init") if flow_init is not None else None,
+                                   pl, pr, pt, pb,
                                    flow.data_ptr(), occl.data_ptr(), sigma.data_ptr(),
                                    flow_lr.data_ptr() if want_flow_lr else None,
                                    ws.data_ptr(), ws.numel(), _stream()), "mftx_raft_refine")

@@ -77,8 +77,8 @@ class FlowOUTrackingResult(object):
     def planes(self):
         return self.flow, self.occlusion, self.sigma
 
-    # ---- IO (plain pickle of the three arrays; the reference's .flowouX16
-    # codec, MFT/utils/io.py:495-563, is outside this tier's scope) ---------
+    # ---- IO (MFT/results.py:61-72): the reference's .flowouX16 cache entry, quantised on the device
+    # (mft_amd/flowou_codec.py); any other name is a plain fp32 pickle of the three arrays ------
     def write(self, path):
         """``*.flowouX16.pkl`` -- the reference's uint16-quantised entry (MFT/results.py:61-65,
         MFT/utils/io.py:179-198), quantised on the device; any other name: a plain fp32 pickle.

@@ -357,11 +357,23 @@ def postprocess(pred, H0, W0):
     return flow, occl, sigma
 
 
-def compute_flow(sd, src_img, dst_img, iters=12, timers=None):
+def downsample_flow_8(flow):
+    """(B, xy, H, W) -> (B, xy, H/8, W/8), bilinear with align_corners=True, values / 8
+    (MFT/raft.py:98-101)."""
+    size = (flow.shape[2] // 8, flow.shape[3] // 8)
+    return F.interpolate(flow, size=size, mode="bilinear", align_corners=True) / 8
+
+
+def compute_flow(sd, src_img, dst_img, iters=12, timers=None, init_flow=None):
     """RAFTWrapper.compute_flow(mode='flow') (MFT/raft.py:30-73) ->
-    flow[2,H,W], occlusion[1,H,W], sigma[1,H,W]."""
+    flow[2,H,W], occlusion[1,H,W], sigma[1,H,W].  init_flow: optional (2, H, W) initial flow, padded like
+    the images and brought to 1/8 resolution (MFT/raft.py:49-52), added to coords1 (core/raft.py:153-154)."""
     H0, W0 = src_img.shape[:2]
-    pred = raft_forward(sd, preprocess(src_img), preprocess(dst_img), iters, timers=timers)
+    flow_init = None
+    if init_flow is not None:
+        l, r, t, b = pad_amounts(H0, W0)
+        flow_init = downsample_flow_8(F.pad(torch.as_tensor(init_flow).to(F32)[None], [l, r, t, b], mode="replicate"))
+    pred = raft_forward(sd, preprocess(src_img), preprocess(dst_img), iters, flow_init=flow_init, timers=timers)
     return postprocess(pred, H0, W0)
 
 

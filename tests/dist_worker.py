@@ -1,5 +1,4 @@
-"""Worker for the 2-rank gloo test of the delta-sharded tracker (CPU)."""
-import os
+"""Worker for the 2-rank gloo test of the window-sharded tracker (CPU)."""
 import sys
 from pathlib import Path
 
@@ -12,20 +11,60 @@ sys.path.insert(0, str(REPO))
 sys.path.insert(0, str(REPO / "tests"))
 
 import golden_inputs as gi  # noqa: E402
-from test_host_logic import StubFlower, make_tracker  # noqa: E402
+from test_host_logic import StubFlower, T, make_tracker  # noqa: E402
+
+N_FRAMES = 20
 
 
-def run(sharded, n_frames=12):
-    tr = make_tracker(StubFlower(), delta_sharding=sharded)
+class ExchangingFlower:
+    """Test double with the feature-exchange interface of RAFTWrapper: a frame's "features" are its id;
+    a pair may only be computed from features this rank encoded itself or adopted from a peer."""
+
+    def __init__(self):
+        self.features, self.encoded = {}, 0
+
+    def encode_packed(self, img):
+        self.encoded += 1
+        return torch.full((6,), float(gi.decode_id(img))), (1, 1)
+
+    def adopt_packed(self, frame_id, buf, img):
+        assert int(buf[0]) == gi.decode_id(img) == frame_id
+        self.features[frame_id] = buf
+
+    def reset_cache(self):
+        self.features = {}
+
+    def retain(self, frame_ids):
+        self.features = {k: v for k, v in self.features.items() if k in set(frame_ids)}
+
+    def compute_pairs(self, pairs):
+        out = []
+        for lk, limg, rk, rimg in pairs:
+            for k, img in ((lk, limg), (rk, rimg)):
+                if k not in self.features:              # only the start frame is ever encoded locally
+                    assert k == 0, f"frame {k} was not exchanged"
+                    self.features[k] = torch.full((6,), float(k))
+            flow, occl, sigma = gi.stub_flowou(int(self.features[lk][0]), int(self.features[rk][0]))
+            out.append((T(flow), T(occl), T(sigma)))
+        return out
+
+
+def run(sharded, window, flower):
+    tr = make_tracker(flower, delta_sharding=sharded)
     tr.init(gi.id_image(0))
-    out = {}
-    for i in range(1, n_frames):
-        res = tr.track(gi.id_image(i)).result
-        out[f"flow{i}"] = res.flow.numpy()
-        out[f"occl{i}"] = res.occlusion.numpy()
-        out[f"sigma{i}"] = res.sigma.numpy()
-        out[f"chosen{i}"] = tr.last_chosen.numpy()
-    return out
+    out, i = {}, 1
+    while i < N_FRAMES:
+        imgs = [gi.id_image(k) for k in range(i, min(i + window, N_FRAMES))]
+        metas = tr.track_window(imgs) if window > 1 else [tr.track(imgs[0])]
+        for k, m in enumerate(metas):
+            res = m.result
+            out[f"flow{i + k}"] = res.flow.numpy()
+            out[f"occl{i + k}"] = res.occlusion.numpy()
+            out[f"sigma{i + k}"] = res.sigma.numpy()
+        out[f"chosen{i + len(imgs) - 1}"] = tr.last_chosen.numpy()
+        out[f"keys{i + len(imgs) - 1}"] = np.array(sorted(tr.memory.keys()))
+        i += len(imgs)
+    return out, tr
 
 
 if __name__ == "__main__":
@@ -33,9 +72,17 @@ if __name__ == "__main__":
     torch.set_num_threads(2)
     dist.init_process_group("gloo")
     rank = dist.get_rank()
-    res = run(sharded=True)
-    np.savez(outdir / f"rank{rank}.npz", **res)
+    for mode, window, mk in (("L1", 1, StubFlower), ("L8", 8, StubFlower), ("L5x", 5, ExchangingFlower)):
+        fl = mk()
+        res, tr = run(True, window, fl)
+        if mode == "L5x":
+            st = tr.sharder.stats
+            res.update(_encoded=np.array(fl.encoded), _frames=np.array(N_FRAMES - 1), _my_units=np.array(st["my_units"]),
+                       _windows=np.array(st["windows"]))
+        np.savez(outdir / f"rank{rank}_{mode}.npz", **res)
     if rank == 0:
-        np.savez(outdir / "single.npz", **run(sharded=False))
+        # single-rank reference: per-frame track(); chosen / keys recorded at the same frames as L = 8
+        ref, _ = run(False, 1, StubFlower())
+        np.savez(outdir / "single.npz", **{k: v for k, v in ref.items() if not k.startswith(("chosen", "keys"))})
     dist.barrier()
     dist.destroy_process_group()

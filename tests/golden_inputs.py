@@ -129,3 +129,20 @@ def results_api_inputs():
     pts = np.array([[0.0, 0.0], [3.25, 7.5], [55.0, 39.0], [-2.0, 4.0], [60.5, 10.0], [27.0, 20.0], [10.75, 38.6]],
                    np.float32)
     return dict(flow=flow.astype(np.float32), occl=occl, sigma=sigma, img=img, mask=mask, pts=pts)
+
+
+def codec_inputs():
+    """One FlowOU triple for the flow-cache codec pin (MFT/utils/io.py:495-563): 37 x 53 (H*W odd, so plane
+    views are not 16-byte aligned), a constant channel (the ub == lb branch) and values that hit both ends
+    of the uint16 range."""
+    H, W = 37, 53
+    r = _rng(51)
+    flow = smooth_field(r, 2, H, W, cells=4, amp=7.0)
+    occl = np.clip(smooth_field(r, 1, H, W, cells=5, amp=0.6), 0, 1).astype(np.float32)
+    sigma = np.full((1, H, W), 0.75, np.float32)           # constant plane -> all zeros after quantisation
+    return dict(flow=flow.astype(np.float32), occl=occl, sigma=sigma)
+
+
+def init_flow_input(H, W):
+    """Full-resolution initial flow for compute_flow(init_flow=...) (MFT/raft.py:49-52)."""
+    return smooth_field(_rng(61), 2, H, W, cells=3, amp=5.0).astype(np.float32)

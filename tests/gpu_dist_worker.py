@@ -1,4 +1,4 @@
-"""Worker for the single-node RCCL test of the delta-sharded tracker (GPU)."""
+"""Worker for the single-node RCCL test of the window-sharded tracker (GPU)."""
 import os
 import sys
 from pathlib import Path
@@ -17,8 +17,10 @@ from mft_amd.raft import RAFTWrapper  # noqa: E402
 from mft_amd.synth import SyntheticVideo  # noqa: E402
 from mft_amd.weights import make_weights  # noqa: E402
 
+N_FRAMES = 14
 
-def run(flower, sharding, n_frames):
+
+def run(flower, sharding, window):
     c = Config()
     c.deltas = [np.inf, 1, 2, 4, 8]
     c.occlusion_threshold = 0.02
@@ -26,14 +28,20 @@ def run(flower, sharding, n_frames):
     c.flow_config = Config()
     c.flow_config.of_class = lambda cfg: flower
     tr = MFT(c)
-    vid = SyntheticVideo(128, 160, n_frames=n_frames, seed=4)
+    vid = SyntheticVideo(128, 160, n_frames=N_FRAMES, seed=4)
     tr.init(vid[0])
-    out = {}
-    for i in range(1, n_frames):
-        res = tr.track(vid[i]).result
-        out[f"flow{i}"], out[f"occl{i}"], out[f"sigma{i}"] = res.flow.numpy(), res.occlusion.numpy(), res.sigma.numpy()
-        out[f"chosen{i}"] = tr.last_chosen.cpu().numpy()
-    return out
+    out, i = {}, 1
+    while i < N_FRAMES:
+        imgs = [vid[k] for k in range(i, min(i + window, N_FRAMES))]
+        metas = tr.track_window(imgs) if window > 1 else [tr.track(imgs[0])]
+        for k, m in enumerate(metas):
+            res = m.result
+            out[f"flow{i + k}"], out[f"occl{i + k}"], out[f"sigma{i + k}"] = \
+                res.flow.numpy(), res.occlusion.numpy(), res.sigma.numpy()
+        i += len(imgs)
+    out["final_chosen"] = tr.last_chosen.cpu().numpy()
+    out["final_keys"] = np.array(sorted(tr.memory.keys()))
+    return out, tr
 
 
 if __name__ == "__main__":
@@ -45,9 +53,12 @@ if __name__ == "__main__":
     fc.flow_iters = 4
     flower = RAFTWrapper(fc, state_dict=make_weights(7))
     rank, world = dist.get_rank(), dist.get_world_size()
-    res = run(flower, "force" if world == 1 else True, 10)
-    np.savez(outdir / f"rank{rank}.npz", **res)
+    sharding = "force" if world == 1 else True
+    for mode, window in (("L1", 1), ("L6", 6)):
+        res, tr = run(flower, sharding, window)
+        res["_encoded"] = np.array(tr.sharder.stats["encoded"])
+        np.savez(outdir / f"rank{rank}_{mode}.npz", **res)
     if rank == 0:
-        np.savez(outdir / "single.npz", **run(flower, False, 10))
+        np.savez(outdir / "single.npz", **run(flower, False, 1)[0])
     dist.barrier()
     dist.destroy_process_group()

@@ -186,3 +186,58 @@ def test_result_write_read_flowouX16(tmp_path):
     assert float((back.occlusion - r.occlusion).abs().max()) < 2e-5 and float((back.sigma - r.sigma).abs().max()) < 2e-5
     with pytest.raises(NotImplementedError):
         r.write(tmp_path / "x.flowou.png")
+
+
+@pytest.mark.gpu
+def test_device_codec_vs_reference_golden(golden_dir, tmp_path):
+    """mftx_quantize_u16 / mftx_dequantize_u16 and the container against what the REFERENCE's own
+    write_flowou_X16 / read_flowou_X16 produced for the same inputs (tests/golden/codec.npz, captured in
+    the build container under a cv2 stub): uint16 planes, (min, max) and decoded floats, bit for bit."""
+    import golden_inputs as gi
+    from mft_amd import ops
+    g = np.load(golden_dir / "codec.npz")
+    d = gi.codec_inputs()
+    flow, occl, sigma = (torch.from_numpy(d[k]).cuda() for k in ("flow", "occl", "sigma"))
+    planes = [flow[0], flow[1], occl[0], sigma[0]]          # views at odd offsets: 37 * 53 floats apart
+    dec = [g["dec_flow"][0], g["dec_flow"][1], g["dec_occl"][0], g["dec_sigma"][0]]
+    for i, x in enumerate(planes):
+        q, lohi = ops.quantize_u16(x)
+        want_u16 = O.bgr_to_u16(g["bgr"][i])
+        assert np.array_equal(q.cpu().numpy(), want_u16), i
+        assert np.array_equal(lohi.cpu().numpy(), g["lohi"][i]), i
+        back = ops.dequantize_u16(q, float(g["lohi"][i, 0]), float(g["lohi"][i, 1]))
+        assert np.array_equal(back.cpu().numpy(), dec[i]), i
+    # the file round trip through the product's writer / reader gives the reference's decoded arrays
+    path = tmp_path / "3--5.flowouX16.pkl"
+    fc.write_flowou_X16(path, flow, occl, sigma)
+    f2, o2, s2 = fc.read_flowou_X16(path)
+    assert np.array_equal(f2.cpu().numpy(), g["dec_flow"]) and np.array_equal(o2.cpu().numpy(), g["dec_occl"])
+    assert np.array_equal(s2.cpu().numpy(), g["dec_sigma"])
+    # and the PNG planes inside are the (B, G, R) planes the reference hands to cv2.imencode
+    with open(path, "rb") as fh:
+        pk = pickle.load(fh)
+    for i, name in enumerate(fc.CHANNELS):
+        assert np.array_equal(fc.png_decode_rgb8(pk[name]["data"])[..., ::-1], g["bgr"][i]), name
+
+
+@pytest.mark.gpu
+def test_codec_on_unaligned_batched_views(tmp_path):
+    """Planes sliced out of a batched engine output start at k * H * W * 4 bytes: with H * W % 4 != 0 they
+    are not 16-byte aligned.  The cache's disk tier and result.write must take them."""
+    from mft_amd import ops
+    from mft_amd.io import FlowCache
+    H, W, P = 125, 187, 3
+    gen = torch.Generator().manual_seed(5)
+    flow = torch.randn(P, 2, H, W, generator=gen).cuda()
+    occl = torch.rand(P, 1, H, W, generator=gen).cuda()
+    sigma = torch.rand(P, 1, H, W, generator=gen).cuda()
+    assert flow[1][1].data_ptr() % 16 != 0
+    for i in range(P):
+        for x in (flow[i][0], flow[i][1], occl[i][0], sigma[i][0]):
+            q, lohi = ops.quantize_u16(x)
+            rq, lo, hi = O.quantize_u16(x.cpu().numpy())
+            assert np.array_equal(q.cpu().numpy(), rq) and float(lohi[0]) == lo and float(lohi[1]) == hi
+    cache = FlowCache(tmp_path / "c", max_RAM_MB=0, max_GPU_RAM_MB=0)
+    cache.write(4, 9, flow[1], occl[1], sigma[1])                       # straight to the disk tier
+    f, o, s_ = cache.read(4, 9)
+    assert f is not None and (f - flow[1]).abs().max() < (flow[1].max() - flow[1].min()) / 65535

@@ -1,7 +1,7 @@
-"""Delta-sharded tracking over RCCL on the GPUs that are visible (1 on the test
-box: the sharded code path -- chain, all-gather, select -- is forced and must
-equal the fused single-GPU path bit for bit; with more GPUs visible the same
-test runs one rank per GPU)."""
+"""Window-sharded tracking over RCCL on the GPUs that are visible (1 on the test box: the sharded
+code path -- feature all-gather, share of the (frame, delta) units, FlowOU all-gather, replicated
+chain + select -- is forced and must equal the plain single-GPU tracker bit for bit; with more GPUs
+visible the same test runs one rank per GPU)."""
 import os
 import subprocess
 import sys
@@ -16,7 +16,7 @@ REPO = Path(__file__).resolve().parents[1]
 
 
 @pytest.mark.timeout(600)
-def test_delta_sharding_rccl_bitwise(tmp_path):
+def test_window_sharding_rccl_bitwise(tmp_path):
     n = min(torch.cuda.device_count(), 4)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29621", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
@@ -25,7 +25,14 @@ def test_delta_sharding_rccl_bitwise(tmp_path):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=550)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     single = np.load(tmp_path / "single.npz")
-    for r in range(n):
-        got = np.load(tmp_path / f"rank{r}.npz")
-        for k in single.files:
-            assert np.array_equal(got[k], single[k]), (r, k)
+    for mode in ("L1", "L6"):
+        enc = 0
+        for r in range(n):
+            got = np.load(tmp_path / f"rank{r}_{mode}.npz")
+            enc += int(got["_encoded"])
+            for k in single.files:
+                assert np.array_equal(got[k], single[k]), (mode, r, k)
+        if mode == "L6" and n <= 6:
+            # every exchanged frame is encoded exactly once across the ranks (the ragged last window of one
+            # frame is shorter than the world size when n > 1: every rank encodes it itself)
+            assert enc == (13 if n == 1 else 12), enc

@@ -161,6 +161,63 @@ def test_conv2d_argument_errors(ops_mod):
 # a10 + a12
 # ---------------------------------------------------------------------------
 
+def _run_update_block(ops_mod, weights_np, inp_d, iters=1):
+    """One engine iteration from the per-op fixture's (net, inp, corr, flow): not reachable through
+    mftx_raft_refine (it computes corr itself), so the layers are chained through mftx_conv2d exactly
+    as csrc/raft_engine.hip chains them."""
+    sd = {k: torch.from_numpy(v).to(DEV) for k, v in weights_np.items()}
+    h, w = gi.OPS_H, gi.OPS_W
+
+    def conv(x, name, k, act, x2=None):
+        wt = sd[name + ".weight"]
+        kh, kw = wt.shape[2:]
+        return ops_mod.conv2d(x, ops_mod.pack_conv_weight(wt), sd[name + ".bias"].contiguous(), 1, h, w, wt.shape[0],
+                              kh, kw, act=act, x2=x2)
+    return sd, conv, h, w
+
+
+def test_update_block_and_ou_heads_vs_golden(ops_mod, gold, inp, weights_np):
+    """a7-a9 + a11 per op against the reference's own update block / occlusion block outputs
+    (gold ub_* / ou_*): the layers run through mftx_conv2d in the engine's order, the gate algebra in torch."""
+    sd, conv, h, w = _run_update_block(ops_mod, weights_np, inp)
+    u, o = "update_block.", "occlusion_block."
+    corr, flow, net, ctx = pm(inp["corr"]), pm(inp["flow"]), pm(inp["net"]), pm(inp["inp"])
+    cor = conv(conv(corr, u + "encoder.convc1", 1, "relu"), u + "encoder.convc2", 3, "relu")
+    # convf1 has 2 input channels: pad to 4 for the 16-byte rule (zero weights for the padding)
+    wf1 = sd[u + "encoder.convf1.weight"]
+    wf1p = torch.zeros(128, 4, 7, 7, device=DEV)
+    wf1p[:, :2] = wf1
+    flow4 = torch.cat([flow, torch.zeros_like(flow)], 1).contiguous()
+    flo = ops_mod.conv2d(flow4, ops_mod.pack_conv_weight(wf1p), sd[u + "encoder.convf1.bias"].contiguous(), 1, h, w, 128,
+                         7, 7, act="relu")
+    flo = conv(flo, u + "encoder.convf2", 3, "relu")
+    mot = conv(torch.cat([cor, flo], 1).contiguous(), u + "encoder.conv", 3, "relu")
+    motion = torch.cat([mot, flow], 1).contiguous()
+    assert maxerr(from_pm(motion, h, w), T(gold["ub_motion"])) < 2e-4
+    x = torch.cat([ctx, motion], 1).contiguous()
+    hcur = net
+    for sfx in ("1", "2"):
+        hx = torch.cat([hcur, x], 1).contiguous()
+        z = conv(hx, u + f"gru.convz{sfx}", 5, "sigmoid")
+        r = conv(hx, u + f"gru.convr{sfx}", 5, "sigmoid")
+        q = conv(torch.cat([r * hcur, x], 1).contiguous(), u + f"gru.convq{sfx}", 5, "tanh")
+        hcur = ((1 - z) * hcur + z * q).contiguous()
+    assert maxerr(from_pm(hcur, h, w), T(gold["ub_net"])) < 2e-4
+    delta = conv(conv(hcur, u + "flow_head.conv1", 3, "relu"), u + "flow_head.conv2", 3, None)
+    assert maxerr(from_pm(delta, h, w), T(gold["ub_delta"])) < 2e-4
+    mask = ops_mod.conv2d(conv(hcur, u + "mask.0", 3, "relu"), ops_mod.pack_conv_weight(sd[u + "mask.2.weight"]),
+                          sd[u + "mask.2.bias"].contiguous(), 1, h, w, 576, 1, 1, out_scale=0.25)
+    assert maxerr(from_pm(mask, h, w), T(gold["ub_mask"])) < 2e-4
+    # a11: OU heads on the fixture's own inputs (core/update.py:196-214)
+    ou_in = torch.cat([pm(inp["net"]), pm(inp["inp"]), pm(inp["corr"]), pm(inp["flow"]), pm(inp["delta_flow"]),
+                       pm(inp["motion"])], 1).contiguous()
+    assert ou_in.shape[1] == 712
+    occl = conv(conv(ou_in, o + "occl_head.conv1", 3, "relu"), o + "occl_head.conv2", 3, None)
+    unc = conv(conv(ou_in, o + "uncertainty_head.conv1", 3, "relu"), o + "uncertainty_head.conv2", 3, None)
+    assert maxerr(from_pm(occl, h, w), T(gold["ou_occl"])) < 2e-4
+    assert maxerr(from_pm(unc, h, w), T(gold["ou_unc"])) < 2e-4
+
+
 def test_convex_upsample_vs_golden(ops_mod, gold, inp):
     h, w = gi.OPS_H, gi.OPS_W
     ou = torch.cat([pm(inp["occl_lr"]), pm(inp["unc_lr"]), torch.zeros(h * w, 1, device=DEV)], 1).contiguous()

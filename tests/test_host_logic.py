@@ -233,7 +233,40 @@ def test_keep_result_on_device_flag():
     tr = make_tracker(StubFlower(), deltas=(np.inf, 1), keep_result_on_device=True)
     tr.init(gi.id_image(0))
     m = tr.track(gi.id_image(1))
-    assert m.result is tr.memory[1]["result"]
+    stored = tr.memory[1]["result"]
+    assert m.result is not stored and torch.equal(m.result.flow, stored.flow)
+    m.result.flow.add_(1.0)                      # a consumer that edits its result in place ...
+    assert not torch.equal(m.result.flow, stored.flow)   # ... does not touch tracker state
+
+
+def test_missing_checkpoint_is_an_error():
+    """A configured but absent checkpoint raises like the reference's torch.load (MFT/raft.py:20-21);
+    synthetic weights need the explicit opt-in model=None + integer seed."""
+    from mft_amd.config import Config
+    from mft_amd.raft import RAFTWrapper
+    c = Config()
+    c.model = "checkpoints/does-not-exist.pth"
+    c.synthetic_weights_seed = 0
+    with pytest.raises(FileNotFoundError):
+        RAFTWrapper._load_weights(c)
+    c.model = None
+    c.synthetic_weights_seed = Config()           # "unset"
+    with pytest.raises(ValueError):
+        RAFTWrapper._load_weights(c)
+    c.synthetic_weights_seed = 3
+    assert len(RAFTWrapper._load_weights(c)) == 187
+
+
+def test_track_window_equals_track():
+    """track_window on one rank is track() frame by frame."""
+    a, b = make_tracker(StubFlower()), make_tracker(StubFlower())
+    a.init(gi.id_image(0)); b.init(gi.id_image(0))
+    ra = [a.track(gi.id_image(i)).result for i in range(1, 7)]
+    rb = [m.result for m in b.track_window([gi.id_image(i) for i in range(1, 4)])]
+    rb += [m.result for m in b.track_window([gi.id_image(i) for i in range(4, 7)])]
+    for x, y in zip(ra, rb):
+        assert torch.equal(x.flow, y.flow) and torch.equal(x.sigma, y.sigma)
+    assert sorted(a.memory) == sorted(b.memory) and a.current_frame_i == b.current_frame_i == 6
 
 
 # ---------------------------------------------------------------------------
@@ -241,14 +274,23 @@ def test_keep_result_on_device_flag():
 # ---------------------------------------------------------------------------
 
 def test_shard_plan():
-    from mft_amd.dist import shard_indices, slots_per_rank
-    assert shard_indices(7, 8, 7) == [] and shard_indices(7, 2, 1) == [1, 3, 5]
-    assert sorted(sum((shard_indices(7, 4, r) for r in range(4)), [])) == list(range(7))
-    assert slots_per_rank(7, 2) == 4 and slots_per_rank(7, 8) == 1 and slots_per_rank(3, 4) == 1
+    from mft_amd.dist import frame_owner, shard_indices, split_units
+    assert split_units(7, 8) == [(i, 1) for i in range(7)] + [(7, 0)]
+    assert split_units(7, 2) == [(0, 4), (4, 3)] and split_units(112, 8) == [(14 * r, 14) for r in range(8)]
+    assert shard_indices(7, 8, 7) == [] and shard_indices(7, 2, 1) == [4, 5, 6]
+    for K in (1, 7, 20, 140):
+        for G in (1, 2, 4, 8):
+            sh = split_units(K, G)
+            assert sorted(sum((list(range(o, o + c)) for o, c in sh), [])) == list(range(K))
+            assert max(c for _, c in sh) - min(c for _, c in sh) <= 1
+    assert [frame_owner(j, 4) for j in range(6)] == [0, 1, 2, 3, 0, 1]
 
 
 @pytest.mark.timeout(300)
-def test_delta_sharding_two_ranks_gloo(tmp_path):
+def test_window_sharding_two_ranks_gloo(tmp_path):
+    """World size 2 over gloo: the per-frame mode (L = 1), look-ahead windows (L = 8, ragged last
+    window) and the feature-exchanging path (L = 5) all reproduce the single-rank tracker bit for bit,
+    on every rank; with exchanged features no rank encodes a frame another rank owns."""
     script = REPO / "tests" / "dist_worker.py"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
     out = tmp_path / "out"
@@ -257,12 +299,17 @@ def test_delta_sharding_two_ranks_gloo(tmp_path):
            "--master-addr", "127.0.0.1", "--master-port", "29611", str(script), str(out)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
-    r0 = np.load(out / "rank0.npz")
-    r1 = np.load(out / "rank1.npz")
     single = np.load(out / "single.npz")
-    for k in single.files:
-        assert np.array_equal(r0[k], r1[k]), k           # replicas stay identical
-        assert np.array_equal(r0[k], single[k]), k       # and equal to the unsharded run
+    for mode in ("L1", "L8", "L5x"):
+        r0 = np.load(out / f"rank0_{mode}.npz")
+        r1 = np.load(out / f"rank1_{mode}.npz")
+        for k in single.files:
+            assert np.array_equal(r0[k], r1[k]), (mode, k)          # replicas stay identical
+            assert np.array_equal(r0[k], single[k]), (mode, k)      # and equal to the unsharded run
+    st = [np.load(out / f"rank{r}_L5x.npz") for r in range(2)]
+    # every window frame was encoded exactly once across the two ranks
+    assert int(st[0]["_encoded"]) + int(st[1]["_encoded"]) == int(st[0]["_frames"])
+    assert abs(int(st[0]["_my_units"]) - int(st[1]["_my_units"])) <= int(st[0]["_windows"])
 
 
 def oracle_flow_cache():

@@ -32,6 +32,7 @@ def main():
     a = ap.parse_args()
     conf = load_config(REPO / "configs" / "MFT_cfg.py")
     fc = conf.flow_config
+    fc.model = None
     fc.synthetic_weights_seed = 0
     fc.flow_iters = a.iters
     fc.async_encode = False

@@ -31,6 +31,23 @@ sys.path.insert(1, str(REF))
 
 cv2 = types.ModuleType("cv2")
 cv2.INTER_NEAREST = 0
+cv2.IMREAD_UNCHANGED = -1
+# The codec pin (gen_codec) needs to see what the reference hands to / takes from cv2's PNG coder: the stub
+# keeps the array given to imencode and returns it from imdecode (PNG is lossless, so this IS cv2's round trip).
+CV2_CAPTURED = []
+
+
+def _imencode(ext, arr):
+    assert ext == ".png"
+    CV2_CAPTURED.append(np.array(arr, copy=True))
+    return True, np.array([len(CV2_CAPTURED) - 1], np.int64)
+
+
+def _imdecode(buf, flags):
+    return CV2_CAPTURED[int(np.asarray(buf).reshape(-1)[0])].copy()
+
+
+cv2.imencode, cv2.imdecode = _imencode, _imdecode
 sys.modules["cv2"] = cv2
 
 import torch  # noqa: E402
@@ -159,6 +176,13 @@ def gen_compute_flow(model):
             out[f"{tag}_meta"] = np.array([H, W, iters, fa, fb])
             print(tag, "flow mean abs", float(flow.abs().mean()), "occl>thr", float((extra["occlusion"] > 0.02).float().mean()),
                   "sigma mean", float(extra["sigma"].mean()))
+        # (c) with an initial flow (MFT/raft.py:49-52 -> core/raft.py:153-154)
+        H, W, iters, fa, fb = 125, 187, 3, 0, 2
+        vid = SyntheticVideo(H, W, n_frames=8, seed=5)
+        fl = build_reference_flower(model, iters)
+        flow, extra = fl.compute_flow(vid[fa], vid[fb], mode="flow", init_flow=T(gi.init_flow_input(H, W)))
+        out["c_flow"], out["c_occl"], out["c_sigma"] = N(flow), N(extra["occlusion"]), N(extra["sigma"])
+        out["c_meta"] = np.array([H, W, iters, fa, fb])
     np.savez_compressed(OUT / "compute_flow.npz", **out)
 
 
@@ -172,6 +196,63 @@ class StubFlower:
         return T(flow), {"occlusion": T(occl), "sigma": T(sigma), "debug": None}
 
 
+class TrackRecorder:
+    """Records, for one reference MFT.track() call, the (left_id, right_id) pairs it requests
+    (get_flowou_with_cache, MFT/MFT.py:99-102) and the chained candidates in delta order (chain_results,
+    MFT/MFT.py:104), and recomputes the per-pixel selected candidate exactly like MFT/MFT.py:112-124
+    (stack -> -sigma -> -inf where occluded -> max(dim=0).indices).  The reference's functions are wrapped,
+    not changed."""
+
+    def __init__(self):
+        import MFT.MFT as refmod
+        self.refmod = refmod
+        self.orig_chain, self.orig_get = refmod.chain_results, refmod.get_flowou_with_cache
+        self.pairs, self.cands = [], []
+
+        def chain(L, R):
+            c = self.orig_chain(L, R)
+            self.cands.append(c)
+            return c
+
+        def get(flower, left_img, right_img, flow_init=None, cache=None, left_id=None, right_id=None, **kw):
+            self.pairs.append((int(left_id), int(right_id)))
+            return self.orig_get(flower, left_img, right_img, flow_init, cache, left_id, right_id, **kw)
+
+        refmod.chain_results, refmod.get_flowou_with_cache = chain, get
+
+    def close(self):
+        self.refmod.chain_results, self.refmod.get_flowou_with_cache = self.orig_chain, self.orig_get
+
+    def begin(self):
+        self.pairs, self.cands = [], []
+
+    def chosen(self, deltas, thr):
+        """deltas: the deltas that produced self.cands, in call order."""
+        order = sorted(range(len(deltas)), key=lambda i: 0 if np.isinf(deltas[i]) else deltas[i])
+        res = [self.cands[i] for i in order]
+        sig = torch.stack([r.sigma for r in res], 0)
+        occ = torch.stack([r.occlusion for r in res], 0)
+        scores = -sig
+        scores[occ > thr] = -float("inf")
+        return scores.max(dim=0, keepdim=True).indices[0, 0].numpy().astype(np.int8)
+
+
+def live_deltas(tr, frame_i):
+    """The deltas whose candidate MFT.track builds at frame_i, in C.deltas order (MFT/MFT.py:74-91)."""
+    out, used = [], []
+    for d in tr.C.deltas:
+        left = frame_i - d * tr.time_direction
+        if tr.is_before_start(left):
+            if not np.isinf(d):
+                continue
+            left = tr.start_frame_i
+        if int(left) in used:
+            continue
+        used.append(int(left))
+        out.append(d)
+    return out
+
+
 def gen_chain_and_sequence():
     out = {}
     # (1) bare chain_results on two stub results
@@ -182,14 +263,20 @@ def gen_chain_and_sequence():
     out["chain_invalid"] = c.invalid_mask().numpy()
     # (2) full init/track sequences with the stub flower: forward and backward
     keep = [1, 2, 3, 5, 9, 17, 33, 34, 43]
+    rec = TrackRecorder()
     for tag, (start, direction) in {"fwd": (0, +1), "bwd": (gi.SEQ_FRAMES - 1, -1)}.items():
         tr = build_reference_tracker(StubFlower())
         tr.init(gi.id_image(start), start_frame_i=start, time_direction=direction)
-        sums, keys = [], []
+        sums, keys, pairs = [], [], []
         for step in range(1, gi.SEQ_FRAMES):
             fid = start + direction * step
+            rec.begin()
             meta = tr.track(gi.id_image(fid))
             res = meta.result
+            pairs.append(np.array([l for l, r in rec.pairs] + [-1] * (7 - len(rec.pairs))))
+            assert all(r == fid for l, r in rec.pairs)
+            if step in keep:
+                out[f"{tag}_{step}_chosen"] = rec.chosen(live_deltas(tr, fid), tr.C.occlusion_threshold)
             sums.append(np.concatenate([gi.checksum(N(res.flow)), gi.checksum(N(res.occlusion)), gi.checksum(N(res.sigma))]))
             keys.append(np.array(sorted(tr.memory.keys()) + [-1] * (40 - len(tr.memory))))
             if step in keep:
@@ -198,6 +285,8 @@ def gen_chain_and_sequence():
         out[f"{tag}_checksums"] = np.stack(sums)
         out[f"{tag}_memory_keys"] = np.stack(keys)
         out[f"{tag}_keep"] = np.array(keep)
+        out[f"{tag}_left_ids"] = np.stack(pairs)          # requested left ids per step, in request order, -1 padded
+    rec.close()
     np.savez_compressed(OUT / "sequence_stub.npz", **out)
     print("sequence_stub.npz", sum(v.nbytes for v in out.values()) / 1e6, "MB")
 
@@ -211,20 +300,27 @@ def gen_e2e(model):
 
     tr = build_reference_tracker(fl)
     keep = [1, 3, 9, 33, 41]
+    rec = TrackRecorder()
     with torch.no_grad():
         tr.init(vid[0])
-        sums = []
+        sums, pairs = [], []
         for i in range(1, gi.E2E_FRAMES):
+            rec.begin()
             meta = tr.track(vid[i])
             res = meta.result
+            pairs.append(np.array([l for l, r in rec.pairs] + [-1] * (7 - len(rec.pairs))))
+            if i in keep:
+                out[f"f{i}_chosen"] = rec.chosen(live_deltas(tr, i), tr.C.occlusion_threshold)
             sums.append(np.concatenate([gi.checksum(N(res.flow)), gi.checksum(N(res.occlusion)), gi.checksum(N(res.sigma))]))
             if i in keep:
                 out[f"f{i}_flow"], out[f"f{i}_occl"], out[f"f{i}_sigma"] = N(res.flow), N(res.occlusion), N(res.sigma)
             if i % 10 == 0:
                 print("e2e frame", i, "occl frac", float((res.occlusion > 0.5).float().mean()),
                       "flow mean abs", float(res.flow.abs().mean()))
+    rec.close()
     out["checksums"] = np.stack(sums)
     out["keep"] = np.array(keep)
+    out["left_ids"] = np.stack(pairs)
     np.savez_compressed(OUT / "sequence_raft.npz", **out)
     print("sequence_raft.npz", sum(v.nbytes for v in out.values()) / 1e6, "MB")
 
@@ -243,6 +339,32 @@ def gen_results_api():
     out["invalid_mask"] = res.invalid_mask().numpy()
     np.savez_compressed(OUT / "results_api.npz", **out)
     print("results_api.npz", sum(v.nbytes for v in out.values()) / 1e3, "kB")
+
+
+def gen_codec():
+    """The flow-cache codec of the reference itself (write_flowou_X16 / read_flowou_X16, MFT/utils/io.py:495-563)
+    on seeded inputs: the uint8 (B, G, R) planes it hands to cv2.imencode, the per-channel (min, max) it pickles,
+    and what read_flowou_X16 makes of them again."""
+    import tempfile
+    from MFT.utils import io as refio
+    d = gi.codec_inputs()
+    out = {}
+    del CV2_CAPTURED[:]
+    with tempfile.TemporaryDirectory() as tmp:
+        path = str(Path(tmp) / "3--5.flowouX16.pkl")
+        refio.write_flowou_X16(path, d["flow"], d["occl"], d["sigma"])
+        import pickle
+        with open(path, "rb") as f:
+            pk = pickle.load(f)
+        names = ("flow_x", "flow_y", "occlusion", "sigma")
+        assert len(CV2_CAPTURED) == 4
+        out["bgr"] = np.stack(CV2_CAPTURED)                                   # [4, H, W, 3] uint8
+        out["lohi"] = np.array([[pk[n]["min"], pk[n]["max"]] for n in names], np.float32)
+        flow, occl, sigma = refio.read_flowou_X16(path)
+        out["dec_flow"], out["dec_occl"], out["dec_sigma"] = (np.asarray(a, np.float32) for a in (flow, occl, sigma))
+        assert flow.dtype == np.float32
+    np.savez_compressed(OUT / "codec.npz", **out)
+    print("codec.npz", sum(v.nbytes for v in out.values()) / 1e3, "kB")
 
 
 def gen_tapvid():
@@ -279,8 +401,10 @@ def gen_tapvid():
 
 if __name__ == "__main__":
     assert REF.exists(), "the reference is only mounted in the build container"
-    which = sys.argv[1:] or ["ops", "flow", "seq", "e2e", "tapvid", "results"]
-    if set(which) <= {"tapvid", "results"}:
+    which = sys.argv[1:] or ["ops", "flow", "seq", "e2e", "tapvid", "results", "codec"]
+    if set(which) <= {"tapvid", "results", "codec"}:
+        if "codec" in which:
+            gen_codec()
         if "tapvid" in which:
             gen_tapvid()
         if "results" in which:
@@ -299,3 +423,5 @@ if __name__ == "__main__":
         gen_tapvid()
     if "results" in which:
         gen_results_api()
+    if "codec" in which:
+        gen_codec()

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--gpu-cache-gb", type=float, default=64.0)
     a = ap.parse_args()
     conf = load_config(REPO / "configs" / "MFT_cfg.py")
+    conf.flow_config.model = None
     conf.flow_config.synthetic_weights_seed = 0
     conf.flow_config.flow_iters = a.iters
     conf.keep_result_on_device = True        # point read-out happens on the device
