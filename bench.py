@@ -14,6 +14,7 @@ Steady state.  The seven deltas are all live only from frame 33 on (MFT/MFT.py:7
 back to frame 1 there), so whatever --warmup is, an UNTIMED pre-roll tracks frames until every warm-up
 and timed frame has 7 flow pairs; the pair count is recorded inside the timed loop (min / mean / max in
 `config.workload` and `pairs_per_frame`) and the run fails rather than mislabel a ramp as steady state.
+(Pre-roll = frames 1..32 always, so warm-up and timed frames all carry 7 pairs.)
 
 Frames are resident in HBM before the timed region and results stay on the device; the PCIe-inclusive
 rate (numpy frames in, CPU results out) is reported separately as "host_io_fps".  For N > 1 the
@@ -66,10 +67,11 @@ def host_cores():
 
 def oracle_threads():
     """Threads for the CPU oracle legs.  The oracle is torch CPU ops on one 512x512 pair at a time
-    (M = 4096 rows per GEMM): it stops scaling long before a 256-core host is full -- the sweep in
-    profiles/r2_cpu_thread_sweep.txt (tools/cpu_thread_sweep.py) is fastest at 32-64 threads -- so the
-    default is min(host cores, 32); MFT_ORACLE_THREADS overrides."""
-    return max(1, min(host_cores(), int(os.environ.get("MFT_ORACLE_THREADS", "32"))))
+    (M = 4096 rows per GEMM): it stops scaling long before a 256-core host is full -- the sweep on the
+    GPU box's 256-core host (profiles/r2_cpu_thread_sweep.txt, tools/cpu_thread_sweep.py) runs a pair in
+    0.69 / 0.52 / 0.89 / 2.2 / 7.0 / 783 s at 8 / 16 / 32 / 64 / 128 / 256 threads -- so the default is
+    min(host cores, 16), the fastest; MFT_ORACLE_THREADS overrides."""
+    return max(1, min(host_cores(), int(os.environ.get("MFT_ORACLE_THREADS", "16"))))
 
 
 def build_tracker(args, sharded):
@@ -279,7 +281,7 @@ def main():
     window = (args.window if args.window > 0 else 3 * world) if sharded else 1
 
     from mft_amd.synth import SyntheticVideo
-    preroll = max(0, FIRST_FULL_FRAME - 1 - args.warmup)          # untimed: frames 1 .. preroll
+    preroll = FIRST_FULL_FRAME - 1                                # untimed: frames 1 .. 32; warm-up starts at frame 33
     n_io = 0 if (args.no_host_io or world > 1 or args.force_sharded) else max(4, args.steps // 2)
     n_prof = 0 if args.no_profile else args.steps
     n_frames = 1 + preroll + args.warmup + args.steps + n_prof + n_io

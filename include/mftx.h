@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MFTX_VERSION 100
+#define MFTX_VERSION 200
 
 #define MFTX_E_ARG (-1)      /* null pointer / non-positive size / unsupported shape */
 #define MFTX_E_ALIGN (-2)    /* pointer or leading dimension not 16-byte aligned */
@@ -58,17 +58,26 @@ int mftx_profile_end(double *ms, double *work, long long *count, int n);
 /* ---- a4 + a5: all-pairs correlation volume and its pyramid ---------------
  * Replaces CorrBlock.corr + CorrBlock.__init__ (MFT/RAFT/core/corr.py:14-28,
  * 53-69).  f1, f2: pixel-major feature maps [P][h*w][C] (C % 32 == 0).
- * lvl0..3: [P][h*w][h_l*w_l] with h_l = h >> l, w_l = w >> l (floor).
- * lvl0[p][i][j] = sum_c f1[p][i][c] * f2[p][j][c] / sqrt(C) on fp32 MFMA; levels
- * 1..3 are 2x2 means of the level below over the TARGET dims. */
+ * Level l holds, per pair and query cell i, the h_l x w_l map (h_l = h >> l, w_l = w >> l, floor) of
+ * lvl0[p][i][j] = sum_c f1[p][i][c] * f2[p][j][c] / sqrt(C) (fp32 MFMA) resp. the 2x2 means of the level
+ * below over the TARGET dims, all four written by ONE launch (the GEMM's epilogue pools).  Storage per
+ * query cell, stride[l] floats (mftx_corr_pyramid_layout):
+ *   levels 0, 1: 8 x 4-float blocks (x fastest, one 128-byte line each), block grid hb_l x wb_l, element
+ *                (y, x) at ((y >> 2) * wb_l + (x >> 3)) * 32 + (y & 3) * 8 + (x & 7); cells of the padded
+ *                block grid outside the level are unspecified (level 0: zero);
+ *   levels 2, 3: row-major [h_l][w_l], stride rounded up to a multiple of 4 floats.
+ * lvl_l must hold P*h*w*stride[l] floats, 16-byte aligned. */
 int mftx_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, int w,
                       float *lvl0, float *lvl1, float *lvl2, float *lvl3, void *stream);
+/* stride[4]: floats per query cell of each level; block_grid[4] = {hb_0, wb_0, hb_1, wb_1}. */
+int mftx_corr_pyramid_layout(int h, int w, long long *stride, int *block_grid);
 
 /* ---- a6: multi-scale 9x9 correlation lookup --------------------------------
  * Replaces CorrBlock.__call__ + bilinear_sampler (core/corr.py:30-51,
  * core/utils/utils.py:98-112).  coords: [P*h*w][2] (x, y) interleaved.
  * out: pixel-major [P*h*w][ld_out], channel l*81 + a*9 + b = level l sampled at
- * (x/2^l + a - 4, y/2^l + b - 4), bilinear, zeros outside. r must be 4. */
+ * (x/2^l + a - 4, y/2^l + b - 4), bilinear, zeros outside. r must be 4.
+ * lvl0..3 in the layout mftx_corr_pyramid writes. */
 int mftx_corr_lookup(const float *lvl0, const float *lvl1, const float *lvl2, const float *lvl3,
                      const float *coords, int P, int h, int w, int r,
                      float *out, int ld_out, void *stream);
@@ -119,12 +128,14 @@ int mftx_raft_workspace_layout(int P, int h, int w, size_t *offsets, int n);
  * applied).  flow_init (optional, may be NULL): [P*h*w][2] initial flow at 1/8
  * resolution, added to the start coordinates (core/raft.py:153-154).  Outputs are planar and UNPADDED: flow [P][2][H0][W0], occl
  * [P][1][H0][W0] (softmax channel 1), sigma [P][1][H0][W0] (sqrt(exp(u))), with
- * H0 = 8h - pad_top - pad_bottom etc.  flow_lr (optional) [P*h*w][2]. */
+ * H0 = 8h - pad_top - pad_bottom etc.  packed (optional, may be NULL): the same four values interleaved per
+ * pixel, [P][H0][W0][4] = (flow x, flow y, occl, sigma), the right-operand format of mftx_chain_select_packed.
+ * flow_lr (optional) [P*h*w][2]. */
 int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters,
                      const float *fmap1, const float *fmap2, const float *net, const float *inp,
                      const float *flow_init,
                      int pad_left, int pad_right, int pad_top, int pad_bottom,
-                     float *flow, float *occl, float *sigma, float *flow_lr,
+                     float *flow, float *occl, float *sigma, float *packed, float *flow_lr,
                      void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- a3: feature / context encoder (BasicEncoder, core/extractor.py:118-195) ---------
@@ -144,11 +155,12 @@ int mftx_encoder_forward(mftx_encoder *e, const uint8_t *img, int H0, int W0, fl
 /* ---- a10 + a12: convex 8x upsampling + post-processing ---------------------
  * Replaces RAFT.upsample_flow (core/raft.py:83-94) for the three heads and
  * MFT/raft.py:57-62.  flow_lr [M][2], ou [M][ld_ou] (occl logit0, logit1,
- * log-variance), mask pixel-major [M][576] (channel k*64 + sy*8 + sx). */
+ * log-variance), mask pixel-major [M][576] (channel k*64 + sy*8 + sx).
+ * packed (optional): [P][H0][W0][4] interleaved copy of the outputs (see mftx_raft_refine). */
 int mftx_convex_upsample(const float *flow_lr, const float *ou, int ld_ou, const float *mask,
                          int P, int h, int w,
                          int pad_left, int pad_right, int pad_top, int pad_bottom,
-                         float *flow, float *occl, float *sigma, void *stream);
+                         float *flow, float *occl, float *sigma, float *packed, void *stream);
 
 /* ---- a14: chain_results -----------------------------------------------------
  * Replaces chain_results (MFT/MFT.py:233-239) = FlowOUTrackingResult.chain +
@@ -177,6 +189,15 @@ int mftx_chain_select(int K,
                       const float *const *flowR, const float *const *occlR, const float *const *sigmaR,
                       float thr, int H, int W,
                       float *flowO, float *occlO, float *sigmaO, int8_t *chosen, void *stream);
+
+/* The same with the right operands (left_id -> current flows, fresh from mftx_raft_refine) in the packed
+ * per-pixel format [H][W][4] = (flow x, flow y, occl, sigma): each bilinear tap of the chain is one 16-byte
+ * gather.  Needs W % 4 == 0 and 16-byte aligned planes.  Bitwise equal to mftx_chain_select. */
+int mftx_chain_select_packed(int K,
+                             const float *const *flowL, const float *const *occlL, const float *const *sigmaL,
+                             const float *const *packedR,
+                             float thr, int H, int W,
+                             float *flowO, float *occlO, float *sigmaO, int8_t *chosen, void *stream);
 
 /* ---- 8f-2: flow-cache codec (".flowouX16" entries) -----------------------------
  * Replaces compress_channel / decompress_channel of write_flowou_X16 / read_flowou_X16

@@ -32,6 +32,17 @@ from .results import FlowOUTrackingResult
 logger = logging.getLogger(__name__)
 
 
+def is_packed(r):
+    """A right operand in the packed per-pixel format [H, W, 4] (fx, fy, occl, sigma)."""
+    return isinstance(r, torch.Tensor)
+
+
+def unpack_planes(r):
+    """packed [H, W, 4] -> (flow[2,H,W], occl[1,H,W], sigma[1,H,W]) (contiguous copies)."""
+    p = r.permute(2, 0, 1)
+    return p[0:2].contiguous(), p[2:3].contiguous(), p[3:4].contiguous()
+
+
 class HipBackend:
     """chain / select on libmftx (the only product backend)."""
 
@@ -45,7 +56,11 @@ class HipBackend:
 
     @staticmethod
     def chain_select(Ls, Rs, thr):
-        return ops.chain_select(Ls, Rs, thr, want_chosen=True)
+        """Rs: per candidate either the (flow, occl, sigma) planes or the packed [H, W, 4] tensor."""
+        W = Ls[0][0].shape[-1]
+        if all(is_packed(r) for r in Rs) and W % 4 == 0:
+            return ops.chain_select_packed(Ls, Rs, thr, want_chosen=True)
+        return ops.chain_select(Ls, [unpack_planes(r) if is_packed(r) else r for r in Rs], thr, want_chosen=True)
 
 
 class MFT():
@@ -120,6 +135,9 @@ class MFT():
         plan = self._plan(frame_i)
         rights = self._flows_for(plan, frame_i, input_img)
         lefts = [self.memory[left_id]['result'].planes() for _, left_id, _ in plan]
+        packed = [getattr(r, "packed", None) for r in rights]
+        if all(p is not None for p in packed):      # fresh from the engine: one 16-byte gather per chain tap
+            return self._finish_frame(frame_i, input_img, plan, lefts, packed)
         return self._finish_frame(frame_i, input_img, plan, lefts, [r.planes() for r in rights])
 
     def track_window(self, imgs):
@@ -149,10 +167,12 @@ class MFT():
         self.cleanup_memory()
         return meta
 
-    def _flows_for_pairs(self, pairs):
-        """[(left_id, left_img, right_id, right_img)] -> [(flow, occl, sigma)], one batched engine pass
-        when the flow plugin offers one, else the reference's per-pair call (MFT/MFT.py:223-225)."""
+    def _flows_for_pairs(self, pairs, packed_out=None):
+        """[(left_id, left_img, right_id, right_img)] -> [(flow, occl, sigma[, packed])], one batched engine
+        pass when the flow plugin offers one, else the reference's per-pair call (MFT/MFT.py:223-225)."""
         if hasattr(self.flower, "compute_pairs"):
+            if packed_out is not None and getattr(self.flower, "has_packed_output", False):
+                return self.flower.compute_pairs(pairs, packed_out=packed_out)
             return self.flower.compute_pairs(pairs)
         res = []
         for _, left_img, _, right_img in pairs:
@@ -179,12 +199,14 @@ class MFT():
                 out[i] = got
         if missing:
             res = self._flows_for_pairs([(plan[i][1], self.memory[plan[i][1]]['img'], right_id, input_img)
-                                         for i in missing])
-            for i, (f, o, s) in zip(missing, res):
+                                         for i in missing], packed_out=(self.img_W % 4 == 0) or None)
+            for i, r in zip(missing, res):
+                f, o, s = r[:3]
                 _, left_id, use_cache = plan[i]
                 if self.flow_cache is not None and use_cache:
                     self.flow_cache.write(left_id, right_id, f, o, s)
                 out[i] = FlowOUTrackingResult(f, o, s, validate=False)
+                out[i].packed = r[3] if len(r) > 3 else None
         return [out[i] for i in range(len(plan))]
 
     # --------------------------------------------------------------- memory

@@ -36,6 +36,7 @@ SIGNATURES = {
     "mftx_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
     "mftx_corr_pyramid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mftx_corr_pyramid_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "mftx_corr_lookup": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p]),
     "mftx_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "mftx_raft_create": (C.c_int, [_PP, C.c_int, C.POINTER(C.c_void_p)]),
@@ -45,7 +46,7 @@ SIGNATURES = {
     "mftx_raft_refine": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_int, C.c_int, C.c_int, C.c_int,
-                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
     "mftx_encoder_create": (C.c_int, [_PP, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mftx_encoder_destroy": (None, [C.c_void_p]),
@@ -53,11 +54,12 @@ SIGNATURES = {
     "mftx_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_size_t, C.c_void_p]),
     "mftx_convex_upsample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 7
-                             + [C.c_void_p] * 4),
+                             + [C.c_void_p] * 5),
     "mftx_chain": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int] + [C.c_void_p] * 4),
     "mftx_warp_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mftx_select": (C.c_int, [C.c_int, _PP, _PP, _PP, C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 5),
     "mftx_chain_select": (C.c_int, [C.c_int] + [_PP] * 6 + [C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "mftx_chain_select_packed": (C.c_int, [C.c_int] + [_PP] * 4 + [C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 5),
     "mftx_quantize_workspace_bytes": (C.c_size_t, []),
     "mftx_quantize_u16": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mftx_dequantize_u16": (C.c_int, [C.c_void_p, C.c_longlong, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),

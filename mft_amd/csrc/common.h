@@ -33,6 +33,32 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 
+// ---- correlation pyramid layout (per query cell) ------------------------------------
+// Levels 0 and 1 are stored in BLOCKS of 8 x 4 floats (x fastest; one 128-byte line each): the 10 x 10
+// lookup window then touches (1 + 9/8)(1 + 9/4) = 6.9 lines on average instead of 12.8 (row-major 64-wide
+// rows) / 10 (level 1).  Element (y, x) of level l < 2 lives at ((y >> 2) * wb[l] + (x >> 3)) * 32 +
+// (y & 3) * 8 + (x & 7).  The block grid is padded so that level 0 is made of whole SUPER-BLOCKS (2 x 2
+// blocks = 16 x 8 cells): one super-block is one N tile of the volume GEMM, whose epilogue also forms the
+// level-1 block and the 4 x 2 / 2 x 1 pieces of levels 2 / 3 it covers.  Levels 2 and 3 (<= 1 KiB per query
+// at 512 x 512) stay row-major [h_l][w_l]; every per-query stride is a multiple of 4 floats.
+struct PyramidLayout {
+    int h[4], w[4];          // level sizes (floor halving, core/corr.py:26-28)
+    int hb[2], wb[2];        // block grid of levels 0, 1
+    int sbh, sbw;            // super-block grid (= block grid of level 1)
+    long long stride[4];     // floats per query cell
+};
+inline PyramidLayout pyramid_layout(int h, int w) {
+    PyramidLayout L;
+    for (int l = 0; l < 4; ++l) { L.h[l] = h >> l; L.w[l] = w >> l; }
+    L.sbh = (h + 7) / 8; L.sbw = (w + 15) / 16;
+    L.hb[0] = 2 * L.sbh; L.wb[0] = 2 * L.sbw; L.hb[1] = L.sbh; L.wb[1] = L.sbw;
+    L.stride[0] = (long long)L.hb[0] * L.wb[0] * 32;
+    L.stride[1] = (long long)L.hb[1] * L.wb[1] * 32;
+    L.stride[2] = ((long long)L.h[2] * L.w[2] + 3) / 4 * 4;
+    L.stride[3] = ((long long)L.h[3] * L.w[3] + 3) / 4 * 4;
+    return L;
+}
+
 // ---- kernel launchers shared between the per-op exports and the RAFT engine
 int launch_conv(const mftx_conv_desc &d, hipStream_t s);
 int launch_conv_pair(const mftx_conv_desc &a, const mftx_conv_desc &b, hipStream_t s);   // two independent ReLU convs, one launch
@@ -47,12 +73,12 @@ struct GruEpilogue {
 int launch_conv_gru(const mftx_conv_desc &d, const GruEpilogue &g, hipStream_t s);
 bool conv_small_applicable(const mftx_conv_desc &d);
 int launch_conv_small(const mftx_conv_desc &d, hipStream_t s, float *accum = nullptr, int ld_accum = 0);
-int launch_corr_volume(const float *f1, const float *f2, int P, int C, int N, float *lvl0, hipStream_t s);
-int launch_corr_pool(const float *lvl0, int rows, int h, int w, float *lvl1, float *lvl2, float *lvl3, hipStream_t s);
+// all-pairs correlation volume + its 3 pooled levels in one launch (pyramid layout above)
+int launch_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, int w, float *const lvl[4], hipStream_t s);
 int launch_corr_lookup(const float *const lvl[4], const float *coords, int P, int h, int w,
                        float *out, int ld_out, hipStream_t s);
 int launch_convex_upsample(const float *flow_lr, const float *ou, int ld_ou, const float *mask,
                            int P, int h, int w, int pl, int pr, int pt, int pb,
-                           float *flow, float *occl, float *sigma, hipStream_t s);
+                           float *flow, float *occl, float *sigma, float *packed, hipStream_t s);
 
 }  // namespace mftx

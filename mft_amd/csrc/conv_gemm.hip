@@ -63,6 +63,10 @@ struct ConvArgs {
     long long a_bstride, w_bstride, o_bstride;  // per batch element
     unsigned a0_bytes, a1_bytes, w_bytes;       // buffer extents (per batch element)
     float *hx; int ld_hx; float *z; float *rh;  // GRU epilogues
+    // EPI_VOLUME only: feature grid and the pooled levels (pyramid layout of common.h; out = level 0)
+    int vh, vw, sbw, wb0;
+    float *lvl1, *lvl2, *lvl3;
+    long long s0, s1, s2, s3;                   // floats per query cell, per level
 };
 
 // Tuning builds only (-DMFTX_ABLATE=n): 1 no global loads, 2 + no barriers, 3 + no LDS reads; 4 no W loads, 5 no A loads, 6 A loads for every fifth chunk only.  A
@@ -120,6 +124,95 @@ __device__ __forceinline__ void wait_vmcnt() {   // counted wait: leaves N LDS-D
 #define MFTX_MINW1 4      // 128 registers: nothing spills; 5 (96 registers, spills in the GRU epilogues) measures 0.5 % slower
 #endif
 constexpr int min_waves(int wave_tiles) { return wave_tiles == 1 ? MFTX_MINW1 : wave_tiles == 2 ? 3 : 2; }
+
+// Epilogue of the correlation-volume GEMM: one wave holds 32 query rows x one super-block (2 x 2 blocks of
+// 8 x 4 target cells, 128 columns) in acc[4].  The tile goes through the wave's private 16 KiB of LDS once:
+//   level 0: read back as float4 -> 512-byte runs per query (global_store_dwordx4, 16 instead of 64 stores);
+//   level 1: 2 x 2 means of level 0 in ATen's order ((a + b) + c + d) * 0.25 -> exactly one 8 x 4 block per
+//            query, stored as a full 128-byte line, and kept in LDS for
+//   level 2 (4 x 2 per super-block) and level 3 (2 x 1), formed the same way from the level below --
+// bit-identical to avg_pool2d applied level by level (core/corr.py:26-28); no second pass over the volume.
+__device__ __forceinline__ float pool4(const float2 top, const float2 bot) {
+    return (((top.x + top.y) + bot.x) + bot.y) * 0.25f;
+}
+
+__device__ __forceinline__ void volume_epilogue(const ConvArgs &p, const f32x16 (&acc)[4], float *st, int lane,
+                                                int q0, int sb, int bz) {
+    const int Nq = p.M;                                       // query cells per pair
+    const int sby = sb / p.sbw, sbx = sb - sby * p.sbw;
+    // ---- stage: st[row][128], row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column = 32 j + (lane & 31)
+    {
+        float *w = st + (4 * (lane >> 5)) * 128 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                w[((r & 3) + 8 * (r >> 2)) * 128 + 32 * j] = acc[j][r] * p.out_scale;
+    }
+    const long long qbase = (long long)bz * Nq;
+    // ---- level 0: float4 pieces; piece c4 of a row = block (c4 >> 3), floats 4 (c4 & 7) .. +3 of it
+    {
+        float *out0 = p.out;
+#pragma unroll
+        for (int t0 = 0; t0 < 16; t0 += 4) {          // four LDS reads in flight, then their four stores
+            f32x4 v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const f32x4 *>(st + ((t0 + t) * 64 + lane) * 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int f = (t0 + t) * 64 + lane, row = f >> 5, c4 = f & 31, jb = c4 >> 3;
+                const int q = q0 + row;
+                if (q < Nq) {
+                    float *dst = out0 + (qbase + q) * p.s0 +
+                                 ((long long)(2 * sby + (jb >> 1)) * p.wb0 + 2 * sbx + (jb & 1)) * 32 + (c4 & 7) * 4;
+                    *reinterpret_cast<f32x4 *>(dst) = v[t];
+                }
+            }
+        }
+    }
+    // ---- level 1: 16 values per lane; lanes of a half-wave = the 32 cells of the level-1 block of one query
+    float l1[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int e = t * 64 + lane, row = e >> 5, pos = e & 31, y1 = pos >> 3, x1 = pos & 7;
+        const float *s = st + row * 128 + ((y1 >> 1) * 2 + (x1 >> 2)) * 32 + (y1 & 1) * 16 + (x1 & 3) * 2;
+        l1[t] = pool4(*reinterpret_cast<const float2 *>(s), *reinterpret_cast<const float2 *>(s + 8));
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int e = t * 64 + lane, row = e >> 5, pos = e & 31;
+        const int q = q0 + row;
+        if (q < Nq) p.lvl1[(qbase + q) * p.s1 + ((long long)sby * p.sbw + sbx) * 32 + pos] = l1[t];
+    }
+    // level 1 -> LDS [row][32] (overlays the level-0 stage: this wave's reads of it are complete, LDS
+    // operations of one wave execute in order)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) st[t * 64 + lane] = l1[t];
+    // ---- level 2: 4 x 2 per query, 4 values per lane; kept at st[1024 + row * 8 + ..]
+    const int h2 = p.vh >> 2, w2 = p.vw >> 2, h3 = p.vh >> 3, w3 = p.vw >> 3;
+    float l2[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int e = t * 64 + lane, row = e >> 3, y2 = (e >> 2) & 1, x2 = e & 3;
+        const float *s = st + row * 32 + y2 * 16 + x2 * 2;
+        l2[t] = pool4(*reinterpret_cast<const float2 *>(s), *reinterpret_cast<const float2 *>(s + 8));
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int e = t * 64 + lane, row = e >> 3, y2 = 2 * sby + ((e >> 2) & 1), x2 = 4 * sbx + (e & 3);
+        const int q = q0 + row;
+        if (q < Nq && y2 < h2 && x2 < w2) p.lvl2[(qbase + q) * p.s2 + (long long)y2 * w2 + x2] = l2[t];
+        st[1024 + e] = l2[t];
+    }
+    // ---- level 3: 2 x 1 per query, one value per lane
+    {
+        const int row = lane >> 1, x3l = lane & 1;
+        const float *s = st + 1024 + row * 8 + x3l * 2;
+        const float v = pool4(*reinterpret_cast<const float2 *>(s), *reinterpret_cast<const float2 *>(s + 4));
+        const int q = q0 + row, x3 = 2 * sbx + x3l;
+        if (q < Nq && sby < h3 && x3 < w3) p.lvl3[(qbase + q) * p.s3 + (long long)sby * w3 + x3] = v;
+    }
+}
 
 // MT = 32: each wave owns 32x32 outputs per MFMA tile (v_mfma_f32_32x32x2_f32).  MT = 16: 16x16 outputs
 // (v_mfma_f32_16x16x4_f32), for small M: a 32x64 workgroup tile still keeps 8 waves -- every SIMD -- busy,
@@ -234,8 +327,18 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
     unsigned woff[RB];                       // byte offsets into W, +128 B per chunk (W is [n][tap][cin_pad])
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        const int n = n0 + srow + RPP * i;
-        woff[i] = (n < p.w_rows && srow + RPP * i < BN) ? (unsigned)n * ktot_b + col4 * 4u : OOB;
+        if constexpr (EPI == EPI_VOLUME) {
+            // N tile = one super-block (16 x 8 target cells) of the blocked level 0: tile column c holds
+            // block (c >> 6, (c >> 5) & 1) of the 2 x 2, cell (y, x) = ((c & 31) >> 3, c & 7) inside it --
+            // each 32-column MFMA tile is one 8 x 4 block, i.e. one 128-byte line of the output per query.
+            const int sb = n0 / BN, c = srow + RPP * i;
+            const int ty = 8 * (sb / p.sbw) + 4 * (c >> 6) + ((c & 31) >> 3);
+            const int tx = 16 * (sb % p.sbw) + 8 * ((c >> 5) & 1) + (c & 7);
+            woff[i] = (ty < p.vh && tx < p.vw) ? (unsigned)(ty * p.vw + tx) * ktot_b + col4 * 4u : OOB;   // outside: zeros
+        } else {
+            const int n = n0 + srow + RPP * i;
+            woff[i] = (n < p.w_rows && srow + RPP * i < BN) ? (unsigned)n * ktot_b + col4 * 4u : OOB;
+        }
     }
     unsigned acell[RA];                      // this tap's source cell of each row, or OOB (conv halo / M tail)
     unsigned acur[RA];                       // byte offsets of the NEXT chunk to fetch, +128 B per chunk inside a run
@@ -397,6 +500,13 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
     // element's loads and serialises 16 x (load - wait - store - wait): ~10 us per tile, fully
     // exposed when a CU has a single tile (one flow pair per GPU).
     // MT = 32: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), r < 16;  MT = 16: col = lane & 15, row = 4 (lane >> 4) + r, r < 4
+    if constexpr (EPI == EPI_VOLUME) {
+        static_assert(MT == 32 && TM == 1 && TN == 4 && WN == 1 && BN == 128, "volume tile: 32 queries x one super-block per wave");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        block_barrier();                      // every wave is done with the ring: it becomes epilogue staging
+        volume_epilogue(p, acc[0], smem + wid * 4096, lane, m0 + wm * 32, n0 / BN, bz);
+        continue;
+    }
     const int col_l = lane & (MT - 1);
     const int row_h = MT == 32 ? 4 * (lane >> 5) : 4 * (lane >> 4);
     auto row_of = [](int r) { return MT == 32 ? (r & 3) + 8 * (r >> 2) : r; };
@@ -487,7 +597,7 @@ static int num_cus() {
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, int MT = 32>
-static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) {
+static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat, double work = -1.0) {
     constexpr size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
     static bool attr_set = false;
     auto kern = conv_gemm_kernel<BM, BN, WM, WN, EPI, MT>;
@@ -507,7 +617,7 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) 
     const long long slots = (long long)num_cus() * resident;
     dim3 grid((unsigned)(n_virtual < slots ? n_virtual : slots));
     // algorithmic flops: real (unpadded) reduction length
-    ProfScope prof(cat, s, 2.0 * a.M * a.N * (double)(a.kh * a.kw) * (a.c0 + a.c1) * batch);
+    ProfScope prof(cat, s, work >= 0 ? work : 2.0 * a.M * a.N * (double)(a.kh * a.kw) * (a.c0 + a.c1) * batch);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, args);
     return check_launch("conv_gemm");
 }
@@ -645,21 +755,26 @@ int launch_conv_gru(const mftx_conv_desc &d, const GruEpilogue &g, hipStream_t s
     return dispatch(a, g.mode == 1 ? EPI_GRU_ZR : EPI_GRU_Q, 1, s, PC_CONV_GEMM);
 }
 
-// lvl0[p][i][j] = <f1[p][i][:], f2[p][j][:]> / sqrt(C)
-int launch_corr_volume(const float *f1, const float *f2, int P, int C, int N, float *lvl0, hipStream_t s) {
-    if ((long long)N * C * 4 > 0x7fffffffLL) return fail(MFTX_E_ARG, "corr_volume: feature map exceeds 2 GiB");
+// lvl[0][p][i][.] = <f1[p][i][:], f2[p][j][:]> / sqrt(C) over all target cells j (blocked layout), and the
+// three pooled levels, in one launch (core/corr.py:14-28, 53-69)
+int launch_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, int w, float *const lvl[4], hipStream_t s) {
+    const int N = h * w;
+    if ((long long)N * C * 4 > 0x7fffffffLL) return fail(MFTX_E_ARG, "corr_pyramid: feature map exceeds 2 GiB");
+    const PyramidLayout L = pyramid_layout(h, w);
     ConvArgs a{};
     a.a0 = f1; a.lda0 = C; a.c0 = C; a.c1 = 0; a.a1 = nullptr; a.lda1 = 0;
-    a.w = f2; a.bias = nullptr; a.out = lvl0; a.ldo = N;
-    a.M = N; a.N = N; a.h = 1; a.wd = N; a.kh = 1; a.kw = 1; a.cin_pad = C;
+    a.w = f2; a.bias = nullptr; a.out = lvl[0]; a.ldo = 0;
+    a.M = N; a.N = L.sbh * L.sbw * 128; a.h = 1; a.wd = N; a.kh = 1; a.kw = 1; a.cin_pad = C;
     a.stride = 1; a.hin = 1; a.win = N; a.pad_y = 0; a.pad_x = 0;
     a.w_rows = N;
     a.act = 0; a.out_scale = 1.0f / sqrtf((float)C);
-    a.a_bstride = (long long)N * C; a.w_bstride = (long long)N * C; a.o_bstride = (long long)N * N;
+    a.a_bstride = (long long)N * C; a.w_bstride = (long long)N * C; a.o_bstride = 0;   // the epilogue addresses by batch itself
     a.a0_bytes = (unsigned)((long long)N * C * 4); a.a1_bytes = 0; a.w_bytes = a.a0_bytes;
-    // measured (tools/bench_corr.py): 128x64 beats 128x128 by 3 % at 64x64 cells and 5 % at 136x240, 64x64 ties it
-    if (N >= 1024) return launch_cfg<128, 64, 2, 2, EPI_VOLUME>(a, P, s, PC_CORR_VOLUME);
-    return launch_cfg<64, 64, 2, 2, EPI_VOLUME>(a, P, s, PC_CORR_VOLUME);
+    a.vh = h; a.vw = w; a.sbw = L.sbw; a.wb0 = L.wb[0];
+    a.lvl1 = lvl[1]; a.lvl2 = lvl[2]; a.lvl3 = lvl[3];
+    a.s0 = L.stride[0]; a.s1 = L.stride[1]; a.s2 = L.stride[2]; a.s3 = L.stride[3];
+    // one wave = 32 queries x one super-block (128 columns): 128 x 128 tiles of four waves stacked along M
+    return launch_cfg<128, 128, 4, 1, EPI_VOLUME>(a, P, s, PC_CORR_VOLUME, 2.0 * N * N * (double)C * P);
 }
 
 }  // namespace mftx

@@ -3,11 +3,9 @@
 // of the fused occlusion/uncertainty heads (core/update.py:17-75, 256 -> 2 + 1).
 //
 // An MFMA tile would be >= 87 % padding here (N = 2 of 32 columns), so this is a
-// VALU kernel: one wave walks a horizontal strip of cells; lane l owns channels
-// 4l..4l+3, keeps its 9 x N x 4 weights in registers for the whole strip, slides
-// a 3x3 window of float4 activations along the row (3 new loads per cell instead
-// of 9) and reduces the N partial sums across the wave with xor shuffles.
-// Reads are 1 KiB-coalesced per (row, column); traffic is 3 (len + 2) / len x the input map.
+// VALU kernel (see the kernel's comment).  Reads are 1 KiB-coalesced per (row, column);
+// traffic is 3 (len + 2) / len x the input map, nearly all of it L2 hits (the
+// producing GEMM has just written the 29 MB map).
 #include "common.h"
 #include "profile.h"
 #include <cstdlib>
@@ -15,12 +13,35 @@
 namespace mftx {
 
 
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
+// One wave per strip of SMALL_STRIP cells of one row.  Lane l owns input channels 4l..4l+3.
+//   * every load of the strip -- 3 rows x (strip + 2) columns of float4, raw buffer loads whose offset is
+//     out of range on the zero-padding border (the hardware returns zeros, no branches) -- is issued before
+//     the first use: one memory round trip per strip (the first version walked the strip column by column and
+//     paid the L2 latency 16 times; 48 us for a 29 MB read);
+//   * the 9 x N x 4 weights of a lane sit in LDS (shared by the block's 4 waves), read as float4 when used;
+//   * each lane accumulates its 4-channel partial sums for all strip x N outputs, and ONE transposing butterfly
+//     reduces them across the wave: at every step a lane keeps half of its values and trades the other half with
+//     its partner (lane ^ 32, ^ 16, ...), so 8 N values take 8 N - 1 + (a few) shuffles instead of 6 per
+//     value, and lane 4 v ends up with output v = cell * N + n.  Fixed order: results do not depend on batch or grid.
+// strip length: 8 cells for N <= 2 (the flow head, 12 launches per refinement), 4 for N = 3, 4 (the OU heads, one launch):
+// keeps 3 x (strip + 2) float4 columns + strip x N partial sums within the register budget
+constexpr int small_strip(int n) { return n <= 2 ? 8 : 4; }
+
 template <int N>
-__global__ __launch_bounds__(256) void conv3x3_small_kernel(const float *__restrict__ x, int ldx,
+__global__ __launch_bounds__(256, 2) void conv3x3_small_kernel(const float *__restrict__ x, int ldx, unsigned x_bytes,
                                                             const float *__restrict__ wpk,   // [>=N][9][256]
                                                             const float *__restrict__ bias, float *__restrict__ out,
-                                                            int ldo, int P, int h, int w, int strip_len, int strips_per_row,
+                                                            int ldo, int P, int h, int w, int strips_per_row,
                                                             float *__restrict__ accum, int ld_accum) {
+    constexpr int S = small_strip(N);
+    constexpr int NP = N <= 2 ? 2 : 4;                  // values per cell in the reduction (power of two)
+    constexpr int V = S * NP;
+    __shared__ __attribute__((aligned(16))) float wsm[9 * N * 256];
+    for (int i = threadIdx.x; i < 9 * N * 64; i += 256)
+        reinterpret_cast<f32x4s *>(wsm)[i] = reinterpret_cast<const f32x4s *>(wpk)[i];     // [n][tap][256] as packed
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);          // global wave id
     const int total = P * h * strips_per_row;
@@ -28,63 +49,67 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(const float *__restr
     const int strip = gw % strips_per_row;
     const int rowid = gw / strips_per_row;                        // img*h + y
     const int y = rowid % h;
-    const long long img_base = (long long)(rowid / h) * h * w;
-    const int x0 = strip * strip_len;
-    const int x1 = min(x0 + strip_len, w);
+    const int img_base = (rowid / h) * h * w;
+    const int x0 = strip * S;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, x_bytes, 0x00020000);
 
-    float4 wt[9][N];
+    f32x4s col[3][S + 2];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int r = 0; r < 3; ++r) {
+        const int yy = y + r - 1;
+        const bool yok = yy >= 0 && yy < h;
 #pragma unroll
-        for (int n = 0; n < N; ++n)
-            wt[t][n] = *reinterpret_cast<const float4 *>(wpk + ((long long)n * 9 + t) * 256 + lane * 4);
-    // lane t * N + n keeps output channel n of the strip's cell t: one store pass after the loop (a store
-    // inside it would sit between the loads of consecutive cells and drain vmcnt every time)
-    const float bb = bias != nullptr ? bias[lane % N] : 0.f;
-    float keep = 0.f;
-    const bool mine = lane < (x1 - x0) * N;
-    const long long my_cell = img_base + (long long)y * w + x0 + lane / N;
-    // the value to accumulate into is fetched now, so that its latency is gone by the end of the strip
-    const float old = (mine && accum != nullptr) ? accum[my_cell * ld_accum + lane % N] : 0.f;
-
-    struct Col { float4 r0, r1, r2; };
-    const bool y0ok = y - 1 >= 0, y2ok = y + 1 < h;
-    auto ld = [&](bool ok, int yy, int xx) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v = *reinterpret_cast<const float4 *>(x + (img_base + (long long)yy * w + xx) * ldx + lane * 4);
-        return v;
-    };
-    auto load_col = [&](int xx) {
-        const bool xok = xx >= 0 && xx < w;
-        Col c;
-        c.r0 = ld(xok && y0ok, y - 1, xx);
-        c.r1 = ld(xok, y, xx);
-        c.r2 = ld(xok && y2ok, y + 1, xx);
-        return c;
-    };
-    auto dot4 = [](const float4 &a, const float4 &b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; };
-    Col c0 = load_col(x0 - 1), c1 = load_col(x0);      // columns x-1, x; x+1 is loaded per step
-    for (int xc = x0; xc < x1; ++xc) {
-        const Col c2 = load_col(xc + 1);
-        float acc[N];
-#pragma unroll
-        for (int n = 0; n < N; ++n) {
-            float a = dot4(c0.r0, wt[0][n]) + dot4(c1.r0, wt[1][n]) + dot4(c2.r0, wt[2][n]);
-            a += dot4(c0.r1, wt[3][n]) + dot4(c1.r1, wt[4][n]) + dot4(c2.r1, wt[5][n]);
-            a += dot4(c0.r2, wt[6][n]) + dot4(c1.r2, wt[7][n]) + dot4(c2.r2, wt[8][n]);
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
-            acc[n] = a;
+        for (int c = 0; c < S + 2; ++c) {
+            const int xx = x0 + c - 1;
+            const bool ok = yok && xx >= 0 && xx < w;
+            const unsigned off = ok ? ((unsigned)(img_base + yy * w + xx) * (unsigned)ldx + (unsigned)lane * 4u) * 4u : 0x80000000u;
+            col[r][c] = __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
         }
+    }
+    // the value to accumulate into is fetched now, so that its latency is gone by the end of the strip
+    const int v_mine = lane >> 2;                                  // output this lane ends up with (if lane % 4 == 0)
+    const int t_mine = v_mine / NP, n_mine = v_mine % NP;
+    const bool mine = (lane & 3) == 0 && n_mine < N && x0 + t_mine < w;
+    const long long my_cell = (long long)img_base + (long long)y * w + x0 + t_mine;
+    const float old = (mine && accum != nullptr) ? accum[my_cell * ld_accum + n_mine] : 0.f;
+    const float bb = (mine && bias != nullptr) ? bias[n_mine] : 0.f;
+
+    float v[V];
 #pragma unroll
-        for (int n = 0; n < N; ++n)
-            if (lane == (xc - x0) * N + n) keep = acc[n] + bb;
-        c0 = c1;
-        c1 = c2;
+    for (int i = 0; i < V; ++i) v[i] = 0.f;
+    auto dot4 = [](const f32x4s &a, const f32x4s &b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; };
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                const f32x4s wv = *reinterpret_cast<const f32x4s *>(wsm + ((n * 9 + r * 3 + kx) * 256 + lane * 4));
+#pragma unroll
+                for (int t = 0; t < S; ++t) v[t * NP + n] += dot4(col[r][t + kx], wv);
+            }
+    // transposing butterfly: V values -> 1 per lane
+    int cnt = V;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const bool upper = (lane & off) != 0;
+        if (cnt > 1) {
+            const int half = cnt / 2;
+#pragma unroll
+            for (int i = 0; i < half; ++i) {
+                const float send = upper ? v[i] : v[i + half];
+                const float keep = upper ? v[i + half] : v[i];
+                v[i] = keep + __shfl_xor(send, off);
+            }
+            cnt = half;
+        } else {
+            v[0] += __shfl_xor(v[0], off);
+        }
     }
     if (mine) {
-        out[my_cell * ldo + lane % N] = keep;
-        if (accum != nullptr) accum[my_cell * ld_accum + lane % N] = old + keep;   // coords1 += delta_flow (core/raft.py:184)
+        const float keep = v[0] + bb;
+        out[my_cell * ldo + n_mine] = keep;
+        if (accum != nullptr) accum[my_cell * ld_accum + n_mine] = old + keep;   // coords1 += delta_flow (core/raft.py:184)
     }
 }
 
@@ -96,19 +121,16 @@ bool conv_small_applicable(const mftx_conv_desc &d) {
 // accum (optional, [cells][ld_accum]): the N outputs are also added to it -- the flow head's last layer
 // updates coords1 in the same pass instead of a separate add kernel.
 int launch_conv_small(const mftx_conv_desc &d, hipStream_t s, float *accum, int ld_accum) {
-    // Cells per wave (measured, tools/bench_small.py): 16 at 7 pairs (20.5 us; 3 -> 24.1 us: the halo
-    // columns of short strips are re-read), 8 when one or two pairs leave the chip short of waves
-    // (13.7 -> 9.9 us at one pair).
-    static const int forced = [] { const char *e = getenv("MFTX_SMALL_STRIP"); return e ? atoi(e) : 0; }();
     const long long cells = (long long)d.P * d.h * d.w;
-    const int strip_len = forced > 0 ? forced : (cells >= 16384 ? 16 : 8);
-    const int strips = cdiv(d.w, strip_len);
+    if (cells * d.lda0 * 4 > 0x7fffffffLL) return fail(MFTX_E_ARG, "conv3x3_small: activation operand exceeds 2 GiB");
+    const int strips = cdiv(d.w, small_strip(d.N));
     const int waves = d.P * d.h * strips;
+    const unsigned x_bytes = (unsigned)(((cells - 1) * d.lda0 + 256) * 4);
     dim3 grid(cdiv(waves, 4));
     ProfScope prof(PC_CONV_SMALL, s, 2.0 * d.P * d.h * d.w * d.N * 9.0 * 256.0);
 #define SN_LAUNCH(NN)                                                                                              \
-    hipLaunchKernelGGL(conv3x3_small_kernel<NN>, grid, dim3(256), 0, s, d.a0, d.lda0, d.wpk, d.bias, d.out, d.ldo, \
-                       d.P, d.h, d.w, strip_len, strips, accum, ld_accum)
+    hipLaunchKernelGGL(conv3x3_small_kernel<NN>, grid, dim3(256), 0, s, d.a0, d.lda0, x_bytes, d.wpk, d.bias, d.out, \
+                       d.ldo, d.P, d.h, d.w, strips, accum, ld_accum)
     switch (d.N) {
         case 1: SN_LAUNCH(1); break;
         case 2: SN_LAUNCH(2); break;

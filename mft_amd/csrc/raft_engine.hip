@@ -112,7 +112,8 @@ static Workspace carve(void *base, int P, int h, int w) {
         off += (floats * sizeof(float) + 255) & ~size_t(255);
         return p;
     };
-    for (int l = 0; l < 4; ++l) ws.lvl[l] = take(M * (size_t)(h >> l) * (size_t)(w >> l));
+    const PyramidLayout L = pyramid_layout(h, w);
+    for (int l = 0; l < 4; ++l) ws.lvl[l] = take(M * (size_t)L.stride[l]);
     ws.coords1 = take(M * 2);
     ws.corr = take(M * 324);
     ws.cor1 = take(M * 256);
@@ -198,8 +199,8 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
                                 const float *fmap2, const float *net, const float *inp, const float *flow_init,
                                 int pad_left,
                                 int pad_right, int pad_top, int pad_bottom, float *flow, float *occl,
-                                float *sigma, float *flow_lr_out, void *workspace, size_t workspace_bytes,
-                                void *stream) {
+                                float *sigma, float *packed, float *flow_lr_out, void *workspace,
+                                size_t workspace_bytes, void *stream) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_refine: bad handle");
     if (!fmap1 || !fmap2 || !net || !inp || !flow || !occl || !sigma || !workspace)
         return fail(MFTX_E_ARG, "raft_refine: null pointer");
@@ -220,8 +221,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     const float *const *W = r->w;
 
     // correlation volume + pyramid (core/corr.py:14-28)
-    TRY(launch_corr_volume(fmap1, fmap2, P, 256, N, ws.lvl[0], s));
-    TRY(launch_corr_pool(ws.lvl[0], M, h, w, ws.lvl[1], ws.lvl[2], ws.lvl[3], s));
+    TRY(launch_corr_pyramid(fmap1, fmap2, P, 256, h, w, ws.lvl, s));
     {
         const long long slots = (long long)M * 64;
         ProfScope prof(PC_GLUE, s, 0);
@@ -303,7 +303,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         TRY(launch_conv(conv_desc(ws.ouin, 712, 712, nullptr, 0, 0, W[W_OU1], W[B_OU1], ws.ouh, 256, P, h, w, 256, 3, 3, 1), s));
         TRY(launch_conv(conv_desc(ws.ouh, 256, 256, nullptr, 0, 0, W[W_OU2], W[B_OU2], ws.ou, 4, P, h, w, 3, 3, 3, 0), s));
         TRY(launch_convex_upsample(flow_lr, ws.ou, 4, ws.mask, P, h, w, pad_left, pad_right, pad_top, pad_bottom,
-                                   flow, occl, sigma, s));
+                                   flow, occl, sigma, packed, s));
     }
     return 0;
 }
@@ -316,9 +316,18 @@ extern "C" int mftx_corr_pyramid(const float *f1, const float *f2, int P, int C,
     if (!f1 || !f2 || !lvl0 || !lvl1 || !lvl2 || !lvl3) return fail(MFTX_E_ARG, "corr_pyramid: null pointer");
     if (P <= 0 || C <= 0 || C % 32 || h < 8 || w < 8) return fail(MFTX_E_ARG, "corr_pyramid: need C %% 32 == 0, h, w >= 8");
     if (!aligned16(f1) || !aligned16(f2)) return fail(MFTX_E_ALIGN, "corr_pyramid: features must be 16-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
-    TRY(launch_corr_volume(f1, f2, P, C, h * w, lvl0, s));
-    return launch_corr_pool(lvl0, P * h * w, h, w, lvl1, lvl2, lvl3, s);
+    if (!aligned16(lvl0) || !aligned16(lvl1) || !aligned16(lvl2) || !aligned16(lvl3))
+        return fail(MFTX_E_ALIGN, "corr_pyramid: levels must be 16-byte aligned");
+    float *const lv[4] = {lvl0, lvl1, lvl2, lvl3};
+    return launch_corr_pyramid(f1, f2, P, C, h, w, lv, (hipStream_t)stream);
+}
+
+extern "C" int mftx_corr_pyramid_layout(int h, int w, long long *stride, int *block_grid) {
+    if (h < 8 || w < 8 || !stride || !block_grid) return fail(MFTX_E_ARG, "corr_pyramid_layout: bad arguments");
+    const PyramidLayout L = pyramid_layout(h, w);
+    for (int l = 0; l < 4; ++l) stride[l] = L.stride[l];
+    block_grid[0] = L.hb[0]; block_grid[1] = L.wb[0]; block_grid[2] = L.hb[1]; block_grid[3] = L.wb[1];
+    return 0;
 }
 
 extern "C" int mftx_corr_lookup(const float *lvl0, const float *lvl1, const float *lvl2, const float *lvl3,
@@ -327,6 +336,7 @@ extern "C" int mftx_corr_lookup(const float *lvl0, const float *lvl1, const floa
     if (!lvl0 || !lvl1 || !lvl2 || !lvl3 || !coords || !out) return fail(MFTX_E_ARG, "corr_lookup: null pointer");
     if (r != 4) return fail(MFTX_E_ARG, "corr_lookup: only radius 4 (RAFT basic) is built");
     if (P <= 0 || h < 8 || w < 8 || ld_out < 324) return fail(MFTX_E_ARG, "corr_lookup: bad sizes");
+    if (!aligned16(lvl0) || !aligned16(lvl1)) return fail(MFTX_E_ALIGN, "corr_lookup: levels 0 and 1 must be 16-byte aligned");
     const float *lv[4] = {lvl0, lvl1, lvl2, lvl3};
     return launch_corr_lookup(lv, coords, P, h, w, out, ld_out, (hipStream_t)stream);
 }
@@ -338,9 +348,9 @@ extern "C" int mftx_conv2d(const mftx_conv_desc *d, void *stream) {
 
 extern "C" int mftx_convex_upsample(const float *flow_lr, const float *ou, int ld_ou, const float *mask, int P,
                                     int h, int w, int pad_left, int pad_right, int pad_top, int pad_bottom,
-                                    float *flow, float *occl, float *sigma, void *stream) {
+                                    float *flow, float *occl, float *sigma, float *packed, void *stream) {
     if (!flow_lr || !ou || !mask || !flow || !occl || !sigma) return fail(MFTX_E_ARG, "convex_upsample: null pointer");
     if (P <= 0 || h <= 0 || w <= 0 || ld_ou < 3) return fail(MFTX_E_ARG, "convex_upsample: bad sizes");
     return launch_convex_upsample(flow_lr, ou, ld_ou, mask, P, h, w, pad_left, pad_right, pad_top, pad_bottom, flow,
-                                  occl, sigma, (hipStream_t)stream);
+                                  occl, sigma, packed, (hipStream_t)stream);
 }

@@ -6,10 +6,14 @@
 // with mult = 8 for flow, 1 for the OU heads (core/raft.py:190,211,218); then
 // MFT/raft.py:57-62: unpad, occl = softmax(logits)[1], sigma = sqrt(exp(u)).
 //
-// One thread per full-resolution pixel; a wave covers 64 consecutive x so the
-// planar stores are fully coalesced and each coarse cell's mask block is read
-// as 8 consecutive floats per k.  The softmax over the 9 mask logits is
-// computed once and shared by the 5 upsampled channels.
+// One WAVE per coarse cell, lane = (sy, sx) of its 8 x 8 output pixels: the cell's 576 mask logits are
+// channel k*64 + sy*8 + sx, so lane l reads mask[cell][k*64 + l] -- nine fully coalesced 256-byte loads, the
+// 66 MB mask (7 pairs, 512 x 512) streams through once at line granularity.  The nine neighbours' coarse
+// values (flow, two logits, log-variance) are the same for the whole wave: scalar loads.  The softmax over
+// the 9 logits is computed once and shared by the 5 upsampled channels.  Outputs: planar flow / occlusion /
+// sigma (the API's layout; 32-byte runs per plane and output row, merged into full lines in L2 with the
+// neighbouring cells' runs) and, optionally, the same four values interleaved per pixel ("packed" FlowOU:
+// fx, fy, occl, sigma) -- 128-byte runs, one 16-byte gather per bilinear tap for the chaining kernel.
 #include "common.h"
 #include "profile.h"
 
@@ -24,28 +28,33 @@ struct UpArgs {
     int pl, pt;            // left / top crop
     int H0, W0;            // unpadded output size
     float *flow, *occl, *sigma;
+    float *packed;         // optional [P][H0][W0][4]
+    int cells;
 };
 
-__global__ __launch_bounds__(256) void convex_upsample_kernel(UpArgs p) {
-    const int X0 = blockIdx.x * blockDim.x + threadIdx.x;   // output (unpadded) x
-    const int Y0 = blockIdx.y;
-    const int img = blockIdx.z;
-    if (X0 >= p.W0) return;
-    const int X = X0 + p.pl, Y = Y0 + p.pt;                 // padded coordinates
-    const int y = Y >> 3, sy = Y & 7, x = X >> 3, sx = X & 7;
-    const long long cell = ((long long)img * p.h + y) * p.w + x;
-    const float *mk = p.mask + cell * 576 + sy * 8 + sx;
+constexpr int UP_WAVES = 4;
+
+__global__ __launch_bounds__(64 * UP_WAVES) void convex_upsample_kernel(UpArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int cell = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * UP_WAVES + (threadIdx.x >> 6)));
+    if (cell >= p.cells) return;
+    const int hw = p.h * p.w;
+    const int img = cell / hw, rem = cell - img * hw;
+    const int y = rem / p.w, x = rem - y * p.w;
+    const float *mk = p.mask + (long long)cell * 576 + lane;
     float m[9];
-    float mx = -INFINITY;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { m[k] = mk[k * 64]; mx = fmaxf(mx, m[k]); }
+    for (int k = 0; k < 9; ++k) m[k] = mk[k * 64];
+    float mx = m[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) mx = fmaxf(mx, m[k]);
     float den = 0.f;
 #pragma unroll
     for (int k = 0; k < 9; ++k) { m[k] = expf(m[k] - mx); den += m[k]; }
     float fxv = 0.f, fyv = 0.f, l0 = 0.f, l1 = 0.f, u = 0.f;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-        const int ny = y + k / 3 - 1, nx = x + k % 3 - 1;
+        const int ny = y + k / 3 - 1, nx = x + k % 3 - 1;          // wave-uniform: scalar branch, scalar loads
         if (ny < 0 || ny >= p.h || nx < 0 || nx >= p.w) continue;
         const long long nc = ((long long)img * p.h + ny) * p.w + nx;
         const float wk = m[k] / den;
@@ -57,29 +66,36 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(UpArgs p) {
         l1 += wk * o[1];
         u += wk * o[2];
     }
+    const int Y0 = 8 * y + (lane >> 3) - p.pt, X0 = 8 * x + (lane & 7) - p.pl;   // unpadded coordinates
+    if (Y0 < 0 || Y0 >= p.H0 || X0 < 0 || X0 >= p.W0) return;
     const long long plane = (long long)p.H0 * p.W0;
     const long long pix = (long long)Y0 * p.W0 + X0;
-    p.flow[(img * 2 + 0) * plane + pix] = fxv;
-    p.flow[(img * 2 + 1) * plane + pix] = fyv;
     // softmax over the two logits, channel 1
     const float lm = fmaxf(l0, l1);
     const float e0 = expf(l0 - lm), e1 = expf(l1 - lm);
-    p.occl[img * plane + pix] = e1 / (e0 + e1);
-    p.sigma[img * plane + pix] = sqrtf(expf(u));
+    const float oc = e1 / (e0 + e1);
+    const float sg = sqrtf(expf(u));
+    p.flow[(img * 2 + 0) * plane + pix] = fxv;
+    p.flow[(img * 2 + 1) * plane + pix] = fyv;
+    p.occl[img * plane + pix] = oc;
+    p.sigma[img * plane + pix] = sg;
+    if (p.packed != nullptr)
+        reinterpret_cast<float4 *>(p.packed)[img * plane + pix] = make_float4(fxv, fyv, oc, sg);
 }
 
 int launch_convex_upsample(const float *flow_lr, const float *ou, int ld_ou, const float *mask, int P, int h,
                            int w, int pl, int pr, int pt, int pb, float *flow, float *occl, float *sigma,
-                           hipStream_t s) {
+                           float *packed, hipStream_t s) {
     UpArgs a;
     a.flow_lr = flow_lr; a.ou = ou; a.ld_ou = ld_ou; a.mask = mask;
     a.P = P; a.h = h; a.w = w; a.pl = pl; a.pt = pt;
     a.H0 = 8 * h - pt - pb; a.W0 = 8 * w - pl - pr;
-    a.flow = flow; a.occl = occl; a.sigma = sigma;
+    a.flow = flow; a.occl = occl; a.sigma = sigma; a.packed = packed;
+    a.cells = P * h * w;
     if (a.H0 <= 0 || a.W0 <= 0) return fail(MFTX_E_ARG, "convex_upsample: bad padding");
-    dim3 grid(cdiv(a.W0, 256), a.H0, P);
+    if (packed != nullptr && !aligned16(packed)) return fail(MFTX_E_ALIGN, "convex_upsample: packed output must be 16-byte aligned");
     ProfScope prof(PC_UPSAMPLE, s, (double)P * h * w * (576 + 5) * 4 + (double)P * 4 * a.H0 * a.W0 * 4);
-    hipLaunchKernelGGL(convex_upsample_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(convex_upsample_kernel, dim3(cdiv(a.cells, UP_WAVES)), dim3(64 * UP_WAVES), 0, s, a);
     return check_launch("convex_upsample");
 }
 

@@ -13,8 +13,9 @@ never depend on tracker state -- RAFT sees only the two images, ``flow_init`` is
      shares (sizes differ by at most one); every rank runs its share through the native RAFT
      engine in batches of up to 7 pairs -- the batch size at which the conv GEMMs reach their
      single-GPU rate (``profiles/r1k_bench_pairs.txt``) -- whatever G is;
-  3. ONE all-gather of the raw FlowOU planes (flow2 | occl | sigma, 16 B per pixel and unit;
-     the last slot of a short share is simply not read -- nothing is zero-filled);
+  3. ONE all-gather of the raw FlowOU results in the packed per-pixel format (fx, fy, occl, sigma:
+     16 B per pixel and unit; written into the send buffer by the engine itself; the last slot of a
+     short share is simply not read -- nothing is zero-filled, nothing is staged);
   4. every rank runs the fused chain + select kernel for the window's frames IN FRAME ORDER
      (frame t's chains read ``memory[t - delta]``), so ``tracker.memory`` stays replicated and
      bitwise equal on all ranks, and equal to the single-GPU tracker: the unit results do not
@@ -129,7 +130,10 @@ class WindowSharder:
         # ---- my share, in engine batches
         H, W = tracker.img_H, tracker.img_W
         dev = tracker.device
-        send = torch.empty(max(slots, 1), 4, H, W, dtype=torch.float32, device=dev)
+        # FlowOU travels in the packed per-pixel format [H, W, 4] = (fx, fy, occl, sigma): the native engine
+        # writes it straight into the send buffer and the chain kernel gathers 16 bytes per tap from the
+        # receive buffer -- no staging copies on either side
+        send = torch.empty(max(slots, 1), H, W, 4, dtype=torch.float32, device=dev)
         mine = units[off: off + cnt]
         for b0 in range(0, cnt, self.MAX_BATCH):
             batch = mine[b0: b0 + self.MAX_BATCH]
@@ -137,12 +141,11 @@ class WindowSharder:
             for j, k in batch:
                 left_id = plans[j][k][1]
                 pairs.append((left_id, img_of(left_id), frame_ids[j], imgs[j]))
-            for s, (f, o, sg) in enumerate(tracker._flows_for_pairs(pairs)):
-                slot = send[b0 + s]
-                slot[0:2].copy_(f)
-                slot[2:3].copy_(o)
-                slot[3:4].copy_(sg)
-        recv = self._all_gather(send)                 # [G, slots, 4, H, W]
+            res = tracker._flows_for_pairs(pairs, packed_out=send[b0: b0 + len(batch)])
+            for s, r in enumerate(res):
+                if len(r) < 4:                        # a plugin without packed output: interleave here
+                    send[b0 + s].copy_(torch.cat([r[0], r[1], r[2]], 0).permute(1, 2, 0))
+        recv = self._all_gather(send)                 # [G, slots, H, W, 4]
         self.stats["windows"] += 1
         self.stats["units"] += len(units)
         self.stats["my_units"] += cnt
@@ -160,8 +163,7 @@ class WindowSharder:
             for k in range(len(plan)):
                 rr, s = owner_slot[u]
                 u += 1
-                c = recv[rr, s]
-                rights.append((c[0:2], c[2:3], c[3:4]))
+                rights.append(recv[rr, s])            # packed [H, W, 4]
                 lefts.append(tracker.memory[plan[k][1]]['result'].planes())
             if j == L - 1:
                 tracker._window_ids = set()

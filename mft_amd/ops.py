@@ -199,21 +199,63 @@ class EncoderEngine:
 # per-op wrappers
 # ---------------------------------------------------------------------------
 
+def pyramid_layout(h: int, w: int):
+    """(stride[4] floats per query cell, (hb0, wb0, hb1, wb1) block grids) of the correlation pyramid
+    (include/mftx.h, mftx_corr_pyramid)."""
+    stride, grid = (C.c_longlong * 4)(), (C.c_int * 4)()
+    check(_lib.load().mftx_corr_pyramid_layout(h, w, stride, grid), "mftx_corr_pyramid_layout")
+    return list(stride), tuple(grid)
+
+
+def _level_index(l: int, h: int, w: int, device):
+    """Flat offset inside a query's level-l slice of every (y, x) of the level, row-major order."""
+    stride, (hb0, wb0, hb1, wb1) = pyramid_layout(h, w)
+    hl, wl = h >> l, w >> l
+    ys, xs = torch.meshgrid(torch.arange(hl, device=device), torch.arange(wl, device=device), indexing="ij")
+    if l < 2:
+        wb = (wb0, wb1)[l]
+        idx = ((ys >> 2) * wb + (xs >> 3)) * 32 + (ys & 3) * 8 + (xs & 7)
+    else:
+        idx = ys * wl + xs
+    return idx.reshape(-1), stride[l]
+
+
+def unblock_level(t: torch.Tensor, l: int, h: int, w: int) -> torch.Tensor:
+    """Level l as mftx_corr_pyramid stores it [P, h*w, stride_l] -> row-major [P, h*w, h_l*w_l]
+    (the reference's layout; tests and tools only)."""
+    idx, _ = _level_index(l, h, w, t.device)
+    return t[..., idx].contiguous()
+
+
+def block_level(t: torch.Tensor, l: int, h: int, w: int) -> torch.Tensor:
+    """Inverse of ``unblock_level``: row-major [P, h*w, h_l*w_l] -> the stored layout, padding zero."""
+    idx, stride = _level_index(l, h, w, t.device)
+    out = torch.zeros(t.shape[:-1] + (stride,), dtype=t.dtype, device=t.device)
+    out[..., idx] = t
+    return out
+
+
 def corr_pyramid(f1: torch.Tensor, f2: torch.Tensor, h: int, w: int):
-    """f1, f2: pixel-major [P, h*w, C] -> 4 levels [P, h*w, (h>>l)*(w>>l)]."""
+    """f1, f2: pixel-major [P, h*w, C] -> 4 levels [P, h*w, stride_l] in the stored layout
+    (``unblock_level`` gives the reference's row-major view)."""
     lib = _lib.load()
     P, N, Cc = f1.shape
     assert N == h * w and f2.shape == f1.shape
-    lv = [torch.empty(P, N, (h >> l) * (w >> l), dtype=torch.float32, device=f1.device) for l in range(4)]
+    stride, _ = pyramid_layout(h, w)
+    lv = [torch.empty(P, N, stride[l], dtype=torch.float32, device=f1.device) for l in range(4)]
     check(lib.mftx_corr_pyramid(_chk(f1, "f1"), _chk(f2, "f2"), P, Cc, h, w,
                                 *[t.data_ptr() for t in lv], _stream()), "mftx_corr_pyramid")
     return lv
 
 
 def corr_lookup(lv, coords: torch.Tensor, h: int, w: int, r: int = 4):
-    """coords pixel-major [P, h*w, 2] (x, y) -> [P, h*w, 324]."""
+    """lv: the 4 levels in the stored layout; coords pixel-major [P, h*w, 2] (x, y) -> [P, h*w, 324]."""
     lib = _lib.load()
     P = coords.shape[0]
+    stride, _ = pyramid_layout(h, w)
+    for l, t in enumerate(lv):
+        if tuple(t.shape) != (P, h * w, stride[l]):
+            raise MftxError(f"corr_lookup: level {l} must be [{P}, {h * w}, {stride[l]}]")
     out = torch.empty(P, h * w, 324, dtype=torch.float32, device=coords.device)
     check(lib.mftx_corr_lookup(*[_chk(t, "level") for t in lv], _chk(coords, "coords"), P, h, w, r,
                                out.data_ptr(), 324, _stream()), "mftx_corr_lookup")
@@ -243,8 +285,9 @@ def conv2d(x: torch.Tensor, wpk: torch.Tensor, bias, P, h, w, N, kh, kw, act=Non
     return out
 
 
-def convex_upsample(flow_lr, ou, mask, P, h, w, pads=(0, 0, 0, 0)):
-    """flow_lr [M,2], ou [M,ld>=3], mask [M,576] -> flow [P,2,H0,W0], occl, sigma [P,1,H0,W0]."""
+def convex_upsample(flow_lr, ou, mask, P, h, w, pads=(0, 0, 0, 0), want_packed=False):
+    """flow_lr [M,2], ou [M,ld>=3], mask [M,576] -> flow [P,2,H0,W0], occl, sigma [P,1,H0,W0]
+    (+ packed [P,H0,W0,4] = (fx, fy, occl, sigma) per pixel)."""
     lib = _lib.load()
     pl, pr, pt, pb = pads
     H0, W0 = 8 * h - pt - pb, 8 * w - pl - pr
@@ -252,10 +295,11 @@ def convex_upsample(flow_lr, ou, mask, P, h, w, pads=(0, 0, 0, 0)):
     flow = torch.empty(P, 2, H0, W0, dtype=torch.float32, device=dev)
     occl = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev)
     sigma = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev)
+    packed = torch.empty(P, H0, W0, 4, dtype=torch.float32, device=dev) if want_packed else None
     check(lib.mftx_convex_upsample(_chk(flow_lr, "flow_lr"), _chk(ou, "ou"), ou.shape[1], _chk(mask, "mask"),
                                    P, h, w, pl, pr, pt, pb, flow.data_ptr(), occl.data_ptr(), sigma.data_ptr(),
-                                   _stream()), "mftx_convex_upsample")
-    return flow, occl, sigma
+                                   packed.data_ptr() if want_packed else None, _stream()), "mftx_convex_upsample")
+    return (flow, occl, sigma, packed) if want_packed else (flow, occl, sigma)
 
 
 def _planes(res, H, W):
@@ -320,6 +364,25 @@ def chain_select(Ls, Rs, thr, want_chosen=False):
     chosen = torch.empty(H, W, dtype=torch.int8, device=out[0].device) if want_chosen else None
     check(lib.mftx_chain_select(K, *[a[0] for a in arrs], float(thr), H, W, *[t.data_ptr() for t in out],
                                 chosen.data_ptr() if want_chosen else None, _stream()), "mftx_chain_select")
+    return out + (chosen,)
+
+
+def chain_select_packed(Ls, Rs, thr, want_chosen=False):
+    """Fused chain + select with the right operands in the packed per-pixel format: Ls = K x (flow[2,H,W],
+    occl[1,H,W], sigma[1,H,W]), Rs = K x [H,W,4] (fx, fy, occl, sigma).  W % 4 == 0."""
+    lib = _lib.load()
+    K = len(Ls)
+    assert len(Rs) == K
+    _, H, W = Ls[0][0].shape
+    lcols = list(zip(*[_planes(c, H, W) for c in Ls]))
+    for r in Rs:
+        if tuple(r.shape) != (H, W, 4):
+            raise MftxError("packed FlowOU must be [H, W, 4]")
+    arrs = [_lib.ptr_array(list(c)) for c in lcols] + [_lib.ptr_array([_chk(r, "packed") for r in Rs])]
+    out = _new_result(H, W, Ls[0][0].device)
+    chosen = torch.empty(H, W, dtype=torch.int8, device=out[0].device) if want_chosen else None
+    check(lib.mftx_chain_select_packed(K, *[a[0] for a in arrs], float(thr), H, W, *[t.data_ptr() for t in out],
+                                       chosen.data_ptr() if want_chosen else None, _stream()), "mftx_chain_select_packed")
     return out + (chosen,)
 
 
@@ -400,10 +463,12 @@ class RaftEngine:
         n = P * h * w * cols
         return self._ws[off: off + 4 * n].view(torch.float32).reshape(P * h * w, cols)
 
-    def refine(self, fmap1, fmap2, net, inp, h, w, iters, pads=(0, 0, 0, 0), want_flow_lr=False, flow_init=None):
+    def refine(self, fmap1, fmap2, net, inp, h, w, iters, pads=(0, 0, 0, 0), want_flow_lr=False, flow_init=None,
+               packed=None):
         """fmap1/fmap2 [P, h*w, 256], net/inp [P, h*w, 128] pixel-major ->
         flow [P,2,H0,W0], occl [P,1,H0,W0], sigma [P,1,H0,W0] (+ flow_lr [P,h*w,2]).
-        flow_init: optional [P, h*w, 2] initial flow at 1/8 resolution (core/raft.py:153-154)."""
+        flow_init: optional [P, h*w, 2] initial flow at 1/8 resolution (core/raft.py:153-154).
+        packed: optional pre-allocated [P,H0,W0,4] that also receives (fx, fy, occl, sigma) per pixel."""
         lib = _lib.load()
         P = fmap1.shape[0]
         pl, pr, pt, pb = pads
@@ -415,12 +480,15 @@ class RaftEngine:
         flow_lr = torch.empty(P, h * w, 2, dtype=torch.float32, device=dev) if want_flow_lr else None
         if flow_init is not None and tuple(flow_init.shape) != (P, h * w, 2):
             raise MftxError("flow_init must be [P, h*w, 2]")
+        if packed is not None and tuple(packed.shape) != (P, H0, W0, 4):
+            raise MftxError("packed must be [P, H0, W0, 4]")
         ws = self.workspace(P, h, w)
         check(lib.mftx_raft_refine(self._h, P, h, w, iters, _chk(fmap1, "fmap1"), _chk(fmap2, "fmap2"),
                                    _chk(net, "net"), _chk(inp, "inp"),
                                    _chk(flow_init, "flow_init") if flow_init is not None else None,
                                    pl, pr, pt, pb,
                                    flow.data_ptr(), occl.data_ptr(), sigma.data_ptr(),
+                                   _chk(packed, "packed") if packed is not None else None,
                                    flow_lr.data_ptr() if want_flow_lr else None,
                                    ws.data_ptr(), ws.numel(), _stream()), "mftx_raft_refine")
         return (flow, occl, sigma, flow_lr) if want_flow_lr else (flow, occl, sigma)

@@ -43,6 +43,8 @@ class FrameFeatures:
 
 
 class RAFTWrapper:
+    has_packed_output = True       # compute_pairs(packed_out=...) is supported
+
     def __init__(self, config, device="cuda", state_dict=None):
         self.C = config
         self.device = torch.device(device)
@@ -160,10 +162,12 @@ class RAFTWrapper:
 
     # ---- batched entry points used by the tracker --------------------------
     @torch.no_grad()
-    def compute_pairs(self, pairs, iters=None, init_flow=None):
+    def compute_pairs(self, pairs, iters=None, init_flow=None, packed_out=None):
         """pairs: [(left_id | None, left_img, right_id | None, right_img)] -> [(flow[2,H,W],
         occl[1,H,W], sigma[1,H,W])], left_i -> right_i for every i, in ONE engine call.  Frame ids key
-        the feature cache (None = do not cache).  init_flow: optional [P,2,H,W] initial flows."""
+        the feature cache (None = do not cache).  init_flow: optional [P,2,H,W] initial flows.
+        packed_out: True, or a pre-allocated [P,H,W,4] tensor: the tuples get a fourth element, the same result
+        interleaved per pixel (fx, fy, occl, sigma) -- what ``mftx_chain_select_packed`` gathers from."""
         iters = int(iters if iters is not None else self.C.flow_iters)
         fls = [self._features(lk, li) for lk, li, _, _ in pairs]
         frs = [self._features(rk, ri) for _, _, rk, ri in pairs]
@@ -178,8 +182,15 @@ class RAFTWrapper:
         flow_init = None
         if init_flow is not None:
             flow_init = self._init_flow_lr(init_flow, ref)
+        packed = None
+        if packed_out is not None and packed_out is not False:
+            H0, W0 = ref.shape
+            packed = packed_out if isinstance(packed_out, torch.Tensor) else \
+                torch.empty(len(pairs), H0, W0, 4, dtype=torch.float32, device=self.device)
         flow, occl, sigma = self.engine.refine(fmap1, fmap2, net, inp, ref.h, ref.w, iters, pads=ref.pads,
-                                               flow_init=flow_init)
+                                               flow_init=flow_init, packed=packed)
+        if packed is not None:
+            return [(flow[i], occl[i], sigma[i], packed[i]) for i in range(len(pairs))]
         return [(flow[i], occl[i], sigma[i]) for i in range(len(pairs))]
 
     def compute_flow_many(self, lefts, right, iters=None):

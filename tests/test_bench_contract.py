@@ -31,7 +31,7 @@ def test_oracle_thread_cap(monkeypatch):
     monkeypatch.setenv("MFT_ORACLE_THREADS", "4")
     assert bench.oracle_threads() <= 4
     monkeypatch.delenv("MFT_ORACLE_THREADS")
-    assert 1 <= bench.oracle_threads() <= 32
+    assert 1 <= bench.oracle_threads() <= 16
 
 
 def test_committed_bench_line_has_the_contract_keys():

@@ -214,7 +214,7 @@ def test_c2_full_track_step_vs_oracle(flower, weights_cpu):
     (frames 1..32 in memory with identity results, frame 33 arriving)."""
     import os
     from mft_amd.results import FlowOUTrackingResult
-    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 32)))
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
     vid = SyntheticVideo(512, 512, n_frames=34, seed=0)
     frames = [vid[i] for i in range(34)]
     H = W = 512

@@ -55,6 +55,7 @@ def test_corr_pyramid_vs_golden(ops_mod, gold, inp):
     lv = ops_mod.corr_pyramid(pm(inp["fmap1"])[None], pm(inp["fmap2"])[None], h, w)
     rows = gold["pyr_rows_idx"]
     for l, t in enumerate(lv):
+        t = ops_mod.unblock_level(t, l, h, w)           # stored (blocked) layout -> the reference's row-major maps
         got = t[0].cpu()[rows].reshape(gold[f"pyr{l}_rows"].shape)
         assert maxerr(got, T(gold[f"pyr{l}_rows"])) < 3e-5, l
         cs = gi.checksum(t.cpu().numpy())
@@ -66,10 +67,31 @@ def test_corr_pool_bit_exact_vs_oracle(ops_mod, inp):
     the kernel's own level 0 on the CPU bit for bit."""
     h, w = gi.OPS_H, gi.OPS_W
     lv = ops_mod.corr_pyramid(pm(inp["fmap1"])[None], pm(inp["fmap2"])[None], h, w)
+    lv = [ops_mod.unblock_level(t, l, h, w) for l, t in enumerate(lv)]
     v = lv[0][0].cpu().reshape(h * w, 1, h, w)
     for l in range(1, 4):
         v = F.avg_pool2d(v, 2, stride=2)
         assert torch.equal(v.reshape(h * w, -1), lv[l][0].cpu()), l
+
+
+@pytest.mark.parametrize("h,w,P", [(17, 23, 2), (64, 64, 1), (20, 20, 1), (33, 50, 1)])
+def test_corr_pyramid_fused_pooling_sizes(ops_mod, h, w, P):
+    """The volume GEMM's pooling epilogue at ragged sizes (partial super-blocks, floored levels, level strides
+    that are not multiples of 4): level 0 against an fp64 product, levels 1..3 bit for bit against avg_pool2d
+    of the level below; the padding of the blocked level 0 is zero."""
+    g = torch.Generator().manual_seed(h * 100 + w)
+    f1 = torch.randn(P, h * w, 256, generator=g).to(DEV)
+    f2 = torch.randn(P, h * w, 256, generator=g).to(DEV)
+    raw = ops_mod.corr_pyramid(f1, f2, h, w)
+    lv = [ops_mod.unblock_level(t, l, h, w) for l, t in enumerate(raw)]
+    ref0 = torch.einsum("pic,pjc->pij", f1.double(), f2.double()) / 16.0
+    assert maxerr(lv[0], ref0) < 2e-4
+    assert torch.equal(ops_mod.block_level(lv[0], 0, h, w), raw[0])          # padding cells are zero
+    for p in range(P):
+        v = lv[0][p].cpu().reshape(h * w, 1, h, w)
+        for l in range(1, 4):
+            v = F.avg_pool2d(v, 2, stride=2)
+            assert torch.equal(v.reshape(h * w, -1), lv[l][p].cpu()), (p, l)
 
 
 def test_corr_lookup_vs_golden(ops_mod, gold, inp):
@@ -94,7 +116,7 @@ def test_corr_lookup_batched_and_odd_size(ops_mod):
     for i in range(P):
         pyr = O.corr_pyramid(O.corr_volume(f1[i:i + 1], f2[i:i + 1]))
         for l in range(4):
-            assert maxerr(lv[l][i].cpu(), pyr[l].reshape(h * w, -1)) < 5e-5
+            assert maxerr(ops_mod.unblock_level(lv[l], l, h, w)[i].cpu(), pyr[l].reshape(h * w, -1)) < 5e-5
         ref = O.corr_lookup(pyr, coords[i:i + 1])
         assert maxerr(from_pm(out[i], h, w), ref) < 1e-4
 
@@ -295,6 +317,62 @@ def test_select_vs_oracle_and_fused_bitwise(ops_mod):
         assert maxerr(c[0].cpu(), ref[0]) < 3e-5 and maxerr(c[2].cpu(), ref[2]) < 1e-5
 
 
+def _rand_results(K, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    Ls, Rs = [], []
+    for k in range(K):
+        Ls.append((torch.randn(2, H, W, generator=g).mul(3).to(DEV), torch.rand(1, H, W, generator=g).mul(0.05).to(DEV),
+                   torch.rand(1, H, W, generator=g).add(0.1).to(DEV)))
+        Rs.append((torch.randn(2, H, W, generator=g).mul(3).to(DEV), torch.rand(1, H, W, generator=g).mul(0.05).to(DEV),
+                   torch.rand(1, H, W, generator=g).add(0.1).to(DEV)))
+    return Ls, Rs
+
+
+def test_chain_select_packed_and_vec4_bitwise(ops_mod):
+    """Three forms of the fused chain + select must agree bit for bit: one pixel per thread (operands at
+    4-byte-misaligned addresses force it), four pixels per thread with planar right operands, and four pixels per
+    thread with PACKED right operands (the tracker's path); all against the oracle."""
+    K, H, W = 5, 64, 96
+    Ls, Rs = _rand_results(K, H, W, 3)
+    thr = 0.02
+    v4 = ops_mod.chain_select(Ls, Rs, thr, want_chosen=True)
+    packed = [torch.cat([f, o, s_], 0).permute(1, 2, 0).contiguous() for f, o, s_ in Rs]
+    pk = ops_mod.chain_select_packed(Ls, packed, thr, want_chosen=True)
+
+    def misaligned(t):                       # same values, base address 4 bytes off a 16-byte boundary
+        buf = torch.empty(t.numel() + 4, dtype=t.dtype, device=t.device)
+        v = buf[1: 1 + t.numel()].view(t.shape)
+        v.copy_(t)
+        assert v.data_ptr() % 16 == 4
+        return v
+    Lm = [tuple(misaligned(t) for t in L) for L in Ls]
+    sc = ops_mod.chain_select(Lm, Rs, thr, want_chosen=True)
+    for a, b, c in zip(v4, pk, sc):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    want = O.select([O.chain(tuple(t.cpu() for t in L), tuple(t.cpu() for t in R)) for L, R in zip(Ls, Rs)], thr)
+    assert (v4[3].cpu().long() == want[3]).float().mean() > 0.999
+    same = v4[3].cpu().long() == want[3]
+    assert (v4[0].cpu() - want[0]).abs().max(0).values[same].max() < 2e-4
+    # select alone: vec4 == scalar
+    cands = [ops_mod.chain(L, R) for L, R in zip(Ls, Rs)]
+    s4 = ops_mod.select(cands, thr, want_chosen=True)
+    s1 = ops_mod.select([tuple(misaligned(t) for t in c) for c in cands], thr, want_chosen=True)
+    for a, b, c in zip(s4, s1, v4):
+        assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_convex_upsample_packed_equals_planar(ops_mod, inp):
+    h, w = gi.OPS_H, gi.OPS_W
+    ou = torch.cat([pm(inp["occl_lr"]), pm(inp["unc_lr"]), torch.zeros(h * w, 1, device=DEV)], 1).contiguous()
+    for pads in ((0, 0, 0, 0), (2, 3, 1, 2)):
+        flow, occl, sigma, packed = ops_mod.convex_upsample(pm(inp["flow"]), ou, pm(inp["mask"]), 1, h, w, pads=pads,
+                                                            want_packed=True)
+        ref = torch.cat([flow[0], occl[0], sigma[0]], 0).permute(1, 2, 0)
+        assert torch.equal(packed[0], ref)
+        plain = ops_mod.convex_upsample(pm(inp["flow"]), ou, pm(inp["mask"]), 1, h, w, pads=pads)
+        assert torch.equal(plain[0], flow) and torch.equal(plain[2], sigma)
+
+
 def test_select_all_occluded_picks_first(ops_mod):
     H, W = 8, 16
     cands = []
@@ -332,18 +410,19 @@ def test_fullsize_properties(ops_mod):
     f2 = torch.randn(2, h * w, 256, generator=g).to(DEV)
     lv = ops_mod.corr_pyramid(f1, f2, h, w)
     lvT = ops_mod.corr_pyramid(f2, f1, h, w)
+    l0, l0T = ops_mod.unblock_level(lv[0], 0, h, w), ops_mod.unblock_level(lvT[0], 0, h, w)
     # V(f1,f2)[i][j] == V(f2,f1)[j][i] bitwise (same fp32 reduction order)
-    assert torch.equal(lv[0][0], lvT[0][0].t())
+    assert torch.equal(l0[0], l0T[0].t())
     # spot-check level 0 against an fp64 dot product
     i = torch.tensor([0, 17, 4095]); j = torch.tensor([5, 2048, 4000])
     ref = (f1[1, i].double() * f2[1, j].double()).sum(1) / 16
-    assert maxerr(lv[0][1][i, j].cpu(), ref.cpu()) < 2e-5
+    assert maxerr(l0[1][i, j].cpu(), ref.cpu()) < 2e-5
     # lookup at integer coordinates reads the volume itself (centre tap, all levels' level-0 part)
     grid = O.pixel_grid(h, w).permute(1, 2, 0).reshape(1, h * w, 2).repeat(2, 1, 1).contiguous().to(DEV)
     out = ops_mod.corr_lookup(lv, grid, h, w)
     centre = 4 * 9 + 4
     diag = torch.arange(h * w, device=DEV)
-    assert maxerr(out[0][:, centre].cpu(), lv[0][0][diag, diag].cpu()) < 1e-6
+    assert maxerr(out[0][:, centre].cpu(), l0[0][diag, diag].cpu()) < 1e-6
     # chain with an identity left result returns the right result
     H = W = 512
     R = (torch.randn(2, H, W, generator=g).to(DEV), torch.rand(1, H, W, generator=g).to(DEV),
@@ -444,8 +523,9 @@ def test_raft_engine_argument_errors(ops_mod, weights_np):
     n = torch.zeros(1, h * w, 128, device=DEV)
     out = [torch.zeros(1, c, 8 * h, 8 * w, device=DEV) for c in (2, 1, 1)]
     ws = torch.zeros(1024, dtype=torch.uint8, device=DEV)            # far too small
-    rc = lib.mftx_raft_refine(eng._h, 1, h, w, 2, f.data_ptr(), f.data_ptr(), n.data_ptr(), n.data_ptr(), 0, 0, 0, 0,
-                              out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), None, ws.data_ptr(), ws.numel(), None)
+    # raw C ABI: (handle, P, h, w, iters, fmap1, fmap2, net, inp, flow_init, 4 pads, flow, occl, sigma, packed, flow_lr, ws, bytes, stream)
+    rc = lib.mftx_raft_refine(eng._h, 1, h, w, 2, f.data_ptr(), f.data_ptr(), n.data_ptr(), n.data_ptr(), None, 0, 0, 0, 0,
+                              out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), None, None, ws.data_ptr(), ws.numel(), None)
     assert rc == -3 and b"workspace" in lib.mftx_last_error_string()
     with pytest.raises(MftxError):
         eng.refine(f, f, n, n, 8, 8, 2)                               # grid too small for 4 pyramid levels
@@ -457,9 +537,9 @@ def test_raft_engine_argument_errors(ops_mod, weights_np):
         eng.refine(f.cpu(), f, n, n, h, w, 2)                         # CPU tensor
     bad = C.c_void_p()
     assert lib.mftx_raft_create(None, 34, C.byref(bad)) == -1
-    assert lib.mftx_raft_refine(None, 1, h, w, 2, f.data_ptr(), f.data_ptr(), n.data_ptr(), n.data_ptr(), 0, 0, 0, 0,
-                                out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), None, ws.data_ptr(), ws.numel(),
-                                None) == -4
+    assert lib.mftx_raft_refine(None, 1, h, w, 2, f.data_ptr(), f.data_ptr(), n.data_ptr(), n.data_ptr(), None, 0, 0, 0, 0,
+                                out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), None, None, ws.data_ptr(),
+                                ws.numel(), None) == -4
     # the happy path still works after the failures
     flow, occl, sigma = eng.refine(f, f, n, n, h, w, 2)
     assert bool(torch.isfinite(flow).all()) and float(occl.min()) >= 0 and float(sigma.min()) >= 0

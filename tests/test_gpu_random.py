@@ -75,7 +75,8 @@ def test_lookup_random(h, w, P, seed, spread):
         got.append(ref[0].permute(1, 2, 0).reshape(N, 324))
         lv = [l.reshape(N, -1) for l in pyr]
         levels = [lv] if levels is None else levels + [lv]
-    lv_dev = [torch.stack([levels[p][l] for p in range(P)]).to(DEV).contiguous() for l in range(4)]
+    lv_dev = [ops.block_level(torch.stack([levels[p][l] for p in range(P)]).to(DEV), l, h, w).contiguous()
+              for l in range(4)]                                        # row-major maps -> the stored pyramid layout
     cpm = coords.permute(0, 2, 3, 1).reshape(P, N, 2).contiguous().to(DEV)
     out = ops.corr_lookup(lv_dev, cpm, h, w).cpu()
     ref = torch.stack(got)

@@ -39,7 +39,7 @@ def test_library_exports_every_header_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mftx_version() == 100
+    assert lib.mftx_version() == 200
     assert lib.mftx_raft_workspace_bytes(7, 64, 64) > 7 * 4096 * 4096 * 4
     assert lib.mftx_raft_workspace_bytes(0, 64, 64) == 0
 
@@ -124,6 +124,8 @@ class OracleBackend:
 
     @staticmethod
     def chain_select(Ls, Rs, thr):
+        from mft_amd.MFT import is_packed, unpack_planes
+        Rs = [unpack_planes(r) if is_packed(r) else r for r in Rs]          # the multi-rank path hands packed results
         return OracleBackend.select([O.chain(l, r) for l, r in zip(Ls, Rs)], thr)
 
 

@@ -16,7 +16,8 @@ ap.add_argument("--w", type=int, default=64)
 args = ap.parse_args()
 P, h, w = args.P, args.h, args.w
 N = h * w
-lv = [torch.randn(P, N, (h >> l) * (w >> l), device="cuda") for l in range(4)]
+stride, _ = ops.pyramid_layout(h, w)
+lv = [torch.randn(P, N, stride[l], device="cuda") for l in range(4)]       # stored layout (padding content is never read)
 ys, xs = torch.meshgrid(torch.arange(h, device="cuda"), torch.arange(w, device="cuda"), indexing="ij")
 coords = (torch.stack([xs, ys], -1).reshape(1, N, 2).float() + torch.randn(P, N, 2, device="cuda")).contiguous()
 for _ in range(3):

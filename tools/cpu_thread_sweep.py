@@ -27,7 +27,8 @@ cores = len(os.sched_getaffinity(0))
 sd = {k: torch.from_numpy(v) for k, v in make_weights(0).items()}
 vid = SyntheticVideo(a.size, a.size, n_frames=8, seed=0)
 print(f"# host cores {cores}; one {a.size}x{a.size} pair, {a.iters} iterations, oracle.compute_flow")
-for n in [t for t in (8, 16, 32, 64, 128, 256) if t <= cores] + ([cores] if cores not in (8, 16, 32, 64, 128, 256) else []):
+ap2 = [t for t in (8, 16, 32, 64, 128) if t <= cores]      # (256 threads on a 256-core host took 783 s per pair: oversubscribed, dropped)
+for n in ap2:
     torch.set_num_threads(n)
     with torch.no_grad():
         O.compute_flow(sd, vid[0], vid[1], 1)                      # touch everything once
