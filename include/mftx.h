@@ -129,7 +129,8 @@ int mftx_raft_workspace_layout(int P, int h, int w, size_t *offsets, int n);
  * resolution, added to the start coordinates (core/raft.py:153-154).  Outputs are planar and UNPADDED: flow [P][2][H0][W0], occl
  * [P][1][H0][W0] (softmax channel 1), sigma [P][1][H0][W0] (sqrt(exp(u))), with
  * H0 = 8h - pad_top - pad_bottom etc.  packed (optional, may be NULL): the same four values interleaved per
- * pixel, [P][H0][W0][4] = (flow x, flow y, occl, sigma), the right-operand format of mftx_chain_select_packed.
+ * pixel, [P][H0][W0][4] = (flow x, flow y, occl, sigma), the right-operand format of mftx_chain_select_packed;
+ * with packed given, flow / occl / sigma may all three be NULL (the tracker's hot path needs only packed).
  * flow_lr (optional) [P*h*w][2]. */
 int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters,
                      const float *fmap1, const float *fmap2, const float *net, const float *inp,
@@ -192,7 +193,7 @@ int mftx_chain_select(int K,
 
 /* The same with the right operands (left_id -> current flows, fresh from mftx_raft_refine) in the packed
  * per-pixel format [H][W][4] = (flow x, flow y, occl, sigma): each bilinear tap of the chain is one 16-byte
- * gather.  Needs W % 4 == 0 and 16-byte aligned planes.  Bitwise equal to mftx_chain_select. */
+ * gather.  packedR[k] must be 16-byte aligned.  Bitwise equal to mftx_chain_select. */
 int mftx_chain_select_packed(int K,
                              const float *const *flowL, const float *const *occlL, const float *const *sigmaL,
                              const float *const *packedR,

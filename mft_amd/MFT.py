@@ -57,8 +57,7 @@ class HipBackend:
     @staticmethod
     def chain_select(Ls, Rs, thr):
         """Rs: per candidate either the (flow, occl, sigma) planes or the packed [H, W, 4] tensor."""
-        W = Ls[0][0].shape[-1]
-        if all(is_packed(r) for r in Rs) and W % 4 == 0:
+        if all(is_packed(r) for r in Rs):
             return ops.chain_select_packed(Ls, Rs, thr, want_chosen=True)
         return ops.chain_select(Ls, [unpack_planes(r) if is_packed(r) else r for r in Rs], thr, want_chosen=True)
 
@@ -135,10 +134,7 @@ class MFT():
         plan = self._plan(frame_i)
         rights = self._flows_for(plan, frame_i, input_img)
         lefts = [self.memory[left_id]['result'].planes() for _, left_id, _ in plan]
-        packed = [getattr(r, "packed", None) for r in rights]
-        if all(p is not None for p in packed):      # fresh from the engine: one 16-byte gather per chain tap
-            return self._finish_frame(frame_i, input_img, plan, lefts, packed)
-        return self._finish_frame(frame_i, input_img, plan, lefts, [r.planes() for r in rights])
+        return self._finish_frame(frame_i, input_img, plan, lefts, rights)
 
     def track_window(self, imgs):
         """Track the next ``len(imgs)`` frames and return their metas in order.  Same results as calling
@@ -167,12 +163,13 @@ class MFT():
         self.cleanup_memory()
         return meta
 
-    def _flows_for_pairs(self, pairs, packed_out=None):
+    def _flows_for_pairs(self, pairs, packed_out=None, planar=True):
         """[(left_id, left_img, right_id, right_img)] -> [(flow, occl, sigma[, packed])], one batched engine
-        pass when the flow plugin offers one, else the reference's per-pair call (MFT/MFT.py:223-225)."""
+        pass when the flow plugin offers one, else the reference's per-pair call (MFT/MFT.py:223-225).
+        planar=False (native plugin only): just the packed results, (None, None, None, packed)."""
         if hasattr(self.flower, "compute_pairs"):
             if packed_out is not None and getattr(self.flower, "has_packed_output", False):
-                return self.flower.compute_pairs(pairs, packed_out=packed_out)
+                return self.flower.compute_pairs(pairs, packed_out=packed_out, planar=planar)
             return self.flower.compute_pairs(pairs)
         res = []
         for _, left_img, _, right_img in pairs:
@@ -181,8 +178,10 @@ class MFT():
         return res
 
     def _flows_for(self, plan, right_id, input_img):
-        """FlowOU (left -> right_id) for every entry of ``plan``: cache first, then one batched flow
-        computation for everything that is missing."""
+        """Right operands of the frame's chains -- FlowOU (left -> right_id) for every entry of ``plan``: cache
+        first, then ONE batched flow computation for everything that is missing.  Each is either the planes
+        tuple (flow, occl, sigma) or, fresh from the native engine, the packed [H, W, 4] tensor (planar copies
+        are only produced when a cache wants them)."""
         out, missing = {}, []
         for i, (_, left_id, use_cache) in enumerate(plan):
             got = None
@@ -190,7 +189,7 @@ class MFT():
                 try:
                     f, o, s = self.flow_cache.read(left_id, right_id)
                     assert f is not None
-                    got = FlowOUTrackingResult(f, o, s)
+                    got = FlowOUTrackingResult(f, o, s).planes()
                 except Exception:
                     got = None
             if got is None:
@@ -198,15 +197,14 @@ class MFT():
             else:
                 out[i] = got
         if missing:
+            to_cache = self.flow_cache is not None and any(plan[i][2] for i in missing)
             res = self._flows_for_pairs([(plan[i][1], self.memory[plan[i][1]]['img'], right_id, input_img)
-                                         for i in missing], packed_out=(self.img_W % 4 == 0) or None)
+                                         for i in missing], packed_out=True, planar=to_cache)
             for i, r in zip(missing, res):
-                f, o, s = r[:3]
                 _, left_id, use_cache = plan[i]
                 if self.flow_cache is not None and use_cache:
-                    self.flow_cache.write(left_id, right_id, f, o, s)
-                out[i] = FlowOUTrackingResult(f, o, s, validate=False)
-                out[i].packed = r[3] if len(r) > 3 else None
+                    self.flow_cache.write(left_id, right_id, r[0], r[1], r[2])
+                out[i] = r[3] if len(r) > 3 else tuple(r[:3])
         return [out[i] for i in range(len(plan))]
 
     # --------------------------------------------------------------- memory

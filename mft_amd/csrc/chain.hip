@@ -165,10 +165,9 @@ __global__ __launch_bounds__(256) void select_kernel(SelSet ss, float thr, int H
     write_selected(b, H, W, x, y, flowO, occlO, sigmaO, chosen);
 }
 
-// ---- four pixels per thread along x (W % 4 == 0): the left planes and the outputs move as float4, and with
-// a PACKED right operand ([H][W][4] = fx, fy, occl, sigma per pixel, written by the upsampler) each bilinear
-// tap is ONE 16-byte gather instead of four 4-byte ones: 20 instead of 80 loads per candidate and thread.
-// Same arithmetic, operation by operation, as chain_px (bitwise equal results).
+// ---- PACKED right operands ([H][W][4] = fx, fy, occl, sigma per pixel, written by the upsampler): each bilinear
+// tap is ONE 16-byte gather instead of four 4-byte ones.  Same arithmetic, operation by operation, as chain_px
+// (bitwise equal results).
 struct PackedSet {
     int K;
     Planes L[MFTX_MAX_CANDIDATES];
@@ -217,46 +216,30 @@ __device__ __forceinline__ void write_selected4(const Best (&b)[4], int H, int W
     if (chosen) *reinterpret_cast<char4 *>(chosen + pix) = ck;
 }
 
-template <bool PACKED>
-__global__ __launch_bounds__(256) void chain_select4_kernel(CandSet cs, PackedSet ps, float thr, int H, int W, float sx,
-                                                            float sy, float *flowO, float *occlO, float *sigmaO,
-                                                            int8_t *chosen) {
-    const int x = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+// One pixel per thread (16 waves per CU at 512 x 512: the chain is two dependent memory round trips per
+// candidate, hidden by other waves -- four pixels per thread left 4 waves per CU and ran 2x slower), right
+// operands PACKED: 4 coalesced 4-byte loads of the left planes + 4 sixteen-byte gathers per candidate
+// instead of 4 + 16 four-byte gathers; the kernel was bound by the texture-address rate of those gathers.
+__global__ __launch_bounds__(256) void chain_select_packed_kernel(PackedSet ps, float thr, int H, int W, float sx,
+                                                                  float sy, float *flowO, float *occlO, float *sigmaO,
+                                                                  int8_t *chosen) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= W) return;
     const long long pix = (long long)y * W + x, plane = (long long)H * W;
-    Best b[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { b[i].score = 0.f; b[i].k = 0; b[i].c = Chained{0.f, 0.f, 0.f, 0.f}; }
-    const int K = PACKED ? ps.K : cs.K;
-    for (int k = 0; k < K; ++k) {
-        const Planes &L = PACKED ? ps.L[k] : cs.L[k];
-        const float4 lfx = *reinterpret_cast<const float4 *>(L.flow + pix);
-        const float4 lfy = *reinterpret_cast<const float4 *>(L.flow + plane + pix);
-        const float4 loc = *reinterpret_cast<const float4 *>(L.occl + pix);
-        const float4 lsg = *reinterpret_cast<const float4 *>(L.sigma + pix);
-        const float lx[4] = {lfx.x, lfx.y, lfx.z, lfx.w}, ly[4] = {lfy.x, lfy.y, lfy.z, lfy.w};
-        const float lo[4] = {loc.x, loc.y, loc.z, loc.w}, ls[4] = {lsg.x, lsg.y, lsg.z, lsg.w};
-        Chained c[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if constexpr (PACKED) {
-                const float4 *R = ps.R[k];
-                c[i] = chain_core(lx[i], ly[i], lo[i], ls[i], H, W, x + i, y, sx, sy, [&](int yy, int xx) {
-                    return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? R[(long long)yy * W + xx] : make_float4(0.f, 0.f, 0.f, 0.f);
-                });
-            } else {
-                const Planes R = cs.R[k];
-                c[i] = chain_core(lx[i], ly[i], lo[i], ls[i], H, W, x + i, y, sx, sy, [&](int yy, int xx) {
-                    return make_float4(tap(R.flow, H, W, yy, xx), tap(R.flow + plane, H, W, yy, xx),
-                                       tap(R.occl, H, W, yy, xx), tap(R.sigma, H, W, yy, xx));
-                });
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) consider(b[i], c[i], k, thr);
+    Best b;
+    b.score = 0.f; b.k = 0; b.c = Chained{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < ps.K; ++k) {
+        const Planes L = ps.L[k];
+        const float4 *R = ps.R[k];
+        const Chained c = chain_core(L.flow[pix], L.flow[plane + pix], L.occl[pix], L.sigma[pix], H, W, x, y, sx, sy,
+                                     [&](int yy, int xx) {
+                                         return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? R[(long long)yy * W + xx]
+                                                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+                                     });
+        consider(b, c, k, thr);
     }
-    write_selected4(b, H, W, x, y, flowO, occlO, sigmaO, chosen);
+    write_selected(b, H, W, x, y, flowO, occlO, sigmaO, chosen);
 }
 
 __global__ __launch_bounds__(256) void select4_kernel(SelSet ss, float thr, int H, int W, float *flowO, float *occlO,
@@ -367,17 +350,9 @@ extern "C" int mftx_chain_select(int K, const float *const *flowL, const float *
     }
     float sx, sy;
     scales(H, W, sx, sy);
-    bool v4 = vec4_ok(W, {flowO, occlO, sigmaO}) && (chosen == nullptr || (reinterpret_cast<uintptr_t>(chosen) & 3) == 0);
-    for (int k = 0; k < K && v4; ++k) v4 = vec4_ok(W, {flowL[k], occlL[k], sigmaL[k]});
     ProfScope prof(PC_CHAIN, (hipStream_t)stream, (32.0 * K + 16.0) * H * W);
-    if (v4) {
-        PackedSet none{};
-        hipLaunchKernelGGL(chain_select4_kernel<false>, dim3(cdiv(W, 4 * 64), H), dim3(64), 0, (hipStream_t)stream, cs,
-                           none, thr, H, W, sx, sy, flowO, occlO, sigmaO, chosen);
-    } else {
-        hipLaunchKernelGGL(chain_select_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, cs, thr, H,
-                           W, sx, sy, flowO, occlO, sigmaO, chosen);
-    }
+    hipLaunchKernelGGL(chain_select_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, cs, thr, H,
+                       W, sx, sy, flowO, occlO, sigmaO, chosen);
     return check_launch("chain_select");
 }
 
@@ -388,24 +363,20 @@ extern "C" int mftx_chain_select_packed(int K, const float *const *flowL, const 
         return fail(MFTX_E_ARG, "chain_select_packed: K must be in 1..%d", MFTX_MAX_CANDIDATES);
     if (!flowL || !occlL || !sigmaL || !packedR || !flowO || !occlO || !sigmaO)
         return fail(MFTX_E_ARG, "chain_select_packed: null pointer");
-    if (H < 2 || W < 2 || W % 4) return fail(MFTX_E_ARG, "chain_select_packed: need H, W >= 2 and W %% 4 == 0");
+    if (H < 2 || W < 2) return fail(MFTX_E_ARG, "chain_select_packed: H and W must be >= 2");
     PackedSet ps;
     ps.K = K;
     for (int k = 0; k < K; ++k) {
         if (!flowL[k] || !occlL[k] || !sigmaL[k] || !packedR[k])
             return fail(MFTX_E_ARG, "chain_select_packed: null candidate %d", k);
-        if (!vec4_ok(W, {flowL[k], occlL[k], sigmaL[k], packedR[k]}))
-            return fail(MFTX_E_ALIGN, "chain_select_packed: planes must be 16-byte aligned");
+        if (!aligned16(packedR[k])) return fail(MFTX_E_ALIGN, "chain_select_packed: packed operands must be 16-byte aligned");
         ps.L[k] = Planes{flowL[k], occlL[k], sigmaL[k]};
         ps.R[k] = reinterpret_cast<const float4 *>(packedR[k]);
     }
-    if (!vec4_ok(W, {flowO, occlO, sigmaO}) || (chosen != nullptr && (reinterpret_cast<uintptr_t>(chosen) & 3)))
-        return fail(MFTX_E_ALIGN, "chain_select_packed: outputs must be 16-byte (chosen: 4-byte) aligned");
     float sx, sy;
     scales(H, W, sx, sy);
-    CandSet none{};
     ProfScope prof(PC_CHAIN, (hipStream_t)stream, (32.0 * K + 16.0) * H * W);
-    hipLaunchKernelGGL(chain_select4_kernel<true>, dim3(cdiv(W, 4 * 64), H), dim3(64), 0, (hipStream_t)stream, none, ps,
-                       thr, H, W, sx, sy, flowO, occlO, sigmaO, chosen);
+    hipLaunchKernelGGL(chain_select_packed_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, ps, thr, H, W,
+                       sx, sy, flowO, occlO, sigmaO, chosen);
     return check_launch("chain_select_packed");
 }

@@ -614,7 +614,8 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat, 
     const int max_res = max_waves / (WM * WN);
     const int resident = (160 * 1024) / (int)lds < max_res ? (160 * 1024) / (int)lds : max_res;
     const long long n_virtual = 8ll * cdiv(cdiv(a.M, BM), 8) * cdiv(a.N, BN) * batch;
-    const long long slots = (long long)num_cus() * resident;
+    static const bool one_tile_per_wg = getenv("MFTX_CONV_NONPERSISTENT") != nullptr;   // tuning: let the dispatcher interleave kernels of two streams
+    const long long slots = one_tile_per_wg ? n_virtual : (long long)num_cus() * resident;
     dim3 grid((unsigned)(n_virtual < slots ? n_virtual : slots));
     // algorithmic flops: real (unpadded) reduction length
     ProfScope prof(cat, s, work >= 0 ? work : 2.0 * a.M * a.N * (double)(a.kh * a.kw) * (a.c0 + a.c1) * batch);
@@ -739,7 +740,8 @@ int launch_conv_pair(const mftx_conv_desc &da, const mftx_conv_desc &db, hipStre
         attr_set = true;
     }
     const long long n_virtual = 8ll * cdiv(cdiv(a.M, BM), 8) * cdiv(a.N, BN) + 8ll * cdiv(cdiv(b.M, BM), 8) * cdiv(b.N, BN);
-    const long long slots = (long long)num_cus() * 4;
+    static const bool one_tile_per_wg = getenv("MFTX_CONV_NONPERSISTENT") != nullptr;
+    const long long slots = one_tile_per_wg ? n_virtual : (long long)num_cus() * 4;
     dim3 grid((unsigned)(n_virtual < slots ? n_virtual : slots));
     ProfScope prof(PC_CONV_GEMM, s, 2.0 * a.M * a.N * (double)(a.kh * a.kw) * (a.c0 + a.c1) +
                                         2.0 * b.M * b.N * (double)(b.kh * b.kw) * (b.c0 + b.c1));

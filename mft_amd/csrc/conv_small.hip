@@ -43,11 +43,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_kernel(const float *__re
         reinterpret_cast<f32x4s *>(wsm)[i] = reinterpret_cast<const f32x4s *>(wpk)[i];     // [n][tap][256] as packed
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);          // global wave id
-    const int total = P * h * strips_per_row;
-    if (gw >= total) return;
-    const int strip = gw % strips_per_row;
-    const int rowid = gw / strips_per_row;                        // img*h + y
+    // A block = 4 consecutive rows of one strip (its waves share 2 of their 3 input rows), and workgroup b runs
+    // on XCD b % 8 (observed; only speed depends on it): each XCD gets a contiguous band of row groups, strips
+    // innermost, so the halo rows / columns a wave re-reads were fetched by a neighbour on the SAME XCD and hit
+    // its L2 -- the input map (written by another XCD's GEMM tiles) crosses the fabric ~once instead of 3.75 x.
+    const int rows = P * h, groups = (rows + 3) / 4;
+    const int nb = groups * strips_per_row, per_xcd = (nb + 7) / 8;
+    const int vb = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || vb >= nb) return;
+    const int strip = vb % strips_per_row;
+    const int rowid = (vb / strips_per_row) * 4 + (threadIdx.x >> 6);     // img*h + y
+    if (rowid >= rows) return;
     const int y = rowid % h;
     const int img_base = (rowid / h) * h * w;
     const int x0 = strip * S;
@@ -124,9 +130,9 @@ int launch_conv_small(const mftx_conv_desc &d, hipStream_t s, float *accum, int 
     const long long cells = (long long)d.P * d.h * d.w;
     if (cells * d.lda0 * 4 > 0x7fffffffLL) return fail(MFTX_E_ARG, "conv3x3_small: activation operand exceeds 2 GiB");
     const int strips = cdiv(d.w, small_strip(d.N));
-    const int waves = d.P * d.h * strips;
+    const int nb = cdiv(d.P * d.h, 4) * strips;
     const unsigned x_bytes = (unsigned)(((cells - 1) * d.lda0 + 256) * 4);
-    dim3 grid(cdiv(waves, 4));
+    dim3 grid(8 * cdiv(nb, 8));
     ProfScope prof(PC_CONV_SMALL, s, 2.0 * d.P * d.h * d.w * d.N * 9.0 * 256.0);
 #define SN_LAUNCH(NN)                                                                                              \
     hipLaunchKernelGGL(conv3x3_small_kernel<NN>, grid, dim3(256), 0, s, d.a0, d.lda0, x_bytes, d.wpk, d.bias, d.out, \

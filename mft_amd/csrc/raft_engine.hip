@@ -202,8 +202,9 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
                                 float *sigma, float *packed, float *flow_lr_out, void *workspace,
                                 size_t workspace_bytes, void *stream) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_refine: bad handle");
-    if (!fmap1 || !fmap2 || !net || !inp || !flow || !occl || !sigma || !workspace)
-        return fail(MFTX_E_ARG, "raft_refine: null pointer");
+    const bool planar = flow && occl && sigma;
+    if (!fmap1 || !fmap2 || !net || !inp || !workspace || (!planar && (flow || occl || sigma || !packed)))
+        return fail(MFTX_E_ARG, "raft_refine: null pointer (outputs: flow + occl + sigma, or packed, or both)");
     if (P <= 0 || h < 16 || w < 16 || iters < 1)
         return fail(MFTX_E_ARG, "raft_refine: need P >= 1, h, w >= 16 (level 3 of the pyramid needs >= 2 cells), iters >= 1");
     if ((long long)P * h * w > (1ll << 24)) return fail(MFTX_E_ARG, "raft_refine: batch too large");
@@ -349,7 +350,9 @@ extern "C" int mftx_conv2d(const mftx_conv_desc *d, void *stream) {
 extern "C" int mftx_convex_upsample(const float *flow_lr, const float *ou, int ld_ou, const float *mask, int P,
                                     int h, int w, int pad_left, int pad_right, int pad_top, int pad_bottom,
                                     float *flow, float *occl, float *sigma, float *packed, void *stream) {
-    if (!flow_lr || !ou || !mask || !flow || !occl || !sigma) return fail(MFTX_E_ARG, "convex_upsample: null pointer");
+    const bool planar = flow && occl && sigma;
+    if (!flow_lr || !ou || !mask || (!planar && (flow || occl || sigma || !packed)))
+        return fail(MFTX_E_ARG, "convex_upsample: null pointer (outputs: flow + occl + sigma, or packed, or both)");
     if (P <= 0 || h <= 0 || w <= 0 || ld_ou < 3) return fail(MFTX_E_ARG, "convex_upsample: bad sizes");
     return launch_convex_upsample(flow_lr, ou, ld_ou, mask, P, h, w, pad_left, pad_right, pad_top, pad_bottom, flow,
                                   occl, sigma, packed, (hipStream_t)stream);

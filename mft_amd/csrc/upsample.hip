@@ -75,10 +75,12 @@ __global__ __launch_bounds__(64 * UP_WAVES) void convex_upsample_kernel(UpArgs p
     const float e0 = expf(l0 - lm), e1 = expf(l1 - lm);
     const float oc = e1 / (e0 + e1);
     const float sg = sqrtf(expf(u));
-    p.flow[(img * 2 + 0) * plane + pix] = fxv;
-    p.flow[(img * 2 + 1) * plane + pix] = fyv;
-    p.occl[img * plane + pix] = oc;
-    p.sigma[img * plane + pix] = sg;
+    if (p.flow != nullptr) {                       // planar outputs are optional when the packed form is asked for
+        p.flow[(img * 2 + 0) * plane + pix] = fxv;
+        p.flow[(img * 2 + 1) * plane + pix] = fyv;
+        p.occl[img * plane + pix] = oc;
+        p.sigma[img * plane + pix] = sg;
+    }
     if (p.packed != nullptr)
         reinterpret_cast<float4 *>(p.packed)[img * plane + pix] = make_float4(fxv, fyv, oc, sg);
 }
@@ -94,6 +96,8 @@ int launch_convex_upsample(const float *flow_lr, const float *ou, int ld_ou, con
     a.cells = P * h * w;
     if (a.H0 <= 0 || a.W0 <= 0) return fail(MFTX_E_ARG, "convex_upsample: bad padding");
     if (packed != nullptr && !aligned16(packed)) return fail(MFTX_E_ALIGN, "convex_upsample: packed output must be 16-byte aligned");
+    // algorithmic bytes: mask + coarse inputs read, 4 values per output pixel written -- once, in
+    // whichever of the two layouts; writing both layouts is 16 more bytes per pixel that are not booked
     ProfScope prof(PC_UPSAMPLE, s, (double)P * h * w * (576 + 5) * 4 + (double)P * 4 * a.H0 * a.W0 * 4);
     hipLaunchKernelGGL(convex_upsample_kernel, dim3(cdiv(a.cells, UP_WAVES)), dim3(64 * UP_WAVES), 0, s, a);
     return check_launch("convex_upsample");

@@ -369,7 +369,7 @@ def chain_select(Ls, Rs, thr, want_chosen=False):
 
 def chain_select_packed(Ls, Rs, thr, want_chosen=False):
     """Fused chain + select with the right operands in the packed per-pixel format: Ls = K x (flow[2,H,W],
-    occl[1,H,W], sigma[1,H,W]), Rs = K x [H,W,4] (fx, fy, occl, sigma).  W % 4 == 0."""
+    occl[1,H,W], sigma[1,H,W]), Rs = K x [H,W,4] (fx, fy, occl, sigma)."""
     lib = _lib.load()
     K = len(Ls)
     assert len(Rs) == K
@@ -464,19 +464,22 @@ class RaftEngine:
         return self._ws[off: off + 4 * n].view(torch.float32).reshape(P * h * w, cols)
 
     def refine(self, fmap1, fmap2, net, inp, h, w, iters, pads=(0, 0, 0, 0), want_flow_lr=False, flow_init=None,
-               packed=None):
+               packed=None, planar=True):
         """fmap1/fmap2 [P, h*w, 256], net/inp [P, h*w, 128] pixel-major ->
         flow [P,2,H0,W0], occl [P,1,H0,W0], sigma [P,1,H0,W0] (+ flow_lr [P,h*w,2]).
         flow_init: optional [P, h*w, 2] initial flow at 1/8 resolution (core/raft.py:153-154).
-        packed: optional pre-allocated [P,H0,W0,4] that also receives (fx, fy, occl, sigma) per pixel."""
+        packed: optional pre-allocated [P,H0,W0,4] that also receives (fx, fy, occl, sigma) per pixel;
+        planar=False (with packed): only the packed result is written, flow = occl = sigma = None."""
         lib = _lib.load()
         P = fmap1.shape[0]
         pl, pr, pt, pb = pads
         H0, W0 = 8 * h - pt - pb, 8 * w - pl - pr
         dev = self.device
-        flow = torch.empty(P, 2, H0, W0, dtype=torch.float32, device=dev)
-        occl = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev)
-        sigma = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev)
+        if not planar and packed is None:
+            raise MftxError("refine: planar=False needs a packed output")
+        flow = torch.empty(P, 2, H0, W0, dtype=torch.float32, device=dev) if planar else None
+        occl = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev) if planar else None
+        sigma = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev) if planar else None
         flow_lr = torch.empty(P, h * w, 2, dtype=torch.float32, device=dev) if want_flow_lr else None
         if flow_init is not None and tuple(flow_init.shape) != (P, h * w, 2):
             raise MftxError("flow_init must be [P, h*w, 2]")
@@ -487,7 +490,8 @@ class RaftEngine:
                                    _chk(net, "net"), _chk(inp, "inp"),
                                    _chk(flow_init, "flow_init") if flow_init is not None else None,
                                    pl, pr, pt, pb,
-                                   flow.data_ptr(), occl.data_ptr(), sigma.data_ptr(),
+                                   flow.data_ptr() if planar else None, occl.data_ptr() if planar else None,
+                                   sigma.data_ptr() if planar else None,
                                    _chk(packed, "packed") if packed is not None else None,
                                    flow_lr.data_ptr() if want_flow_lr else None,
                                    ws.data_ptr(), ws.numel(), _stream()), "mftx_raft_refine")

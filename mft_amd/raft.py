@@ -16,6 +16,7 @@ norm, so per-frame encoding is exact) and the refinement a4-a12
 from __future__ import annotations
 
 import logging
+import os
 from pathlib import Path
 
 import numpy as np
@@ -58,6 +59,8 @@ class RAFTWrapper:
         self.fnet_engine = ops.EncoderEngine(self.sd, "fnet", True, self.device)
         self.cnet_engine = ops.EncoderEngine(self.sd, "cnet", False, self.device)
         self.engine = ops.RaftEngine(self.sd, self.device)
+        self._engine2 = None
+        self._split_streams = os.environ.get("MFTX_SPLIT_STREAMS", "0") not in ("", "0")
         self._frames = {}
         # Optional (C.async_encode): encode new frames on a side stream.  The encoders of frame t
         # only need the image, so with results kept on the device (no per-frame host sync) their
@@ -162,12 +165,13 @@ class RAFTWrapper:
 
     # ---- batched entry points used by the tracker --------------------------
     @torch.no_grad()
-    def compute_pairs(self, pairs, iters=None, init_flow=None, packed_out=None):
+    def compute_pairs(self, pairs, iters=None, init_flow=None, packed_out=None, planar=True):
         """pairs: [(left_id | None, left_img, right_id | None, right_img)] -> [(flow[2,H,W],
         occl[1,H,W], sigma[1,H,W])], left_i -> right_i for every i, in ONE engine call.  Frame ids key
         the feature cache (None = do not cache).  init_flow: optional [P,2,H,W] initial flows.
         packed_out: True, or a pre-allocated [P,H,W,4] tensor: the tuples get a fourth element, the same result
-        interleaved per pixel (fx, fy, occl, sigma) -- what ``mftx_chain_select_packed`` gathers from."""
+        interleaved per pixel (fx, fy, occl, sigma) -- what ``mftx_chain_select_packed`` gathers from;
+        planar=False then skips the planar outputs (the first three elements are None)."""
         iters = int(iters if iters is not None else self.C.flow_iters)
         fls = [self._features(lk, li) for lk, li, _, _ in pairs]
         frs = [self._features(rk, ri) for _, _, rk, ri in pairs]
@@ -183,15 +187,51 @@ class RAFTWrapper:
         if init_flow is not None:
             flow_init = self._init_flow_lr(init_flow, ref)
         packed = None
+        H0, W0 = ref.shape
+        P = len(pairs)
         if packed_out is not None and packed_out is not False:
-            H0, W0 = ref.shape
             packed = packed_out if isinstance(packed_out, torch.Tensor) else \
-                torch.empty(len(pairs), H0, W0, 4, dtype=torch.float32, device=self.device)
-        flow, occl, sigma = self.engine.refine(fmap1, fmap2, net, inp, ref.h, ref.w, iters, pads=ref.pads,
-                                               flow_init=flow_init, packed=packed)
+                torch.empty(P, H0, W0, 4, dtype=torch.float32, device=self.device)
+        want_planar = planar or packed is None
+        if self._split_streams and P >= 4 and flow_init is None:
+            flow, occl, sigma = self._refine_two_streams(fmap1, fmap2, net, inp, ref, iters, packed, want_planar)
+        else:
+            flow, occl, sigma = self.engine.refine(fmap1, fmap2, net, inp, ref.h, ref.w, iters, pads=ref.pads,
+                                                   flow_init=flow_init, packed=packed, planar=want_planar)
+        if packed is not None and flow is None:
+            return [(None, None, None, packed[i]) for i in range(P)]
         if packed is not None:
-            return [(flow[i], occl[i], sigma[i], packed[i]) for i in range(len(pairs))]
-        return [(flow[i], occl[i], sigma[i]) for i in range(len(pairs))]
+            return [(flow[i], occl[i], sigma[i], packed[i]) for i in range(P)]
+        return [(flow[i], occl[i], sigma[i]) for i in range(P)]
+
+    def _refine_two_streams(self, fmap1, fmap2, net, inp, geom, iters, packed, planar):
+        """Tuning option (MFTX_SPLIT_STREAMS=1): the batch as two halves on two HIP streams with their own
+        workspaces, so that one half's kernel tails and launch gaps are filled by the other half's kernels.
+        Same per-pair results (batch-invariant kernels)."""
+        P = fmap1.shape[0]
+        H0, W0 = geom.shape
+        n1 = (P + 1) // 2
+        if self._engine2 is None:
+            self._engine2 = ops.RaftEngine(self.sd, self.device)
+            self._side = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
+        dev = self.device
+        flow = torch.empty(P, 2, H0, W0, dtype=torch.float32, device=dev) if planar else None
+        occl = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev) if planar else None
+        sigma = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev) if planar else None
+        # workspaces are allocated up front on the calling stream
+        self.engine.workspace(n1, geom.h, geom.w)
+        self._engine2.workspace(P - n1, geom.h, geom.w)
+        main = torch.cuda.current_stream()
+        for eng, st, sl in ((self.engine, self._side[0], slice(0, n1)), (self._engine2, self._side[1], slice(n1, P))):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                f, o, s_ = eng.refine(fmap1[sl], fmap2[sl], net[sl], inp[sl], geom.h, geom.w, iters, pads=geom.pads,
+                                      packed=packed[sl] if packed is not None else None, planar=planar)
+                if planar:
+                    flow[sl].copy_(f); occl[sl].copy_(o); sigma[sl].copy_(s_)
+        for st in self._side:
+            main.wait_stream(st)
+        return flow, occl, sigma
 
     def compute_flow_many(self, lefts, right, iters=None):
         """lefts: [(frame_id | None, img)], right: (frame_id | None, img): left_i -> right for every i."""
