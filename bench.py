@@ -88,13 +88,16 @@ def build_tracker(args, sharded):
 
 def profile_pass(tracker, frames, first, steps):
     """Same kind of steps again (steady state, 7 pairs each) with HIP-event brackets around every kernel
-    launch.  Frames are encoded on the main stream here so that every kernel is timed alone (in the
-    timed region the encoders of frame t+1 overlap frame t on a side stream, which would stretch the
-    bracketed intervals)."""
+    launch.  Frames are encoded on the main stream and the 7 pairs run as one batch on one stream here, so
+    that every kernel is timed alone (in the timed region the encoders of frame t+1 overlap frame t on a side
+    stream and the batch runs as two halves on two streams -- overlapping kernels would stretch the bracketed
+    intervals; that overlap is why `ms_per_step` is a little below the sum of these per-kernel times)."""
     from mft_amd import _lib
     lib = _lib.load()
     enc_stream = getattr(tracker.flower, "_enc_stream", None)
+    split = getattr(tracker.flower, "_split_streams", 1)
     tracker.flower._enc_stream = None
+    tracker.flower._split_streams = 1          # (and the batch as one part on one stream, for the same reason)
     torch.cuda.synchronize()
     lib.mftx_profile_begin()
     pairs = []
@@ -102,6 +105,7 @@ def profile_pass(tracker, frames, first, steps):
         tracker.track(frames[i])
         pairs.append(len(tracker.last_pairs))
     tracker.flower._enc_stream = enc_stream
+    tracker.flower._split_streams = split
     n = len(CATS)
     ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
     _lib.check(lib.mftx_profile_end(ms, work, cnt, n), "mftx_profile_end")

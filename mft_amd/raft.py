@@ -59,8 +59,11 @@ class RAFTWrapper:
         self.fnet_engine = ops.EncoderEngine(self.sd, "fnet", True, self.device)
         self.cnet_engine = ops.EncoderEngine(self.sd, "cnet", False, self.device)
         self.engine = ops.RaftEngine(self.sd, self.device)
-        self._engine2 = None
-        self._split_streams = os.environ.get("MFTX_SPLIT_STREAMS", "0") not in ("", "0")
+        # C.split_streams (env MFTX_SPLIT_STREAMS overrides): batches of >= 6 pairs run as that many parts on
+        # separate HIP streams (see _refine_split); 1 = one stream.  Measured at 7 pairs, 512 x 512
+        # (profiles/r2_split_streams.txt): 1 / 2 / 3 / 4 / 7 parts = 63.0 / 64.9 / 59.4 / 60.6 / 49.8 frames/s.
+        self._split_streams = int(os.environ.get("MFTX_SPLIT_STREAMS", "") or getattr(config, "split_streams", 0) or 2)
+        self._engines, self._side = [], []
         self._frames = {}
         # Optional (C.async_encode): encode new frames on a side stream.  The encoders of frame t
         # only need the image, so with results kept on the device (no per-frame host sync) their
@@ -193,8 +196,8 @@ class RAFTWrapper:
             packed = packed_out if isinstance(packed_out, torch.Tensor) else \
                 torch.empty(P, H0, W0, 4, dtype=torch.float32, device=self.device)
         want_planar = planar or packed is None
-        if self._split_streams and P >= 4 and flow_init is None:
-            flow, occl, sigma = self._refine_two_streams(fmap1, fmap2, net, inp, ref, iters, packed, want_planar)
+        if self._split_streams > 1 and P >= 6 and flow_init is None:
+            flow, occl, sigma = self._refine_split(fmap1, fmap2, net, inp, ref, iters, packed, want_planar)
         else:
             flow, occl, sigma = self.engine.refine(fmap1, fmap2, net, inp, ref.h, ref.w, iters, pads=ref.pads,
                                                    flow_init=flow_init, packed=packed, planar=want_planar)
@@ -204,32 +207,34 @@ class RAFTWrapper:
             return [(flow[i], occl[i], sigma[i], packed[i]) for i in range(P)]
         return [(flow[i], occl[i], sigma[i]) for i in range(P)]
 
-    def _refine_two_streams(self, fmap1, fmap2, net, inp, geom, iters, packed, planar):
-        """Tuning option (MFTX_SPLIT_STREAMS=1): the batch as two halves on two HIP streams with their own
-        workspaces, so that one half's kernel tails and launch gaps are filled by the other half's kernels.
-        Same per-pair results (batch-invariant kernels)."""
+    def _refine_split(self, fmap1, fmap2, net, inp, geom, iters, packed, planar):
+        """The batch as ``C.split_streams`` parts on as many HIP streams, each with its own workspace: one part's
+        kernel tails, launch gaps and ragged last tile rounds are filled by the other parts' kernels (the
+        hardware interleaves workgroups of kernels from different streams).  Same per-pair results -- the
+        kernels are batch-invariant (``test_batch_invariance_bitwise``)."""
         P = fmap1.shape[0]
         H0, W0 = geom.shape
-        n1 = (P + 1) // 2
-        if self._engine2 is None:
-            self._engine2 = ops.RaftEngine(self.sd, self.device)
-            self._side = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
+        S = min(self._split_streams, P)
+        while len(self._engines) < S:
+            self._engines.append(ops.RaftEngine(self.sd, self.device) if self._engines else self.engine)
+            self._side.append(torch.cuda.Stream(device=self.device))
         dev = self.device
         flow = torch.empty(P, 2, H0, W0, dtype=torch.float32, device=dev) if planar else None
         occl = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev) if planar else None
         sigma = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev) if planar else None
-        # workspaces are allocated up front on the calling stream
-        self.engine.workspace(n1, geom.h, geom.w)
-        self._engine2.workspace(P - n1, geom.h, geom.w)
+        bounds = [(P * k) // S for k in range(S + 1)]
+        parts = [(self._engines[k], self._side[k], slice(bounds[k], bounds[k + 1])) for k in range(S)]
+        for eng, _, sl in parts:                      # workspaces are allocated up front, on the calling stream
+            eng.workspace(sl.stop - sl.start, geom.h, geom.w)
         main = torch.cuda.current_stream()
-        for eng, st, sl in ((self.engine, self._side[0], slice(0, n1)), (self._engine2, self._side[1], slice(n1, P))):
+        for eng, st, sl in parts:
             st.wait_stream(main)
             with torch.cuda.stream(st):
                 f, o, s_ = eng.refine(fmap1[sl], fmap2[sl], net[sl], inp[sl], geom.h, geom.w, iters, pads=geom.pads,
                                       packed=packed[sl] if packed is not None else None, planar=planar)
                 if planar:
                     flow[sl].copy_(f); occl[sl].copy_(o); sigma[sl].copy_(s_)
-        for st in self._side:
+        for _, st, _ in parts:
             main.wait_stream(st)
         return flow, occl, sigma
 
