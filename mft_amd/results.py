@@ -80,18 +80,15 @@ class FlowOUTrackingResult(object):
     # ---- IO (MFT/results.py:61-72): the reference's .flowouX16 cache entry, quantised on the device
     # (mft_amd/flowou_codec.py); any other name is a plain fp32 pickle of the three arrays ------
     def write(self, path):
-        """``*.flowouX16.pkl`` -- the reference's uint16-quantised entry (MFT/results.py:61-65,
-        MFT/utils/io.py:179-198), quantised on the device; any other name: a plain fp32 pickle.
-        (The fixed-point ``.flowou.png`` and the ``.flowouX32`` variants are not rebuilt.)"""
+        """``*.flowou.png`` / ``*.flowouX16.pkl`` / ``*.flowouX32.pkl``: the reference's cache-entry formats
+        (MFT/results.py:61-65 -> MFT/utils/io.py:174-197; X16 is quantised on the device); any other name: a plain
+        fp32 pickle."""
         from pathlib import Path
         suffixes = Path(path).suffixes
-        if suffixes and suffixes[0] == ".flowouX16":
-            from .flowou_codec import write_flowou_X16
-            dev = self.flow.device if self.flow.is_cuda else "cuda"
-            write_flowou_X16(path, self.flow.to(dev), self.occlusion.to(dev), self.sigma.to(dev))
+        if suffixes and suffixes[0] in (".flowou", ".flowouX16", ".flowouX32"):
+            from .flowou_codec import write_flowou
+            write_flowou(path, self.flow, self.occlusion, self.sigma)
             return
-        if suffixes and suffixes[0] in (".flowou", ".flowouX32"):
-            raise NotImplementedError(f"{suffixes[0]} entries are not supported, use .flowouX16.pkl")
         with open(path, "wb") as f:
             pickle.dump({k: getattr(self, k).detach().cpu().numpy() for k in ("flow", "occlusion", "sigma")}, f)
 
@@ -100,9 +97,9 @@ class FlowOUTrackingResult(object):
         """Counterpart of ``write``; like the reference (MFT/results.py:67-72) the result is on the host."""
         from pathlib import Path
         suffixes = Path(path).suffixes
-        if suffixes and suffixes[0] == ".flowouX16":
-            from .flowou_codec import read_flowou_X16
-            return FlowOUTrackingResult(*(t.cpu() for t in read_flowou_X16(path)))
+        if suffixes and suffixes[0] in (".flowou", ".flowouX16", ".flowouX32"):
+            from .flowou_codec import read_flowou
+            return FlowOUTrackingResult(*(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)) for a in read_flowou(path)))
         with open(path, "rb") as f:
             d = pickle.load(f)
         return FlowOUTrackingResult(torch.from_numpy(d["flow"]), torch.from_numpy(d["occlusion"]),

@@ -188,6 +188,74 @@ def test_result_write_read_flowouX16(tmp_path):
         r.write(tmp_path / "x.flowou.png")
 
 
+def test_flowou_png_and_X32_vs_reference_golden(golden_dir, tmp_path):
+    """``.flowou.png`` (16-bit fixed point) and ``.flowouX32.pkl`` against what the REFERENCE's own writers handed to
+    cv2 and its readers returned (tests/golden/codec.npz, captured under a cv2 stub): planes and decoded arrays
+    bit for bit, through real files and the product's own PNG coder."""
+    import golden_inputs as gi
+    g = np.load(golden_dir / "codec.npz")
+    d = gi.codec_inputs()
+    # .flowou.png
+    p1 = tmp_path / "sub" / "3--5.flowou.png"
+    fc.write_flowou(p1, d["flow"], d["occl"], d["sigma"])
+    with open(p1, "rb") as fh:
+        assert np.array_equal(fc.cv2_imdecode_png(fh.read()), g["png16_bgra"])       # what cv2.imread would return
+    f, o, s_ = fc.read_flowou(p1)
+    assert f.dtype == np.float32
+    assert np.array_equal(f, g["png16_dec_flow"]) and np.array_equal(o, g["png16_dec_occl"])
+    assert np.array_equal(s_, g["png16_dec_sigma"])
+    with pytest.raises(AssertionError):
+        fc.write_flowou(tmp_path / "x.flowou.png", d["flow"] * 1000, d["occl"], d["sigma"])   # |flow| >= 1024
+    # .flowouX32.pkl
+    p2 = tmp_path / "3--5.flowouX32.pkl"
+    with np.errstate(invalid="ignore"):
+        fc.write_flowou(p2, d["flow"], d["occl"], d["sigma"])
+    with open(p2, "rb") as fh:
+        pk = pickle.load(fh)
+    for i, name in enumerate(fc.CHANNELS):
+        assert np.array_equal(fc.cv2_imdecode_png(pk[name]["data"]), g["x32_bgra"][i]), name
+        assert np.float32(pk[name]["min"]) == g["x32_lohi"][i, 0] and np.float32(pk[name]["max"]) == g["x32_lohi"][i, 1]
+    f, o, s_ = fc.read_flowou(p2)
+    assert np.array_equal(f, g["x32_dec_flow"]) and np.array_equal(o, g["x32_dec_occl"])
+    assert np.array_equal(s_, g["x32_dec_sigma"])
+    with pytest.raises(ValueError):
+        fc.read_flowou(tmp_path / "a.flowou2.png")
+    # FlowOUTrackingResult.write / read dispatch on the suffix (MFT/results.py:61-72)
+    from mft_amd.results import FlowOUTrackingResult
+    r = FlowOUTrackingResult(torch.from_numpy(d["flow"]), torch.from_numpy(d["occl"]), torch.from_numpy(d["sigma"]))
+    r.write(tmp_path / "r.flowou.png")
+    back = FlowOUTrackingResult.read(tmp_path / "r.flowou.png")
+    assert np.array_equal(back.flow.numpy(), g["png16_dec_flow"])
+
+
+def test_png_16bit_rgba_every_filter_type():
+    """16-bit RGBA rows (bpp = 8) through the C scanline reconstruction, all filter types."""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 65536, size=(9, 11, 4)).astype(np.uint16)
+    H, W, _ = img.shape
+    be = img.astype(">u2").view(np.uint8).reshape(H, W * 8).astype(np.int32)
+    bpp, rb = 8, W * 8
+    raw = bytearray()
+    for y in range(H):
+        ft = y % 5
+        cur, prev = be[y], (be[y - 1] if y else np.zeros(rb, np.int32))
+        out = np.zeros(rb, np.int32)
+        for i in range(rb):
+            a = cur[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            pred = [0, a, b, (a + b) // 2, paeth(int(a), int(b), int(c))][ft]
+            out[i] = (cur[i] - pred) & 0xFF
+        raw.append(ft)
+        raw += bytes(out.astype(np.uint8))
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+    png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 16, 6, 0, 0, 0)) +
+           chunk(b"IDAT", zlib.compress(bytes(raw), 6)) + chunk(b"IEND", b""))
+    assert np.array_equal(fc.png_decode(png), img)
+
+
 @pytest.mark.gpu
 def test_device_codec_vs_reference_golden(golden_dir, tmp_path):
     """mftx_quantize_u16 / mftx_dequantize_u16 and the container against what the REFERENCE's own

@@ -47,7 +47,20 @@ def _imdecode(buf, flags):
     return CV2_CAPTURED[int(np.asarray(buf).reshape(-1)[0])].copy()
 
 
-cv2.imencode, cv2.imdecode = _imencode, _imdecode
+CV2_FILES = {}
+
+
+def _imwrite(path, arr):
+    CV2_FILES[str(path)] = np.array(arr, copy=True)
+    return True
+
+
+def _imread(path, flags=None):
+    return CV2_FILES[str(path)].copy()
+
+
+cv2.IMREAD_ANYDEPTH = 2
+cv2.imencode, cv2.imdecode, cv2.imwrite, cv2.imread = _imencode, _imdecode, _imwrite, _imread
 sys.modules["cv2"] = cv2
 
 import torch  # noqa: E402
@@ -363,6 +376,21 @@ def gen_codec():
         flow, occl, sigma = refio.read_flowou_X16(path)
         out["dec_flow"], out["dec_occl"], out["dec_sigma"] = (np.asarray(a, np.float32) for a in (flow, occl, sigma))
         assert flow.dtype == np.float32
+        # the other two formats (MFT/utils/io.py:222-291, 372-443)
+        p1 = Path(tmp) / "3--5.flowou.png"
+        refio.write_flowou1_png(p1, d["flow"], d["occl"], d["sigma"])
+        out["png16_bgra"] = CV2_FILES[str(p1)]                                 # uint16 [H, W, 4] handed to cv2.imwrite
+        f1, o1, s1 = refio.read_flowou1_png(p1)
+        out["png16_dec_flow"], out["png16_dec_occl"], out["png16_dec_sigma"] = (np.asarray(a) for a in (f1, o1, s1))
+        del CV2_CAPTURED[:]
+        p2 = str(Path(tmp) / "3--5.flowouX32.pkl")
+        refio.write_flowou_X32(p2, d["flow"], d["occl"], d["sigma"])
+        out["x32_bgra"] = np.stack(CV2_CAPTURED)                               # [4, H, W, 4] uint8
+        with open(p2, "rb") as f:
+            pk = pickle.load(f)
+        out["x32_lohi"] = np.array([[pk[n]["min"], pk[n]["max"]] for n in names], np.float32)
+        f2, o2, s2 = refio.read_flowou_X32(p2)
+        out["x32_dec_flow"], out["x32_dec_occl"], out["x32_dec_sigma"] = (np.asarray(a) for a in (f2, o2, s2))
     np.savez_compressed(OUT / "codec.npz", **out)
     print("codec.npz", sum(v.nbytes for v in out.values()) / 1e3, "kB")
 
