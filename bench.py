@@ -286,7 +286,7 @@ def main():
 
     from mft_amd.synth import SyntheticVideo
     preroll = FIRST_FULL_FRAME - 1                                # untimed: frames 1 .. 32; warm-up starts at frame 33
-    n_io = 0 if (args.no_host_io or world > 1 or args.force_sharded) else max(4, args.steps // 2)
+    n_io = 0 if (args.no_host_io or world > 1 or args.force_sharded) else max(8, args.steps)
     n_prof = 0 if args.no_profile else args.steps
     n_frames = 1 + preroll + args.warmup + args.steps + n_prof + n_io
     vid = SyntheticVideo(args.height, args.width, n_frames=max(n_frames, 48), seed=0)
@@ -365,14 +365,22 @@ def main():
             result["kernels"] = kernels
     if not sharded and rank == 0:
         if n_io:
-            # PCIe-inclusive variant of the same loop: numpy frames in, CPU results out
-            conf.keep_result_on_device = False
+            # PCIe-inclusive variant of the same loop: numpy frames in through the pinned upload ring, results out to
+            # pinned host memory on a copy stream (mft_amd/video.py) -- every frame crosses PCIe in, every result out
+            from mft_amd.video import FrameRing, ResultDrain
             base = first + args.steps + n_prof
+            drain = ResultDrain()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i in range(base, base + n_io):
-                tracker.track(host_frames[i])
+            got = 0
+            for dev_frame in FrameRing(host_frames[base: base + n_io], depth=4):
+                drain.submit(tracker.track(dev_frame).result)
+                while len(drain) > 2:
+                    drain.collect(); got += 1
+            while len(drain):
+                drain.collect(); got += 1
             torch.cuda.synchronize()
+            assert got == n_io
             result["host_io_fps"] = n_io / (time.perf_counter() - t0)
             log("host-io pass done")
         torch.set_num_threads(oracle_threads())

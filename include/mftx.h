@@ -82,6 +82,18 @@ int mftx_corr_lookup(const float *lvl0, const float *lvl1, const float *lvl2, co
                      const float *coords, int P, int h, int w, int r,
                      float *out, int ld_out, void *stream);
 
+/* ---- a17: on-demand correlation lookup (no stored volume) ------------------------------------------------
+ * Replaces AlternateCorrBlock + the optional CUDA op alt_cuda_corr (MFT/RAFT/core/corr.py:72-100,
+ * alt_cuda_corr/correlation_kernel.cu:18-119; raft_params.alternate_corr).  mftx_fmap_pyramid average-pools the
+ * SECOND feature map three times (pixel-major [P][h_l*w_l][C] per level, 2x2 means, floor sizes);
+ * mftx_corr_lookup_ondemand evaluates <f1[cell], f2_l[tap]> / sqrt(C) for the 10x10 taps of every level and blends
+ * them exactly like mftx_corr_lookup: same output layout, equal up to fp32 rounding (pooling the features equals
+ * pooling the volume over the target dims).  C must be 256, r must be 4. */
+int mftx_fmap_pyramid(const float *f2, int P, int C, int h, int w, float *lvl1, float *lvl2, float *lvl3, void *stream);
+int mftx_corr_lookup_ondemand(const float *f1, const float *f2l0, const float *f2l1, const float *f2l2, const float *f2l3,
+                              const float *coords, int P, int C, int h, int w, int r,
+                              float *out, int ld_out, void *stream);
+
 /* ---- a7-a9, a11: one convolution as an fp32-MFMA implicit GEMM -------------
  * Replaces the nn.Conv2d calls of core/update.py (zero "same" padding, bias,
  * optional activation).  Input = up to two pixel-major segments concatenated on
@@ -120,6 +132,11 @@ typedef struct mftx_raft mftx_raft;
 int mftx_raft_create(const float *const *weights, int n_weights, mftx_raft **out);
 void mftx_raft_destroy(mftx_raft *r);
 size_t mftx_raft_workspace_bytes(int P, int h, int w);
+/* on != 0: mftx_raft_refine uses the on-demand correlation (a17) instead of the stored pyramid -- no N x N volume in
+ * the workspace (29.8 GB per 7-pair 1080p frame), 4-5x more time per lookup at 512x512, about even at 1080p.
+ * mftx_raft_workspace_bytes_for gives the workspace size for the handle's current mode. */
+int mftx_raft_set_ondemand(mftx_raft *r, int on);
+size_t mftx_raft_workspace_bytes_for(const mftx_raft *r, int P, int h, int w);
 /* Byte offsets (19 of them) of the workspace regions lvl0..3, coords1, corr,
  * cor1, corflo, flo1, hx, z, rh, fh, delta, mask, ouin, ouh, ou, flow_lr: after
  * mftx_raft_refine they hold the intermediates of the last iteration (tests). */

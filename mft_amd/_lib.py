@@ -38,6 +38,10 @@ SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mftx_corr_pyramid_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "mftx_corr_lookup": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p]),
+    "mftx_fmap_pyramid": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 4),
+    "mftx_corr_lookup_ondemand": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p, C.c_int, C.c_void_p]),
+    "mftx_raft_set_ondemand": (C.c_int, [C.c_void_p, C.c_int]),
+    "mftx_raft_workspace_bytes_for": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mftx_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "mftx_raft_create": (C.c_int, [_PP, C.c_int, C.POINTER(C.c_void_p)]),
     "mftx_raft_destroy": (None, [C.c_void_p]),

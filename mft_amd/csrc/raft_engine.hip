@@ -98,12 +98,13 @@ enum WeightSlot {
 
 struct Workspace {
     float *lvl[4];
+    float *f2l[3];                 // on-demand correlation: the pooled second feature map, levels 1..3
     float *coords1, *corr, *cor1, *corflo, *flo1, *hx, *z, *rh, *fh, *delta, *mask, *ouin, *ouh, *ou, *flow_lr;
     float *pre_zr[2], *pre_q[2];   // inp part of the GRU gate convolutions (+ bias), per pass
     size_t bytes;
 };
 
-static Workspace carve(void *base, int P, int h, int w) {
+static Workspace carve(void *base, int P, int h, int w, bool ondemand = false) {
     Workspace ws{};
     const size_t N = (size_t)h * w, M = (size_t)P * N;
     size_t off = 0;
@@ -113,7 +114,8 @@ static Workspace carve(void *base, int P, int h, int w) {
         return p;
     };
     const PyramidLayout L = pyramid_layout(h, w);
-    for (int l = 0; l < 4; ++l) ws.lvl[l] = take(M * (size_t)L.stride[l]);
+    for (int l = 0; l < 4; ++l) ws.lvl[l] = take(ondemand ? 0 : M * (size_t)L.stride[l]);
+    for (int l = 1; l < 4; ++l) ws.f2l[l - 1] = take(ondemand ? (size_t)P * (h >> l) * (w >> l) * 256 : 0);
     ws.coords1 = take(M * 2);
     ws.corr = take(M * 324);
     ws.cor1 = take(M * 256);
@@ -140,6 +142,7 @@ using namespace mftx;
 
 struct mftx_raft {
     uint32_t magic;
+    int ondemand;                  // 1: on-demand correlation (no volume), see csrc/corr_ondemand.hip
     const float *w[W_COUNT];
 };
 static constexpr uint32_t RAFT_MAGIC = 0x4d465458;  // "MFTX"
@@ -154,6 +157,7 @@ extern "C" int mftx_raft_create(const float *const *weights, int n_weights, mftx
     mftx_raft *r = new (std::nothrow) mftx_raft;
     if (!r) return fail(MFTX_E_ARG, "raft_create: out of host memory");
     r->magic = RAFT_MAGIC;
+    r->ondemand = 0;
     for (int i = 0; i < W_COUNT; ++i) r->w[i] = weights[i];
     *out = r;
     return 0;
@@ -166,6 +170,17 @@ extern "C" void mftx_raft_destroy(mftx_raft *r) {
 extern "C" size_t mftx_raft_workspace_bytes(int P, int h, int w) {
     if (P <= 0 || h <= 0 || w <= 0) return 0;
     return carve(nullptr, P, h, w).bytes;
+}
+
+extern "C" int mftx_raft_set_ondemand(mftx_raft *r, int on) {
+    if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_ondemand: bad handle");
+    r->ondemand = on ? 1 : 0;
+    return 0;
+}
+
+extern "C" size_t mftx_raft_workspace_bytes_for(const mftx_raft *r, int P, int h, int w) {
+    if (!r || r->magic != RAFT_MAGIC || P <= 0 || h <= 0 || w <= 0) return 0;
+    return carve(nullptr, P, h, w, r->ondemand != 0).bytes;
 }
 
 // Byte offsets of the workspace regions, in the order lvl0..3, coords1, corr,
@@ -214,7 +229,8 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     if (pad_left < 0 || pad_right < 0 || pad_top < 0 || pad_bottom < 0 || pad_left + pad_right >= 8 ||
         pad_top + pad_bottom >= 8)
         return fail(MFTX_E_ARG, "raft_refine: bad padding");
-    Workspace ws = carve(workspace, P, h, w);
+    const bool ondemand = r->ondemand != 0;
+    Workspace ws = carve(workspace, P, h, w, ondemand);
     if (ws.bytes > workspace_bytes)
         return fail(MFTX_E_WORKSPACE, "raft_refine: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
     hipStream_t s = (hipStream_t)stream;
@@ -222,7 +238,9 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     const float *const *W = r->w;
 
     // correlation volume + pyramid (core/corr.py:14-28)
-    TRY(launch_corr_pyramid(fmap1, fmap2, P, 256, h, w, ws.lvl, s));
+    const float *f2lv[4] = {fmap2, ws.f2l[0], ws.f2l[1], ws.f2l[2]};
+    if (ondemand) TRY(launch_fmap_pyramid(fmap2, P, 256, h, w, ws.f2l, s));   // core/corr.py:78-82 (only fmap2's pyramid is used)
+    else TRY(launch_corr_pyramid(fmap1, fmap2, P, 256, h, w, ws.lvl, s));
     {
         const long long slots = (long long)M * 64;
         ProfScope prof(PC_GLUE, s, 0);
@@ -248,8 +266,9 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
             const ConvF1Args f1{ws.coords1, W[W_CONVF1], W[B_CONVF1], ws.flo1, ws.hx, h, w, strips, P * h * strips};
             const int f1_blocks = cdiv(f1.n_strips, 2);
             static const bool nofuse = getenv("MFTX_RAFT_NOFUSE") != nullptr;
-            if (prof_enabled() || nofuse) {
-                TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, 324, s));
+            if (prof_enabled() || nofuse || ondemand) {
+                if (ondemand) TRY(launch_corr_ondemand(fmap1, f2lv, ws.coords1, P, h, w, ws.corr, 324, s));
+                else TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, 324, s));
                 ProfScope prof(PC_CONVF1, s, 2.0 * M * 128 * 98);
                 hipLaunchKernelGGL(convf1_kernel, dim3(f1_blocks), dim3(256), 0, s, f1);
             } else {
@@ -340,6 +359,28 @@ extern "C" int mftx_corr_lookup(const float *lvl0, const float *lvl1, const floa
     if (!aligned16(lvl0) || !aligned16(lvl1)) return fail(MFTX_E_ALIGN, "corr_lookup: levels 0 and 1 must be 16-byte aligned");
     const float *lv[4] = {lvl0, lvl1, lvl2, lvl3};
     return launch_corr_lookup(lv, coords, P, h, w, out, ld_out, (hipStream_t)stream);
+}
+
+extern "C" int mftx_fmap_pyramid(const float *f2, int P, int C, int h, int w, float *lvl1, float *lvl2, float *lvl3,
+                                 void *stream) {
+    if (!f2 || !lvl1 || !lvl2 || !lvl3) return fail(MFTX_E_ARG, "fmap_pyramid: null pointer");
+    if (P <= 0 || C <= 0 || C % 4 || h < 8 || w < 8) return fail(MFTX_E_ARG, "fmap_pyramid: need C %% 4 == 0, h, w >= 8");
+    if (!aligned16(f2) || !aligned16(lvl1) || !aligned16(lvl2) || !aligned16(lvl3))
+        return fail(MFTX_E_ALIGN, "fmap_pyramid: maps must be 16-byte aligned");
+    float *const lv[3] = {lvl1, lvl2, lvl3};
+    return launch_fmap_pyramid(f2, P, C, h, w, lv, (hipStream_t)stream);
+}
+
+extern "C" int mftx_corr_lookup_ondemand(const float *f1, const float *f2l0, const float *f2l1, const float *f2l2,
+                                         const float *f2l3, const float *coords, int P, int C, int h, int w, int r,
+                                         float *out, int ld_out, void *stream) {
+    if (!f1 || !f2l0 || !f2l1 || !f2l2 || !f2l3 || !coords || !out) return fail(MFTX_E_ARG, "corr_lookup_ondemand: null pointer");
+    if (r != 4 || C != 256) return fail(MFTX_E_ARG, "corr_lookup_ondemand: only radius 4, 256 channels (RAFT basic) are built");
+    if (P <= 0 || h < 8 || w < 8 || ld_out < 324) return fail(MFTX_E_ARG, "corr_lookup_ondemand: bad sizes");
+    if (!aligned16(f1) || !aligned16(f2l0) || !aligned16(f2l1) || !aligned16(f2l2) || !aligned16(f2l3))
+        return fail(MFTX_E_ALIGN, "corr_lookup_ondemand: feature maps must be 16-byte aligned");
+    const float *lv[4] = {f2l0, f2l1, f2l2, f2l3};
+    return launch_corr_ondemand(f1, lv, coords, P, h, w, out, ld_out, (hipStream_t)stream);
 }
 
 extern "C" int mftx_conv2d(const mftx_conv_desc *d, void *stream) {

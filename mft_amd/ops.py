@@ -262,6 +262,27 @@ def corr_lookup(lv, coords: torch.Tensor, h: int, w: int, r: int = 4):
     return out
 
 
+def fmap_pyramid(f2: torch.Tensor, h: int, w: int):
+    """f2 pixel-major [P, h*w, C] -> [f2, pooled level 1, 2, 3] ([P, h_l*w_l, C]); the feature pyramid of the
+    on-demand correlation (AlternateCorrBlock, core/corr.py:78-82)."""
+    lib = _lib.load()
+    P, N, Cc = f2.shape
+    assert N == h * w
+    lv = [torch.empty(P, (h >> l) * (w >> l), Cc, dtype=torch.float32, device=f2.device) for l in (1, 2, 3)]
+    check(lib.mftx_fmap_pyramid(_chk(f2, "f2"), P, Cc, h, w, *[t.data_ptr() for t in lv], _stream()), "mftx_fmap_pyramid")
+    return [f2] + lv
+
+
+def corr_lookup_ondemand(f1: torch.Tensor, f2_levels, coords: torch.Tensor, h: int, w: int, r: int = 4):
+    """f1 [P, h*w, 256], f2_levels from ``fmap_pyramid``, coords [P, h*w, 2] -> [P, h*w, 324] (as ``corr_lookup``)."""
+    lib = _lib.load()
+    P, N, Cc = f1.shape
+    out = torch.empty(P, N, 324, dtype=torch.float32, device=f1.device)
+    check(lib.mftx_corr_lookup_ondemand(_chk(f1, "f1"), *[_chk(t, "f2 level") for t in f2_levels], _chk(coords, "coords"),
+                                        P, Cc, h, w, r, out.data_ptr(), 324, _stream()), "mftx_corr_lookup_ondemand")
+    return out
+
+
 def conv2d(x: torch.Tensor, wpk: torch.Tensor, bias, P, h, w, N, kh, kw, act=None, out_scale=1.0, x2=None,
            addend=None, stride=0, hin=0, win=0, pad_y=0, pad_x=0, residual_mode=0):
     """x: pixel-major [P*h*w, C0] (optionally concatenated with x2 [P*h*w, C1]) ->
@@ -428,7 +449,7 @@ def dequantize_u16(q, lo, hi):
 class RaftEngine:
     """Handle on the native refinement runtime (``mftx_raft_*``)."""
 
-    def __init__(self, state_dict: dict, device):
+    def __init__(self, state_dict: dict, device, ondemand_corr=False):
         lib = _lib.load()
         self.device = torch.device(device)
         self.weights = pack_raft_weights(state_dict, self.device)   # keep alive: the engine holds raw pointers
@@ -437,6 +458,9 @@ class RaftEngine:
         check(lib.mftx_raft_create(arr, len(self.weights), C.byref(handle)), "mftx_raft_create")
         self._h = handle
         self._ws = None
+        self.ondemand_corr = bool(ondemand_corr)
+        if self.ondemand_corr:                 # raft_params.alternate_corr: no stored correlation volume
+            check(lib.mftx_raft_set_ondemand(self._h, 1), "mftx_raft_set_ondemand")
 
     def __del__(self):
         try:
@@ -447,7 +471,7 @@ class RaftEngine:
             pass
 
     def workspace(self, P, h, w):
-        need = _lib.load().mftx_raft_workspace_bytes(P, h, w)
+        need = _lib.load().mftx_raft_workspace_bytes_for(self._h, P, h, w)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws

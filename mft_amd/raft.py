@@ -58,7 +58,9 @@ class RAFTWrapper:
         self.sd = {k: v.to(self.device) for k, v in sd.items()}
         self.fnet_engine = ops.EncoderEngine(self.sd, "fnet", True, self.device)
         self.cnet_engine = ops.EncoderEngine(self.sd, "cnet", False, self.device)
-        self.engine = ops.RaftEngine(self.sd, self.device)
+        # raft_params.alternate_corr (core/raft.py:137-138): correlation on demand instead of the stored volume
+        self._ondemand = bool(getattr(getattr(config, "raft_params", None), "alternate_corr", False))
+        self.engine = ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand)
         # C.split_streams (env MFTX_SPLIT_STREAMS overrides): batches of >= 6 pairs run as that many parts on
         # separate HIP streams (see _refine_split); 1 = one stream.  Measured at 7 pairs, 512 x 512
         # (profiles/r2_split_streams.txt): 1 / 2 / 3 / 4 / 7 parts = 63.0 / 64.9 / 59.4 / 60.6 / 49.8 frames/s.
@@ -216,7 +218,8 @@ class RAFTWrapper:
         H0, W0 = geom.shape
         S = min(self._split_streams, P)
         while len(self._engines) < S:
-            self._engines.append(ops.RaftEngine(self.sd, self.device) if self._engines else self.engine)
+            self._engines.append(ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand)
+                                 if self._engines else self.engine)
             self._side.append(torch.cuda.Stream(device=self.device))
         dev = self.device
         flow = torch.empty(P, 2, H0, W0, dtype=torch.float32, device=dev) if planar else None

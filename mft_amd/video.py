@@ -1,0 +1,203 @@
+"""Video ingest -- drop-in for ``GeneralVideoCapture`` / ``get_video_frames`` / ``get_video_length``
+(``MFT/utils/io.py:566-615``) plus what the MI355X path adds: a pinned-host -> HBM frame ring that uploads
+frame t+1.. while frame t is being tracked, and its mirror for results coming back.
+
+Sources: a directory of images (``.png`` decoded by this package's own PNG coder; ``.jpg`` / ``.jpeg`` and
+container formats need OpenCV, which is used when it is importable and reported clearly when it is not), or
+a ``.npy`` / ``.npz`` array of frames ``[T, H, W, 3]`` uint8 BGR.  Frames are BGR ``(H, W, 3)`` uint8 like
+``cv2.imread`` returns them.
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+
+import numpy as np
+import torch
+
+IMAGE_SUFFIXES = ('.jpg', '.png', '.jpeg')
+
+
+def _cv2():
+    try:
+        import cv2
+        return cv2
+    except ImportError:
+        return None
+
+
+def imread_bgr(path):
+    """``cv2.imread(path)``: 8-bit BGR (alpha dropped, 16-bit scaled down) -- PNG natively, the rest through cv2."""
+    path = Path(path)
+    if path.suffix.lower() == '.png':
+        from .flowou_codec import png_decode
+        img = png_decode(path.read_bytes())
+        if img.dtype == np.uint16:
+            img = (img >> 8).astype(np.uint8)
+        return np.ascontiguousarray(img[..., [2, 1, 0]])
+    cv2 = _cv2()
+    if cv2 is None:
+        raise RuntimeError(f"cannot decode {path.name}: only PNG is decoded natively, {path.suffix} needs OpenCV (cv2)")
+    return cv2.imread(str(path))
+
+
+def imread_unchanged(path):
+    """``cv2.imread(path, cv2.IMREAD_UNCHANGED)`` for a PNG: (B, G, R[, A]) channel order, depth kept."""
+    from .flowou_codec import cv2_imdecode_png
+    return cv2_imdecode_png(Path(path).read_bytes())
+
+
+def imwrite_bgr(path, img):
+    """``cv2.imwrite`` for ``.png``: (H, W, 3 | 4) uint8 / uint16 in (B, G, R[, A]) order."""
+    from .flowou_codec import cv2_imencode_png
+    Path(path).parent.mkdir(parents=True, exist_ok=True)
+    Path(path).write_bytes(cv2_imencode_png(np.asarray(img)).tobytes())
+
+
+class GeneralVideoCapture(object):
+    """A cv2.VideoCapture replacement that can also read images in a directory (and frame arrays)."""
+
+    def __init__(self, path, reverse=False):
+        path = Path(path)
+        self.image_inputs = path.is_dir()
+        self.array = None
+        self.cap = None
+        self.i = 0
+        if self.image_inputs:
+            self.path = path
+            self.images = sorted([f for f in next(os.walk(path))[2] if os.path.splitext(f)[1].lower() in IMAGE_SUFFIXES])
+            if reverse:
+                self.images = self.images[::-1]
+        elif path.suffix.lower() in ('.npy', '.npz'):
+            arr = np.load(path)
+            if not isinstance(arr, np.ndarray):
+                arr = arr[arr.files[0]]
+            if arr.ndim != 4 or arr.shape[-1] != 3 or arr.dtype != np.uint8:
+                raise ValueError("frame array must be [T, H, W, 3] uint8 (BGR)")
+            self.array = arr[::-1] if reverse else arr
+        else:
+            cv2 = _cv2()
+            if cv2 is None:
+                raise RuntimeError(f"cannot open {path}: video containers need OpenCV (cv2); give a directory of "
+                                   "PNG frames or a .npy / .npz frame array instead")
+            self.cap = cv2.VideoCapture(str(path))
+
+    def read(self):
+        if self.image_inputs:
+            if self.i >= len(self.images):
+                return False, None
+            self.frame_src = self.images[self.i]
+            img = imread_bgr(self.path / self.images[self.i])
+            self.i += 1
+            return True, img
+        if self.array is not None:
+            if self.i >= len(self.array):
+                return False, None
+            self.i += 1
+            return True, np.ascontiguousarray(self.array[self.i - 1])
+        return self.cap.read()
+
+    def release(self):
+        return None if self.cap is None else self.cap.release()
+
+
+def get_video_frames(path):
+    cap = GeneralVideoCapture(path)
+    while True:
+        success, frame = cap.read()
+        if not success or frame is None:
+            return None
+        yield frame
+
+
+def get_video_length(path):
+    N = 0
+    for _ in get_video_frames(path):
+        N += 1
+    return N
+
+
+class FrameRing:
+    """Host frames -> HBM through ``depth`` pinned staging buffers and a copy stream: while the tracker works on
+    frame t the uploads of frames t+1 .. t+depth-1 are already in flight, so ``MFT.track`` never waits for PCIe.
+
+        for dev_frame in FrameRing(get_video_frames(path)):
+            meta = tracker.track(dev_frame)          # uint8 (H, W, 3) device tensor
+
+    A yielded tensor stays valid until ``depth`` more frames have been taken from the ring (the tracker keeps
+    frames in ``memory`` for up to 32 steps: pass ``keep=True`` to get private device copies instead of ring slots).
+    """
+
+    def __init__(self, frames, depth=4, device="cuda", keep=True):
+        self.frames = iter(frames)
+        self.depth = max(2, int(depth))
+        self.device = torch.device(device)
+        self.keep = keep
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._pinned, self._dev, self._events = [], [], []
+
+    def _alloc(self, shape):
+        for _ in range(self.depth):
+            self._pinned.append(torch.empty(shape, dtype=torch.uint8).pin_memory())
+            self._dev.append(torch.empty(shape, dtype=torch.uint8, device=self.device))
+            self._events.append(torch.cuda.Event())
+
+    def _submit(self, slot, frame):
+        if not self._pinned:
+            self._alloc(frame.shape)
+        self._events[slot].synchronize()              # the slot's previous upload has finished: host buffer is free
+        self._pinned[slot].copy_(torch.from_numpy(np.ascontiguousarray(frame)))
+        # consumers of the slot's previous contents were enqueued on the caller's stream before this point
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            self._dev[slot].copy_(self._pinned[slot], non_blocking=True)
+            self._events[slot].record(self.stream)
+
+    def __iter__(self):
+        pending = []                                  # slots in flight, oldest first
+        nxt = 0
+        for frame in self.frames:
+            self._submit(nxt % self.depth, frame)
+            pending.append(nxt % self.depth)
+            nxt += 1
+            if len(pending) == self.depth - 1:
+                yield self._take(pending.pop(0))
+        while pending:
+            yield self._take(pending.pop(0))
+
+    def _take(self, slot):
+        torch.cuda.current_stream(self.device).wait_event(self._events[slot])
+        return self._dev[slot].clone() if self.keep else self._dev[slot]
+
+
+class ResultDrain:
+    """Device results -> pinned host memory on a copy stream (the D2H mirror of ``FrameRing``): ``submit`` enqueues
+    the copies of a result's three planes behind the kernels that produce them and returns immediately;
+    ``collect`` waits for one and hands back CPU tensors."""
+
+    def __init__(self, device="cuda"):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._queue = []
+
+    def submit(self, result):
+        planes = result.planes() if hasattr(result, "planes") else tuple(result)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        host = []
+        with torch.cuda.stream(self.stream):
+            for t in planes:
+                h = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+                h.copy_(t, non_blocking=True)
+                t.record_stream(self.stream)
+                host.append(h)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._queue.append((ev, host))
+
+    def collect(self):
+        ev, host = self._queue.pop(0)
+        ev.synchronize()
+        return tuple(host)
+
+    def __len__(self):
+        return len(self._queue)

@@ -164,13 +164,15 @@ def context(sd, image):
 # ---------------------------------------------------------------------------
 
 def corr_volume(fmap1, fmap2):
-    """V[i,j] = sum_c f1[c,i] f2[c,j] / sqrt(C) -> [N,1,h,w] (core/corr.py:53-69)."""
+    """V[i,j] = sum_c f1[c,i] f2[c,j] / sqrt(C) -> [N,1,h2,w2] (core/corr.py:53-69); fmap2 may be a pooled
+    (smaller) map, as in the on-demand variant."""
     B, C, h, w = fmap1.shape
     assert B == 1
+    h2, w2 = fmap2.shape[-2:]
     a = fmap1.reshape(C, h * w)
-    b = fmap2.reshape(C, h * w)
+    b = fmap2.reshape(C, h2 * w2)
     v = torch.matmul(a.t(), b) / torch.sqrt(torch.tensor(float(C)))
-    return v.reshape(h * w, 1, h, w)
+    return v.reshape(h * w, 1, h2, w2)
 
 
 def corr_pyramid(vol, levels=4):
@@ -220,6 +222,22 @@ def corr_lookup(pyr, coords, r=4):
         outs.append(acc.reshape(N, -1))
     out = torch.cat(outs, dim=1)                       # [N, 324]
     return out.t().reshape(1, -1, h, w).contiguous()
+
+
+def corr_lookup_ondemand(fmap1, fmap2, coords, r=4, levels=4):
+    """AlternateCorrBlock (core/corr.py:72-100) + alt_cuda_corr's forward kernel
+    (alt_cuda_corr/correlation_kernel.cu:18-119): the pyramid is built on the SECOND feature map
+    (F.avg_pool2d, corr.py:80-82; fmap1 stays at level 0, corr.py:91), every level's window is
+    <f1[cell], f2_l[tap]> / sqrt(C) sampled bilinearly at coords / 2^l with zeros outside; channel
+    l*81 + ix*9 + iy like CorrBlock (kernel lines 99-102: index iy + rd*ix, ix offsets x).
+    "Parity unpinned" against the CUDA op itself (it cannot be built here: no nvcc); pinned through the
+    equivalence with CorrBlock the reference relies on (tests: vs the golden lookup)."""
+    pyr = []
+    f2 = fmap2
+    for l in range(levels):
+        pyr.append(corr_volume(fmap1, f2))           # [N, 1, h_l, w_l] = <f1, f2_l> / sqrt(C)
+        f2 = F.avg_pool2d(f2, 2, stride=2)
+    return corr_lookup(pyr, coords, r)
 
 
 # ---------------------------------------------------------------------------

@@ -242,6 +242,31 @@ def test_c2_full_track_step_vs_oracle(flower, weights_cpu):
     assert ((got.sigma - rs).abs() / rs.clamp_min(1e-6))[0][same].max() < 2e-3
 
 
+def test_alternate_corr_engine_matches_default(weights_np, flower):
+    """raft_params.alternate_corr (core/raft.py:137-138): the engine with on-demand correlation -- no stored
+    volume in the workspace -- gives the default engine's flow (fp32 rounding of the correlation apart)."""
+    from mft_amd.config import AttrDict, Config
+    from mft_amd.raft import RAFTWrapper
+    c = Config()
+    c.flow_iters = 6
+    c.raft_params = AttrDict(alternate_corr=True)
+    alt = RAFTWrapper(c, state_dict=weights_np)
+    assert alt.engine.ondemand_corr
+    vid = SyntheticVideo(136, 200, n_frames=6, seed=23)
+    flower.C.flow_iters = 6
+    try:
+        f0, e0 = flower.compute_flow(vid[0], vid[3], mode="flow")
+    finally:
+        flower.C.flow_iters = 12
+    f1, e1 = alt.compute_flow(vid[0], vid[3], mode="flow")
+    e = epe(f1.cpu(), f0.cpu())
+    assert e.mean() < 1e-3 and e.max() < 1e-2, (float(e.mean()), float(e.max()))
+    assert (e1["occlusion"] - e0["occlusion"]).abs().max() < 2e-3
+    from mft_amd import _lib
+    lib = _lib.load()
+    assert lib.mftx_raft_workspace_bytes_for(alt.engine._h, 7, 135, 240) < lib.mftx_raft_workspace_bytes(7, 135, 240) / 2
+
+
 def test_result_api(flower):
     from mft_amd.results import FlowOUTrackingResult, FlowOUResult
     assert FlowOUResult is FlowOUTrackingResult

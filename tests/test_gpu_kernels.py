@@ -121,6 +121,31 @@ def test_corr_lookup_batched_and_odd_size(ops_mod):
         assert maxerr(from_pm(out[i], h, w), ref) < 1e-4
 
 
+@pytest.mark.parametrize("h,w,P,spread", [(16, 24, 1, 3.0), (17, 23, 3, 6.0), (64, 64, 2, 40.0)])
+def test_corr_lookup_ondemand_vs_materialised(ops_mod, h, w, P, spread):
+    """a17 (AlternateCorrBlock / alt_cuda_corr): the on-demand lookup must give the materialised lookup's output --
+    same layout, fp32-rounding apart -- and the pooled feature pyramid is avg_pool2d bit for bit."""
+    g = torch.Generator().manual_seed(h + w)
+    f1 = torch.randn(P, 256, h, w, generator=g)
+    f2 = torch.randn(P, 256, h, w, generator=g)
+    coords = O.pixel_grid(h, w)[None] + spread * torch.randn(P, 2, h, w, generator=g)
+    coords[0, :, 0, 0] = torch.tensor([5.0, 3.0])                     # exactly integral
+    a = torch.stack([pm(f1[i:i + 1]) for i in range(P)])
+    b = torch.stack([pm(f2[i:i + 1]) for i in range(P)])
+    cpm = torch.stack([pm(coords[i:i + 1]) for i in range(P)])
+    f2lv = ops_mod.fmap_pyramid(b, h, w)
+    ref = f2
+    for l in range(1, 4):
+        ref = F.avg_pool2d(ref, 2, stride=2)
+        assert torch.equal(f2lv[l].cpu(), ref.permute(0, 2, 3, 1).reshape(P, -1, 256)), l
+    od = ops_mod.corr_lookup_ondemand(a, f2lv, cpm, h, w)
+    mat = ops_mod.corr_lookup(ops_mod.corr_pyramid(a, b, h, w), cpm, h, w)
+    assert maxerr(od, mat) < 2e-4
+    for i in range(min(P, 2)):
+        want = O.corr_lookup_ondemand(f1[i:i + 1], f2[i:i + 1], coords[i:i + 1])
+        assert maxerr(from_pm(od[i], h, w), want) < 2e-4
+
+
 # ---------------------------------------------------------------------------
 # a7-a9/a11: conv kernel
 # ---------------------------------------------------------------------------
