@@ -59,7 +59,8 @@ def run(args):
         frames = list(vio.get_video_frames(args.video))
         name = args.video.stem
     logger.info("tracking %d frames", len(frames))
-    results, queries = [], None
+    from mft_amd.results import FlowOUTrackingResult
+    results, host_results, queries = [], [], None
     drain = vio.ResultDrain()
     for i, dev_frame in enumerate(vio.FrameRing(frames, depth=4)):
         if i == 0:
@@ -70,12 +71,12 @@ def run(args):
             meta = tracker.track(dev_frame)
         coords, occlusions = convert_to_point_tracking(meta.result, queries)
         drain.submit(meta.result)
+        host_results.append(FlowOUTrackingResult(*drain.collect(copy=True), validate=False))
         results.append((coords, occlusions))
     edit = vio.imread_unchanged(args.edit) if args.edit.exists() else None
-    from mft_amd.results import FlowOUTrackingResult
     for i, frame in enumerate(frames):
         coords, occlusions = results[i]
-        result = FlowOUTrackingResult(*drain.collect(), validate=False)
+        result = host_results[i]
         vio.imwrite_bgr(args.out / f"{name}_points" / f"{i:05d}.png", vis.draw_dots(frame, coords, occlusions))
         if edit is not None:
             vio.imwrite_bgr(args.out / f"{name}_edit" / f"{i:05d}.png", vis.draw_edit(frame, result, edit))

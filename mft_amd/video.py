@@ -173,31 +173,38 @@ class FrameRing:
 class ResultDrain:
     """Device results -> pinned host memory on a copy stream (the D2H mirror of ``FrameRing``): ``submit`` enqueues
     the copies of a result's three planes behind the kernels that produce them and returns immediately;
-    ``collect`` waits for one and hands back CPU tensors."""
+    ``collect`` waits for the oldest one and hands back its CPU tensors.  The pinned buffers form a ring of
+    ``depth`` sets (pinning memory is slow, it happens once): a collected result stays valid until ``depth`` more
+    results have been submitted (``copy=True`` returns private copies instead)."""
 
-    def __init__(self, device="cuda"):
+    def __init__(self, device="cuda", depth=4):
         self.device = torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device)
-        self._queue = []
+        self.depth = depth
+        self._sets, self._queue, self._n = [], [], 0
 
     def submit(self, result):
         planes = result.planes() if hasattr(result, "planes") else tuple(result)
+        if len(self._queue) >= self.depth:
+            raise RuntimeError("ResultDrain: collect() before submitting more than `depth` results")
+        slot = self._n % self.depth
+        if len(self._sets) <= slot:
+            self._sets.append([torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in planes])
+        host = self._sets[slot]
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
-        host = []
         with torch.cuda.stream(self.stream):
-            for t in planes:
-                h = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+            for h, t in zip(host, planes):
                 h.copy_(t, non_blocking=True)
                 t.record_stream(self.stream)
-                host.append(h)
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self._queue.append((ev, host))
+        self._n += 1
 
-    def collect(self):
+    def collect(self, copy=False):
         ev, host = self._queue.pop(0)
         ev.synchronize()
-        return tuple(host)
+        return tuple(h.clone() for h in host) if copy else tuple(host)
 
     def __len__(self):
         return len(self._queue)

@@ -184,8 +184,9 @@ def test_result_write_read_flowouX16(tmp_path):
     back = FlowOUTrackingResult.read(p)
     assert not back.flow.is_cuda and float((back.flow - r.flow).abs().max()) < 1e-3
     assert float((back.occlusion - r.occlusion).abs().max()) < 2e-5 and float((back.sigma - r.sigma).abs().max()) < 2e-5
-    with pytest.raises(NotImplementedError):
-        r.write(tmp_path / "x.flowou.png")
+    r.write(tmp_path / "x.flowou.png")                       # the fixed-point variant: 1/32 px flow steps
+    back = FlowOUTrackingResult.read(tmp_path / "x.flowou.png")
+    assert float((back.flow - r.flow).abs().max()) <= 1 / 32 and float((back.occlusion - r.occlusion).abs().max()) <= 2 ** -15
 
 
 def test_flowou_png_and_X32_vs_reference_golden(golden_dir, tmp_path):

@@ -96,6 +96,10 @@ def test_frame_ring_and_result_drain():
         f, o, s = drain.collect()
         assert not f.is_cuda and float(f.mean()) == i and float(s.mean()) == 2.0 * i
     assert len(drain) == 0
+    for i in range(6):                               # the pinned ring is reused; copy=True detaches a result from it
+        drain.submit(rs[i % 4])
+        f, _, _ = drain.collect(copy=True)
+        assert float(f.mean()) == i % 4
 
 
 @pytest.mark.gpu
@@ -106,10 +110,10 @@ def test_demo_on_png_directory(tmp_path):
     from pathlib import Path
     from mft_amd.synth import SyntheticVideo
     repo = Path(__file__).resolve().parents[1]
-    vid = SyntheticVideo(96, 128, n_frames=4, seed=1)
+    vid = SyntheticVideo(128, 160, n_frames=4, seed=1)
     for i in range(4):
         vio.imwrite_bgr(tmp_path / "in" / f"{i:03d}.png", vid[i])
-    edit = np.zeros((96, 128, 4), np.uint8)
+    edit = np.zeros((128, 160, 4), np.uint8)
     edit[30:50, 40:70] = (0, 255, 255, 200)
     vio.imwrite_bgr(tmp_path / "edit.png", edit)
     res = subprocess.run([sys.executable, str(repo / "demo.py"), "--video", str(tmp_path / "in"), "--edit", str(tmp_path / "edit.png"),
@@ -120,4 +124,4 @@ def test_demo_on_png_directory(tmp_path):
     eds = sorted((tmp_path / "out" / "in_edit").glob("*.png"))
     assert len(pts) == 4 and len(eds) == 4
     first = vio.imread_bgr(pts[0])
-    assert first.shape == (96, 128, 3) and (first == np.array(vis.RED, np.uint8)).all(-1).sum() > 100
+    assert first.shape == (128, 160, 3) and (first == np.array(vis.RED, np.uint8)).all(-1).sum() > 100
