@@ -124,8 +124,9 @@ class FrameRing:
         for dev_frame in FrameRing(get_video_frames(path)):
             meta = tracker.track(dev_frame)          # uint8 (H, W, 3) device tensor
 
-    A yielded tensor stays valid until ``depth`` more frames have been taken from the ring (the tracker keeps
-    frames in ``memory`` for up to 32 steps: pass ``keep=True`` to get private device copies instead of ring slots).
+    ``keep=True`` (default): every frame is a private device tensor (the tracker keeps frames in ``memory`` for up
+    to 32 steps); ``keep=False``: frames are the ring's own slots, valid until ``depth`` more have been taken.
+    A yielded tensor carries ``ready_event`` (fired once the upload is complete) for consumers on other streams.
     """
 
     def __init__(self, frames, depth=4, device="cuda", keep=True):
@@ -134,7 +135,8 @@ class FrameRing:
         self.device = torch.device(device)
         self.keep = keep
         self.stream = torch.cuda.Stream(device=self.device)
-        self._pinned, self._dev, self._events = [], [], []
+        self._consumer = torch.cuda.current_stream(self.device)
+        self._pinned, self._dev, self._events, self._out = [], [], [], {}
 
     def _alloc(self, shape):
         for _ in range(self.depth):
@@ -147,11 +149,16 @@ class FrameRing:
             self._alloc(frame.shape)
         self._events[slot].synchronize()              # the slot's previous upload has finished: host buffer is free
         self._pinned[slot].copy_(torch.from_numpy(np.ascontiguousarray(frame)))
-        # consumers of the slot's previous contents were enqueued on the caller's stream before this point
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.stream):
-            self._dev[slot].copy_(self._pinned[slot], non_blocking=True)
+            if self.keep:                             # private device copy made by the copy stream itself: nothing
+                dst = torch.empty_like(self._dev[slot])   # on the caller's stream is ever waited for
+            else:
+                # consumers of the slot's previous contents were enqueued on the caller's stream before this point
+                self.stream.wait_stream(self._consumer)
+                dst = self._dev[slot]
+            dst.copy_(self._pinned[slot], non_blocking=True)
             self._events[slot].record(self.stream)
+        self._out[slot] = dst
 
     def __iter__(self):
         pending = []                                  # slots in flight, oldest first
@@ -166,8 +173,14 @@ class FrameRing:
             yield self._take(pending.pop(0))
 
     def _take(self, slot):
-        torch.cuda.current_stream(self.device).wait_event(self._events[slot])
-        return self._dev[slot].clone() if self.keep else self._dev[slot]
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(self._events[slot])
+        out = self._out.pop(slot)
+        out.record_stream(cur)                        # allocated on the copy stream, used on the caller's
+        ev = torch.cuda.Event()
+        ev.record(self.stream)                        # (>= the upload's completion: for consumers on other streams)
+        out.ready_event = ev
+        return out
 
 
 class ResultDrain:
