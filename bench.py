@@ -34,13 +34,15 @@ import sys
 import time
 from pathlib import Path
 
-import numpy as np
-import torch
-import torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # see mft_amd/__init__.py (set before the HIP runtime starts)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak

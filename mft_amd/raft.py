@@ -65,7 +65,7 @@ class RAFTWrapper:
         # separate HIP streams (see _refine_split); 1 = one stream.  Measured at 7 pairs, 512 x 512
         # (profiles/r2_split_streams.txt): 1 / 2 / 3 / 4 / 7 parts = 63.0 / 64.9 / 59.4 / 60.6 / 49.8 frames/s.
         self._split_streams = int(os.environ.get("MFTX_SPLIT_STREAMS", "") or getattr(config, "split_streams", 0) or 2)
-        self._engines, self._side = [], []
+        self._engines, self._side = [], []            # part k: engine (own workspace) and stream (None = caller's)
         self._frames = {}
         # Optional (C.async_encode): encode new frames on a side stream.  The encoders of frame t
         # only need the image, so with results kept on the device (no per-frame host sync) their
@@ -223,7 +223,9 @@ class RAFTWrapper:
         while len(self._engines) < S:
             self._engines.append(ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand)
                                  if self._engines else self.engine)
-            self._side.append(torch.cuda.Stream(device=self.device))
+            # part 0 runs on the calling stream, the others on side streams (HIP multiplexes streams onto a handful
+            # of hardware queues: every stream saved keeps the copy / encoder streams on queues of their own)
+            self._side.append(torch.cuda.Stream(device=self.device) if self._side or len(self._engines) > 1 else None)
         dev = self.device
         flow = torch.empty(P, 2, H0, W0, dtype=torch.float32, device=dev) if planar else None
         occl = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev) if planar else None
@@ -233,14 +235,19 @@ class RAFTWrapper:
         for eng, _, sl in parts:                      # workspaces are allocated up front, on the calling stream
             eng.workspace(sl.stop - sl.start, geom.h, geom.w)
         main = torch.cuda.current_stream()
-        for eng, st, sl in parts:
+
+        def run(eng, sl):
+            f, o, s_ = eng.refine(fmap1[sl], fmap2[sl], net[sl], inp[sl], geom.h, geom.w, iters, pads=geom.pads,
+                                  packed=packed[sl] if packed is not None else None, planar=planar)
+            if planar:
+                flow[sl].copy_(f); occl[sl].copy_(o); sigma[sl].copy_(s_)
+
+        for eng, st, sl in parts[1:]:                 # side streams first: they start as soon as the inputs exist
             st.wait_stream(main)
             with torch.cuda.stream(st):
-                f, o, s_ = eng.refine(fmap1[sl], fmap2[sl], net[sl], inp[sl], geom.h, geom.w, iters, pads=geom.pads,
-                                      packed=packed[sl] if packed is not None else None, planar=planar)
-                if planar:
-                    flow[sl].copy_(f); occl[sl].copy_(o); sigma[sl].copy_(s_)
-        for _, st, _ in parts:
+                run(eng, sl)
+        run(parts[0][0], parts[0][2])
+        for _, st, _ in parts[1:]:
             main.wait_stream(st)
         return flow, occl, sigma
 

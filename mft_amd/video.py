@@ -16,6 +16,17 @@ import numpy as np
 import torch
 
 IMAGE_SUFFIXES = ('.jpg', '.png', '.jpeg')
+_copy_streams = {}
+
+
+def copy_stream(device):
+    """The one stream uploads and downloads share (HIP multiplexes streams onto a handful of hardware queues;
+    a copy stream that lands on the queue of a stream full of GEMM launches waits behind all of them)."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _copy_streams:
+        _copy_streams[key] = torch.cuda.Stream(device=device)
+    return _copy_streams[key]
 
 
 def _cv2():
@@ -134,7 +145,7 @@ class FrameRing:
         self.depth = max(2, int(depth))
         self.device = torch.device(device)
         self.keep = keep
-        self.stream = torch.cuda.Stream(device=self.device)
+        self.stream = copy_stream(self.device)
         self._consumer = torch.cuda.current_stream(self.device)
         self._pinned, self._dev, self._events, self._out = [], [], [], {}
 
@@ -192,7 +203,7 @@ class ResultDrain:
 
     def __init__(self, device="cuda", depth=4):
         self.device = torch.device(device)
-        self.stream = torch.cuda.Stream(device=self.device)
+        self.stream = copy_stream(self.device)
         self.depth = depth
         self._sets, self._queue, self._n = [], [], 0
 
