@@ -35,7 +35,6 @@ import time
 from pathlib import Path
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # see mft_amd/__init__.py (set before the HIP runtime starts)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -371,10 +370,11 @@ def main():
             # pinned host memory on a copy stream (mft_amd/video.py) -- every frame crosses PCIe in, every result out
             from mft_amd.video import FrameRing, ResultDrain
             base = first + args.steps + n_prof
-            lead = 4                                     # untimed: the ring / drain pin their host buffers on first use
+            lead = 4                                     # untimed: the drain pins its host buffers on first use
+            ring = FrameRing(host_frames[base: base + lead + n_io]).prepare(host_frames[base].shape)
             drain = ResultDrain()
             got = 0
-            for k, dev_frame in enumerate(FrameRing(host_frames[base: base + lead + n_io], depth=4)):
+            for k, dev_frame in enumerate(ring):
                 if k == lead:
                     while len(drain):
                         drain.collect()

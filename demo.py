@@ -62,7 +62,7 @@ def run(args):
     from mft_amd.results import FlowOUTrackingResult
     results, host_results, queries = [], [], None
     drain = vio.ResultDrain()
-    for i, dev_frame in enumerate(vio.FrameRing(frames, depth=4)):
+    for i, dev_frame in enumerate(vio.FrameRing(frames)):
         if i == 0:
             meta = tracker.init(dev_frame)
             meta.result = meta.result.cuda()

@@ -5,13 +5,6 @@ Drop-in names: ``MFT`` (tracker), ``FlowOUTrackingResult`` / ``FlowOUResult``,
 Compute runs in ``libmftx.so`` (hand-written gfx950 HIP kernels, C ABI in
 ``include/mftx.h``); there is no CPU fallback.
 """
-import os as _os
-
-# HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The tracker uses the caller's stream,
-# one for the second half-batch, one for the encoders and one for PCIe copies; a little headroom keeps a copy from
-# queueing behind a stream full of GEMM launches.  Read by the HIP runtime at its initialisation.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 from .config import Config, load_config  # noqa: F401
 from .results import FlowOUTrackingResult, FlowOUResult  # noqa: F401
 

@@ -151,9 +151,6 @@ class RAFTWrapper:
         if self._enc_stream is None:
             return self.encode(img)
         main = torch.cuda.current_stream()
-        ready = getattr(img, "ready_event", None)      # a frame handed over by mft_amd.video.FrameRing: uploaded on
-        if ready is not None:                           # another stream, complete once this event has fired
-            self._enc_stream.wait_event(ready)
         with torch.cuda.stream(self._enc_stream):
             f = self.encode(img)
         main.wait_stream(self._enc_stream)

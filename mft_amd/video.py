@@ -1,6 +1,6 @@
 """Video ingest -- drop-in for ``GeneralVideoCapture`` / ``get_video_frames`` / ``get_video_length``
-(``MFT/utils/io.py:566-615``) plus what the MI355X path adds: a pinned-host -> HBM frame ring that uploads
-frame t+1.. while frame t is being tracked, and its mirror for results coming back.
+(``MFT/utils/io.py:566-615``) plus what the MI355X path adds: frames staged in pinned host memory so that their upload is asynchronous and
+overlaps the previous frame's refinement, and the mirror for results coming back.
 
 Sources: a directory of images (``.png`` decoded by this package's own PNG coder; ``.jpg`` / ``.jpeg`` and
 container formats need OpenCV, which is used when it is importable and reported clearly when it is not), or
@@ -20,8 +20,8 @@ _copy_streams = {}
 
 
 def copy_stream(device):
-    """The one stream uploads and downloads share (HIP multiplexes streams onto a handful of hardware queues;
-    a copy stream that lands on the queue of a stream full of GEMM launches waits behind all of them)."""
+    """The download stream, one per device (HIP multiplexes streams onto a handful of hardware queues: the tracker
+    already uses the caller's stream, one for the second half-batch and one for the encoders)."""
     device = torch.device(device)
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     if key not in _copy_streams:
@@ -129,69 +129,42 @@ def get_video_length(path):
 
 
 class FrameRing:
-    """Host frames -> HBM through ``depth`` pinned staging buffers and a copy stream: while the tracker works on
-    frame t the uploads of frames t+1 .. t+depth-1 are already in flight, so ``MFT.track`` never waits for PCIe.
+    """Host frames -> a rotation of PINNED host buffers, handed to the tracker as uint8 (H, W, 3) CPU tensors:
 
-        for dev_frame in FrameRing(get_video_frames(path)):
-            meta = tracker.track(dev_frame)          # uint8 (H, W, 3) device tensor
+        for frame in FrameRing(get_video_frames(path)):
+            meta = tracker.track(frame)
 
-    ``keep=True`` (default): every frame is a private device tensor (the tracker keeps frames in ``memory`` for up
-    to 32 steps); ``keep=False``: frames are the ring's own slots, valid until ``depth`` more have been taken.
-    A yielded tensor carries ``ready_event`` (fired once the upload is complete) for consumers on other streams.
+    The tracker's flow plugin uploads a frame with a non-blocking copy on the stream that encodes it (the encoder
+    side stream when ``C.async_encode`` is set): from pinned memory that copy is truly asynchronous -- the host
+    moves on to the next frame and the upload overlaps the previous frame's refinement -- and it needs no stream of
+    its own (HIP multiplexes streams onto a few hardware queues; a dedicated copy stream ended up behind queues
+    full of GEMM launches and stalled the loop for a frame time, ``tools/io_paths.py``).
+
+    ``keep``: how many later frames a yielded frame stays valid for (its buffer is recycled after that); the default
+    covers the tracker's memory ring (32 frames + the frames in flight).
     """
 
-    def __init__(self, frames, depth=4, device="cuda", keep=True):
+    def __init__(self, frames, keep=40):
         self.frames = iter(frames)
-        self.depth = max(2, int(depth))
-        self.device = torch.device(device)
-        self.keep = keep
-        self.stream = copy_stream(self.device)
-        self._consumer = torch.cuda.current_stream(self.device)
-        self._pinned, self._dev, self._events, self._out = [], [], [], {}
+        self.slots = max(2, int(keep))
+        self._pinned = []
 
-    def _alloc(self, shape):
-        for _ in range(self.depth):
-            self._pinned.append(torch.empty(shape, dtype=torch.uint8).pin_memory())
-            self._dev.append(torch.empty(shape, dtype=torch.uint8, device=self.device))
-            self._events.append(torch.cuda.Event())
-
-    def _submit(self, slot, frame):
-        if not self._pinned:
-            self._alloc(frame.shape)
-        self._events[slot].synchronize()              # the slot's previous upload has finished: host buffer is free
-        self._pinned[slot].copy_(torch.from_numpy(np.ascontiguousarray(frame)))
-        with torch.cuda.stream(self.stream):
-            if self.keep:                             # private device copy made by the copy stream itself: nothing
-                dst = torch.empty_like(self._dev[slot])   # on the caller's stream is ever waited for
-            else:
-                # consumers of the slot's previous contents were enqueued on the caller's stream before this point
-                self.stream.wait_stream(self._consumer)
-                dst = self._dev[slot]
-            dst.copy_(self._pinned[slot], non_blocking=True)
-            self._events[slot].record(self.stream)
-        self._out[slot] = dst
+    def prepare(self, shape):
+        """Pin all the buffers now (pinning is slow -- milliseconds each -- and otherwise happens frame by frame)."""
+        while len(self._pinned) < self.slots:
+            self._pinned.append(torch.empty(tuple(shape), dtype=torch.uint8).pin_memory())
+        return self
 
     def __iter__(self):
-        pending = []                                  # slots in flight, oldest first
-        nxt = 0
-        for frame in self.frames:
-            self._submit(nxt % self.depth, frame)
-            pending.append(nxt % self.depth)
-            nxt += 1
-            if len(pending) == self.depth - 1:
-                yield self._take(pending.pop(0))
-        while pending:
-            yield self._take(pending.pop(0))
-
-    def _take(self, slot):
-        cur = torch.cuda.current_stream(self.device)
-        cur.wait_event(self._events[slot])
-        out = self._out.pop(slot)
-        out.record_stream(cur)                        # allocated on the copy stream, used on the caller's
-        ev = torch.cuda.Event()
-        ev.record(self.stream)                        # (>= the upload's completion: for consumers on other streams)
-        out.ready_event = ev
-        return out
+        for n, frame in enumerate(self.frames):
+            frame = np.ascontiguousarray(frame)
+            if len(self._pinned) < self.slots:
+                self._pinned.append(torch.empty(frame.shape, dtype=torch.uint8).pin_memory())
+            buf = self._pinned[n % self.slots]
+            if tuple(buf.shape) != frame.shape:
+                raise ValueError("all frames of a video must have the same size")
+            buf.copy_(torch.from_numpy(frame))
+            yield buf
 
 
 class ResultDrain:
@@ -203,7 +176,7 @@ class ResultDrain:
 
     def __init__(self, device="cuda", depth=4):
         self.device = torch.device(device)
-        self.stream = copy_stream(self.device)
+        self.stream = copy_stream(self.device)          # downloads only (uploads ride on the encoder's stream)
         self.depth = depth
         self._sets, self._queue, self._n = [], [], 0
 

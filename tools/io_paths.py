@@ -53,7 +53,7 @@ def dev_loop(p):
 
 
 def ring_loop(p):
-    it = iter(FrameRing(host[p: p + N], depth=4))
+    it = iter(FrameRing(host[p: p + N]))
     while True:
         with T("ring"):
             f = next(it, None)
@@ -74,7 +74,7 @@ def drain_loop(p):
 
 def both_loop(p):
     d = ResultDrain()
-    it = iter(FrameRing(host[p: p + N], depth=4))
+    it = iter(FrameRing(host[p: p + N]))
     while True:
         with T("ring"):
             f = next(it, None)
