@@ -16,18 +16,6 @@ import numpy as np
 import torch
 
 IMAGE_SUFFIXES = ('.jpg', '.png', '.jpeg')
-_copy_streams = {}
-
-
-def copy_stream(device):
-    """The download stream, one per device (HIP multiplexes streams onto a handful of hardware queues: the tracker
-    already uses the caller's stream, one for the second half-batch and one for the encoders)."""
-    device = torch.device(device)
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    if key not in _copy_streams:
-        _copy_streams[key] = torch.cuda.Stream(device=device)
-    return _copy_streams[key]
-
 
 def _cv2():
     try:
@@ -168,15 +156,17 @@ class FrameRing:
 
 
 class ResultDrain:
-    """Device results -> pinned host memory on a copy stream (the D2H mirror of ``FrameRing``): ``submit`` enqueues
-    the copies of a result's three planes behind the kernels that produce them and returns immediately;
-    ``collect`` waits for the oldest one and hands back its CPU tensors.  The pinned buffers form a ring of
-    ``depth`` sets (pinning memory is slow, it happens once): a collected result stays valid until ``depth`` more
-    results have been submitted (``copy=True`` returns private copies instead)."""
+    """Device results -> pinned host memory without stalling the loop: ``submit`` enqueues non-blocking copies of a
+    result's three planes on the CALLER's stream -- right behind the kernels that produce them, 4 MB = ~0.1 ms at
+    512 x 512 -- and returns immediately; ``collect`` waits for the oldest one and hands back its CPU tensors, so a
+    loop that collects a couple of frames late never waits for the GPU.  (A separate download stream was measured
+    and dropped: next to the pinned uploads it serialised the whole loop, 36 instead of 62 frames/s,
+    ``tools/io_paths.py``.)  The pinned buffers form a ring of ``depth`` sets (pinning memory is slow, it happens
+    once): a collected result stays valid until ``depth`` more results have been submitted (``copy=True`` returns
+    private copies instead)."""
 
     def __init__(self, device="cuda", depth=4):
         self.device = torch.device(device)
-        self.stream = copy_stream(self.device)          # downloads only (uploads ride on the encoder's stream)
         self.depth = depth
         self._sets, self._queue, self._n = [], [], 0
 
@@ -188,13 +178,10 @@ class ResultDrain:
         if len(self._sets) <= slot:
             self._sets.append([torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in planes])
         host = self._sets[slot]
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self.stream):
-            for h, t in zip(host, planes):
-                h.copy_(t, non_blocking=True)
-                t.record_stream(self.stream)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
+        for h, t in zip(host, planes):
+            h.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
         self._queue.append((ev, host))
         self._n += 1
 
