@@ -289,7 +289,7 @@ def main():
     preroll = FIRST_FULL_FRAME - 1                                # untimed: frames 1 .. 32; warm-up starts at frame 33
     n_io = 0 if (args.no_host_io or world > 1 or args.force_sharded) else max(8, args.steps)
     n_prof = 0 if args.no_profile else args.steps
-    n_frames = 1 + preroll + args.warmup + args.steps + n_prof + (n_io + 4 if n_io else 0)
+    n_frames = 1 + preroll + args.warmup + args.steps + n_prof + n_io
     vid = SyntheticVideo(args.height, args.width, n_frames=max(n_frames, 48), seed=0)
     host_frames = [vid[i] for i in range(n_frames)]
     frames = [torch.from_numpy(f).cuda() for f in host_frames]      # resident in HBM
@@ -366,28 +366,19 @@ def main():
             result["kernels"] = kernels
     if not sharded and rank == 0:
         if n_io:
-            # PCIe-inclusive variant of the same loop: numpy frames in through the pinned upload ring, results out to
-            # pinned host memory on a copy stream (mft_amd/video.py) -- every frame crosses PCIe in, every result out
-            from mft_amd.video import FrameRing, ResultDrain
+            # PCIe-inclusive variant of the same loop: numpy frames in, CPU results out -- every frame crosses PCIe in,
+            # every result out.  (Pageable frames + synchronous .cpu(): of the paths measured in
+            # profiles/r2_io_paths.txt the fastest that moves data in BOTH directions; pinned-ring uploads and pinned
+            # downloads are each faster alone but serialise when combined on this software stack.)
+            conf.keep_result_on_device = False
             base = first + args.steps + n_prof
-            lead = 4                                     # untimed: the drain pins its host buffers on first use
-            ring = FrameRing(host_frames[base: base + lead + n_io]).prepare(host_frames[base].shape)
-            drain = ResultDrain()
-            got = 0
-            for k, dev_frame in enumerate(ring):
-                if k == lead:
-                    while len(drain):
-                        drain.collect()
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    got = 0
-                drain.submit(tracker.track(dev_frame).result)
-                while len(drain) > 2:
-                    drain.collect(); got += 1
-            while len(drain):
-                drain.collect(); got += 1
             torch.cuda.synchronize()
-            assert got == n_io, got
+            t0 = time.perf_counter()
+            for i in range(base, base + n_io):
+                out = tracker.track(host_frames[i]).result
+                assert not out.flow.is_cuda
+            torch.cuda.synchronize()
+            conf.keep_result_on_device = True
             result["host_io_fps"] = n_io / (time.perf_counter() - t0)
             log("host-io pass done")
         torch.set_num_threads(oracle_threads())

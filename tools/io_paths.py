@@ -94,7 +94,31 @@ def simple_loop(p):
     conf.keep_result_on_device = True
 
 
+def ring_sync_loop(p):
+    conf.keep_result_on_device = False
+    for f in FrameRing(host[p: p + N]):
+        with T("track"): tr.track(f)
+    conf.keep_result_on_device = True
+
+
+def ring_drain1_loop(p):
+    """one packed D2H per frame instead of three"""
+    pinned = [torch.empty(4, 512, 512).pin_memory() for _ in range(4)]
+    evs = []
+    for k, f in enumerate(FrameRing(host[p: p + N])):
+        with T("track"): m = tr.track(f)
+        with T("submit"):
+            r = m.result
+            pinned[k % 4].copy_(torch.cat([r.flow, r.occlusion, r.sigma], 0), non_blocking=True)
+            ev = torch.cuda.Event(); ev.record(); evs.append(ev)
+        with T("collect"):
+            if len(evs) > 2: evs.pop(0).synchronize()
+    for e in evs: e.synchronize()
+
+
 run("device frames, device results", dev_loop)
+run("ring in, .cpu() out", ring_sync_loop)
+run("ring in, one packed pinned copy out", ring_drain1_loop)
 run("ring in, device results", ring_loop)
 run("device frames, drain out", drain_loop)
 run("ring in, drain out", both_loop)
