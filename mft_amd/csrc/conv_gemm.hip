@@ -63,7 +63,6 @@ struct ConvArgs {
     long long a_bstride, w_bstride, o_bstride;  // per batch element
     unsigned a0_bytes, a1_bytes, w_bytes;       // buffer extents (per batch element)
     float *hx; int ld_hx; float *z; float *rh;  // GRU epilogues
-    int n_big;                                  // balanced launches: virtual tiles done as whole tiles (the rest as quarter tiles)
     // EPI_VOLUME only: feature grid and the pooled levels (pyramid layout of common.h; out = level 0)
     int vh, vw, sbw, wb0;
     float *lvl1, *lvl2, *lvl3;
@@ -222,10 +221,8 @@ __device__ __forceinline__ void volume_epilogue(const ConvArgs &p, const f32x16 
 // form consumes -- (k, k+4, k+1, k+5), (k+2, k+6, k+3, k+7) across its four lane groups -- the 16x16x4
 // form rounds bit-identically (both are sequential fmaf chains; tools/micro/mfma_order.hip), so the
 // tile choice still does not show in the results.
-// QUARTER: this instantiation (BM x BN = half the main tile in each direction) works through QUARTER TILES of the
-// virtual tiles [n_big, n_virtual) of the main (2 BM x 2 BN) tiling -- see conv_gemm_balanced_kernel.
-template <int BM, int BN, int WM, int WN, int EPI, int MT = 32, bool QUARTER = false>
-__device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0, int vt_end = 0x7fffffff) {
+template <int BM, int BN, int WM, int WN, int EPI, int MT = 32>
+__device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
     constexpr int NS = 2;                       // LDS ring of two K chunks (deeper rings were measured: no gain)
     constexpr int TM = BM / WM / MT, TN = BN / WN / MT;
     constexpr int NR = MT == 32 ? 16 : 4;       // accumulator registers per MFMA tile
@@ -255,9 +252,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0, int v
     // own contiguous band of M tiles with the N tiles innermost: the column tiles
     // of one A tile and the 3x3 halo rows of neighbouring A tiles then meet in
     // the same 4 MiB L2 instead of being fetched once per XCD.
-    constexpr int GM = QUARTER ? 2 * BM : BM, GN = QUARTER ? 2 * BN : BN;   // tile grid the virtual tiles are counted in
-    const int tiles_n = (p.N + GN - 1) / GN;
-    const int tiles_m = (p.M + GM - 1) / GM;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
     const int band = (tiles_m + 7) / 8;               // M tiles per XCD
     const int per_batch = band * tiles_n;              // virtual tiles per XCD per batch element
     const int n_virtual = 8 * per_batch * p.batch;
@@ -292,9 +288,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0, int v
     float *const a_dst = As + wid * 8 * LDK;
     float *const b_dst = Bs + wid * 8 * LDK;
 
-    const int it_end = QUARTER ? 4 * (n_virtual - p.n_big) : (vt_end < n_virtual ? vt_end : n_virtual);
-    for (int wi = vt0; wi < it_end; wi += gridDim.x) {
-    const int vt = QUARTER ? p.n_big + (wi >> 2) : wi;
+    for (int vt = vt0; vt < n_virtual; vt += gridDim.x) {
     const int xcd = vt & 7;
     const int q = vt >> 3;
     const int bz = q / per_batch;
@@ -304,9 +298,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0, int v
     // cycles through its L2, instead of every XCD re-reading all of f2 once per M tile (fabric reads 879 -> ~270 MB)
     const int tm = EPI == EPI_VOLUME ? xcd * band + r % band : xcd * band + r / tiles_n;
     if (tm >= tiles_m) continue;                       // ragged band (uniform per workgroup)
-    const int m0 = tm * GM + (QUARTER ? ((wi >> 1) & 1) * BM : 0);
-    const int n0 = (EPI == EPI_VOLUME ? r / band : r % tiles_n) * GN + (QUARTER ? (wi & 1) * BN : 0);
-    if (QUARTER && (m0 >= p.M || n0 >= p.N)) continue; // quarter of a partial edge tile that holds nothing
+    const int m0 = tm * BM;
+    const int n0 = (EPI == EPI_VOLUME ? r / band : r % tiles_n) * BN;
     float *out = p.out + bz * p.o_bstride;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     block_barrier();                      // previous tile's last LDS reads are done
@@ -579,22 +572,6 @@ void conv_gemm_kernel(ConvArgs p) {
     conv_gemm_body<BM, BN, WM, WN, EPI, MT>(p, blockIdx.x);
 }
 
-// Balanced launch.  With n virtual 64 x 64 tiles on 256 CUs, n mod 256 CUs get one tile more than the others and
-// the launch lasts ceil(n / 256) tile times where n / 256 would do: 12.5 % at 3.5 tiles per CU (the N = 128
-// layers at 7 pairs: 896 tiles).  Here the first n_big = 256 floor(n / 256) tiles run as whole tiles and the
-// remaining ones as QUARTER tiles of 32 x 32 (four waves of v_mfma_f32_16x16x4_f32, bit-identical results, see
-// conv_gemm_body), dealt round-robin over the workgroups right behind the whole tiles: every CU ends up with the
-// same amount of work.  The quarter tiles need 4 x the LDS fragment traffic per MFMA cycle, which is why they are
-// only used for that last partial round.
-template <int EPI>
-__global__ __launch_bounds__(256, MFTX_MINW1)
-void conv_gemm_balanced_kernel(ConvArgs p) {
-    conv_gemm_body<64, 64, 2, 2, EPI, 32, false>(p, blockIdx.x, p.n_big);
-    int u0 = (int)blockIdx.x - p.n_big % (int)gridDim.x;
-    if (u0 < 0) u0 += gridDim.x;
-    conv_gemm_body<32, 32, 2, 2, EPI, 16, true>(p, u0);
-}
-
 // Two independent convolutions in one launch (the two branches of the motion encoder, convc2 and convf2):
 // the virtual tiles of b follow those of a in the same round-robin, so the pair fills the chip as one
 // problem -- at one flow pair per GPU 192 + 64 tiles for 256 CUs instead of two half-empty launches, at
@@ -653,36 +630,7 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat, 
 // vmcnt) were measured twice and do not pay at either M = 28672 or M = 4096 (tools/bench_conv.py):
 // the ring is fixed at two chunks, which lets the K loop be unrolled over the slots.
 template <int EPI>
-static int launch_balanced(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat, int n_big) {
-    constexpr size_t lds = (size_t)2 * (64 + 64) * LDK * sizeof(float);
-    static bool attr_set = false;
-    auto kern = conv_gemm_balanced_kernel<EPI>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
-    ConvArgs args = a;
-    args.batch = batch;
-    args.n_big = n_big;
-    dim3 grid((unsigned)(num_cus() * 4));
-    ProfScope prof(cat, s, 2.0 * a.M * a.N * (double)(a.kh * a.kw) * (a.c0 + a.c1) * batch);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, args);
-    return check_launch("conv_gemm (balanced)");
-}
-
-template <int EPI>
 static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) {
-    if (tile == 2 && batch == 1) {
-        // ragged last round?  (whole tiles per CU >= 1, and the remainder leaves at least a quarter of the CUs idle)
-        static const bool off = getenv("MFTX_CONV_NOBALANCE") != nullptr;
-        const long long n_virtual = 8ll * cdiv(cdiv(a.M, 64), 8) * cdiv(a.N, 64);
-        const int cus = num_cus();
-        const long long rem = n_virtual % cus;
-        if (!off && n_virtual > cus && rem != 0 && rem <= (3 * cus) / 4)
-            return launch_balanced<EPI>(a, batch, s, cat, (int)(n_virtual - rem));
-    }
     switch (tile) {
         case 0: return launch_cfg<128, 128, 2, 2, EPI>(a, batch, s, cat);
         case 1: return launch_cfg<128, 64, 2, 2, EPI>(a, batch, s, cat);
