@@ -82,6 +82,8 @@ def build_tracker(args, sharded):
     conf.flow_config.synthetic_weights_seed = 0     # seeded synthetic weights
     conf.flow_config.flow_iters = args.iters
     conf.flow_config.async_encode = not args.sync_encode
+    if getattr(args, "alternate_corr", False):
+        conf.flow_config.raft_params.alternate_corr = True
     conf.keep_result_on_device = True
     conf.delta_sharding = sharded
     return conf.tracker_class(conf), conf
@@ -266,12 +268,20 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size EPE check against the CPU oracle")
     ap.add_argument("--no-host-io", action="store_true")
     ap.add_argument("--sync-encode", action="store_true", help="encode frames on the main stream")
+    ap.add_argument("--alternate-corr", action="store_true",
+                    help="on-demand correlation (raft_params.alternate_corr): no stored volume, for memory-bound sizes")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (windows, RCCL all-gathers) even with one rank (testing)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(respawn_under_torchrun(args.gpus))
+    # stdout must carry ONE JSON line and nothing else: native libraries (the RCCL version banner, ...) print to fd 1
+    # from C, some of it only when the process exits -- so fd 1 is pointed at stderr for the whole run and the JSON
+    # line goes to the real stdout at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -392,7 +402,7 @@ def main():
                 result.setdefault("parity", {}).update(track_parity(args, vid, oracle_meta))
                 log(f"track() parity vs oracle: {result['parity']}")
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if sharded:
         dist.barrier()
         dist.destroy_process_group()

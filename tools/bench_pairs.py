@@ -36,6 +36,7 @@ def main():
     fc.synthetic_weights_seed = 0
     fc.flow_iters = a.iters
     fc.async_encode = False
+    fc.split_streams = 1          # one batch on one stream: per-kernel event times must not overlap
     flower = fc.of_class(fc)
     vid = SyntheticVideo(a.size, a.size, n_frames=8, seed=0)
     frames = [vid[i] for i in range(8)]

@@ -43,7 +43,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             data.setdefault(k, {})[c] = (len(d[c]), top_half_mean(d[c]) * 1024 / 1e6)
 with open(out / "pmc_hbm_traffic.csv", "w") as f:
     f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) on\n"
-            "#   python bench.py --steps 3 --warmup 34 --no-cpu-baseline --no-profile (512x512, 7 pairs/frame)\n"
+            "#   MFTX_SPLIT_STREAMS=1 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-parity --no-host-io --sync-encode\n"
+            "#   (512x512, 7 pairs/frame after the 32-frame pre-roll; one batch on one stream so that kernels do not overlap)\n"
             "# per launch, steady-state launches (upper half of each kernel's dispatches); counter x 1024 B.\n"
             "# gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reads 1/2 of the bytes of wide (16 B/lane)\n"
             "# coalesced streams -> column fetch_x2_MB for the kernels that read that way (conv_gemm LDS-DMA).\n"
