@@ -635,6 +635,7 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
         case 0: return launch_cfg<128, 128, 2, 2, EPI>(a, batch, s, cat);
         case 1: return launch_cfg<128, 64, 2, 2, EPI>(a, batch, s, cat);
         case 2: return launch_cfg<64, 64, 2, 2, EPI>(a, batch, s, cat);
+        case 4: return launch_cfg<64, 128, 2, 2, EPI>(a, batch, s, cat);       // a wave owns 32 x 64: the A tile is gathered once for N = 128
         case 5: return launch_cfg<32, 32, 2, 2, EPI, 16>(a, batch, s, cat);    // 4 waves of 16x16: four times the workgroups of 64x64
         default: return launch_cfg<128, 32, 4, 1, EPI>(a, batch, s, cat);
     }
@@ -643,7 +644,7 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
 static int pick_tile(const ConvArgs &a, int batch) {
     // debug/tuning override: MFTX_CONV_TILE=0..3
     static const int forced = [] { const char *e = getenv("MFTX_CONV_TILE"); return e ? atoi(e) : -1; }();
-    if ((forced >= 0 && forced <= 3) || forced == 5) return forced;
+    if (forced >= 0 && forced <= 5) return forced;
     // Measured on MI355X (tools/bench_conv.py, M = 7 x 4096 and 4096): the 64x64
     // tile (4 workgroups per CU) wins or ties on every layer -- 7 x 2^k rows tile
     // the 256 CUs more evenly in small tiles than bigger tiles save on operand
