@@ -216,10 +216,49 @@ __device__ __forceinline__ void write_selected4(const Best (&b)[4], int H, int W
     if (chosen) *reinterpret_cast<char4 *>(chosen + pix) = ck;
 }
 
-// One pixel per thread (16 waves per CU at 512 x 512: the chain is two dependent memory round trips per
-// candidate, hidden by other waves -- four pixels per thread left 4 waves per CU and ran 2x slower), right
-// operands PACKED: 4 coalesced 4-byte loads of the left planes + 4 sixteen-byte gathers per candidate
-// instead of 4 + 16 four-byte gathers; the kernel was bound by the texture-address rate of those gathers.
+// One pixel per thread, right operands PACKED: 4 coalesced 4-byte loads of the left planes + 4 sixteen-byte gathers
+// per candidate instead of 4 + 16 four-byte gathers (the planar kernel is bound by the texture-address rate of
+// its gathers).  The chain of a candidate is two dependent memory round trips (left planes -> tap addresses -> taps);
+// walked candidate by candidate that is 2 K round trips per thread and the kernel is latency-bound (24 us for 63 MB at
+// K = 7).  With K known at compile time (KT = 1..8) ALL left planes are loaded first, then the taps in batches of
+// four candidates: 1 + ceil(K / 4) round trips.  Taps outside the image are read at a clamped address and replaced by
+// zeros afterwards (no branches).  Same arithmetic, operation by operation, as chain_px: bitwise equal results.
+struct ChainPrep { float px, py, gx, gy, w00, w01, w10, w11; int x0, y0; };
+
+__device__ __forceinline__ ChainPrep chain_prep(float lfx, float lfy, int H, int W, int x, int y, float sx, float sy) {
+    ChainPrep c;
+    c.gx = (float)x; c.gy = (float)y;
+    c.px = c.gx + lfx;
+    c.py = c.gy + lfy;
+    const float ix = ((c.px * sx - 1.f) + 1.f) / 2.f * (float)(W - 1);
+    const float iy = ((c.py * sy - 1.f) + 1.f) / 2.f * (float)(H - 1);
+    const float flx = floorf(ix), fly = floorf(iy);
+    const float wx = ix - flx, wy = iy - fly;
+    c.x0 = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
+    c.y0 = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
+    c.w00 = (1.f - wx) * (1.f - wy); c.w01 = wx * (1.f - wy); c.w10 = (1.f - wx) * wy; c.w11 = wx * wy;
+    return c;
+}
+
+__device__ __forceinline__ float4 packed_tap(const float4 *R, int H, int W, int yy, int xx) {
+    const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+    const int cy = min(max(yy, 0), H - 1), cx = min(max(xx, 0), W - 1);
+    const float4 v = R[(long long)cy * W + cx];
+    return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__device__ __forceinline__ Chained chain_finish(const ChainPrep &c, float locc, float lsig, const float4 &a, const float4 &b,
+                                                const float4 &cc, const float4 &d) {
+    Chained o;
+    o.fx = (c.px + (a.x * c.w00 + b.x * c.w01 + cc.x * c.w10 + d.x * c.w11)) - c.gx;
+    o.fy = (c.py + (a.y * c.w00 + b.y * c.w01 + cc.y * c.w10 + d.y * c.w11)) - c.gy;
+    o.occ = max_nanprop(locc, a.z * c.w00 + b.z * c.w01 + cc.z * c.w10 + d.z * c.w11);
+    const float sr = a.w * c.w00 + b.w * c.w01 + cc.w * c.w10 + d.w * c.w11;
+    o.sig = sqrtf(lsig * lsig + sr * sr);
+    return o;
+}
+
+template <int KT>    // KT = number of candidates (1..8), or 0: any K, candidate by candidate
 __global__ __launch_bounds__(256) void chain_select_packed_kernel(PackedSet ps, float thr, int H, int W, float sx,
                                                                   float sy, float *flowO, float *occlO, float *sigmaO,
                                                                   int8_t *chosen) {
@@ -229,15 +268,42 @@ __global__ __launch_bounds__(256) void chain_select_packed_kernel(PackedSet ps, 
     const long long pix = (long long)y * W + x, plane = (long long)H * W;
     Best b;
     b.score = 0.f; b.k = 0; b.c = Chained{0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < ps.K; ++k) {
-        const Planes L = ps.L[k];
-        const float4 *R = ps.R[k];
-        const Chained c = chain_core(L.flow[pix], L.flow[plane + pix], L.occl[pix], L.sigma[pix], H, W, x, y, sx, sy,
-                                     [&](int yy, int xx) {
-                                         return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? R[(long long)yy * W + xx]
-                                                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
-                                     });
-        consider(b, c, k, thr);
+    if constexpr (KT == 0) {
+        for (int k = 0; k < ps.K; ++k) {
+            const Planes L = ps.L[k];
+            const ChainPrep c = chain_prep(L.flow[pix], L.flow[plane + pix], H, W, x, y, sx, sy);
+            const float4 *R = ps.R[k];
+            consider(b, chain_finish(c, L.occl[pix], L.sigma[pix], packed_tap(R, H, W, c.y0, c.x0), packed_tap(R, H, W, c.y0, c.x0 + 1),
+                                     packed_tap(R, H, W, c.y0 + 1, c.x0), packed_tap(R, H, W, c.y0 + 1, c.x0 + 1)), k, thr);
+        }
+    } else {
+        float lfx[KT], lfy[KT], loc[KT], lsg[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            lfx[k] = ps.L[k].flow[pix]; lfy[k] = ps.L[k].flow[plane + pix];
+            loc[k] = ps.L[k].occl[pix]; lsg[k] = ps.L[k].sigma[pix];
+        }
+#pragma unroll
+        for (int k0 = 0; k0 < KT; k0 += 4) {
+            constexpr int B = 4;
+            ChainPrep c[B];
+            float4 t[B][4];
+#pragma unroll
+            for (int j = 0; j < B; ++j) {
+                if (k0 + j < KT) {
+                    c[j] = chain_prep(lfx[k0 + j], lfy[k0 + j], H, W, x, y, sx, sy);
+                    const float4 *R = ps.R[k0 + j];
+                    t[j][0] = packed_tap(R, H, W, c[j].y0, c[j].x0);
+                    t[j][1] = packed_tap(R, H, W, c[j].y0, c[j].x0 + 1);
+                    t[j][2] = packed_tap(R, H, W, c[j].y0 + 1, c[j].x0);
+                    t[j][3] = packed_tap(R, H, W, c[j].y0 + 1, c[j].x0 + 1);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < B; ++j)
+                if (k0 + j < KT)
+                    consider(b, chain_finish(c[j], loc[k0 + j], lsg[k0 + j], t[j][0], t[j][1], t[j][2], t[j][3]), k0 + j, thr);
+        }
     }
     write_selected(b, H, W, x, y, flowO, occlO, sigmaO, chosen);
 }
@@ -376,7 +442,20 @@ extern "C" int mftx_chain_select_packed(int K, const float *const *flowL, const 
     float sx, sy;
     scales(H, W, sx, sy);
     ProfScope prof(PC_CHAIN, (hipStream_t)stream, (32.0 * K + 16.0) * H * W);
-    hipLaunchKernelGGL(chain_select_packed_kernel, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, ps, thr, H, W,
-                       sx, sy, flowO, occlO, sigmaO, chosen);
+#define CSP_LAUNCH(KT)                                                                                               \
+    hipLaunchKernelGGL(chain_select_packed_kernel<KT>, dim3(cdiv(W, 256), H), dim3(256), 0, (hipStream_t)stream, ps, thr, H, \
+                       W, sx, sy, flowO, occlO, sigmaO, chosen)
+    switch (K) {
+        case 1: CSP_LAUNCH(1); break;
+        case 2: CSP_LAUNCH(2); break;
+        case 3: CSP_LAUNCH(3); break;
+        case 4: CSP_LAUNCH(4); break;
+        case 5: CSP_LAUNCH(5); break;
+        case 6: CSP_LAUNCH(6); break;
+        case 7: CSP_LAUNCH(7); break;
+        case 8: CSP_LAUNCH(8); break;
+        default: CSP_LAUNCH(0); break;
+    }
+#undef CSP_LAUNCH
     return check_launch("chain_select_packed");
 }

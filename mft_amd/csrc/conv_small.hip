@@ -39,9 +39,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_kernel(const float *__re
     constexpr int NP = N <= 2 ? 2 : 4;                  // values per cell in the reduction (power of two)
     constexpr int V = S * NP;
     __shared__ __attribute__((aligned(16))) float wsm[9 * N * 256];
-    for (int i = threadIdx.x; i < 9 * N * 64; i += 256)
-        reinterpret_cast<f32x4s *>(wsm)[i] = reinterpret_cast<const f32x4s *>(wpk)[i];     // [n][tap][256] as packed
-    __syncthreads();
     const int lane = threadIdx.x & 63;
     // A block = 4 consecutive rows of one strip (its waves share 2 of their 3 input rows), and workgroup b runs
     // on XCD b % 8 (observed; only speed depends on it): each XCD gets a contiguous band of row groups, strips
@@ -50,10 +47,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_kernel(const float *__re
     const int rows = P * h, groups = (rows + 3) / 4;
     const int nb = groups * strips_per_row, per_xcd = (nb + 7) / 8;
     const int vb = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per_xcd || vb >= nb) return;
+    if ((int)(blockIdx.x >> 3) >= per_xcd || vb >= nb) return;            // (uniform per block)
     const int strip = vb % strips_per_row;
-    const int rowid = (vb / strips_per_row) * 4 + (threadIdx.x >> 6);     // img*h + y
-    if (rowid >= rows) return;
+    const int rowid_raw = (vb / strips_per_row) * 4 + (threadIdx.x >> 6); // img*h + y
+    const bool live = rowid_raw < rows;                                   // a wave past the last row still helps fill the weights
+    const int rowid = live ? rowid_raw : rows - 1;
     const int y = rowid % h;
     const int img_base = (rowid / h) * h * w;
     const int x0 = strip * S;
@@ -72,6 +70,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_small_kernel(const float *__re
             col[r][c] = __builtin_bit_cast(f32x4s, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
         }
     }
+    // the block's weights go to LDS while the input loads are in flight (both latencies overlap)
+    for (int i = threadIdx.x; i < 9 * N * 64; i += 256)
+        reinterpret_cast<f32x4s *>(wsm)[i] = reinterpret_cast<const f32x4s *>(wpk)[i];     // [n][tap][256] as packed
+    __syncthreads();
+    if (!live) return;
     // the value to accumulate into is fetched now, so that its latency is gone by the end of the strip
     const int v_mine = lane >> 2;                                  // output this lane ends up with (if lane % 4 == 0)
     const int t_mine = v_mine / NP, n_mine = v_mine % NP;

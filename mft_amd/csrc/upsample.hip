@@ -45,6 +45,21 @@ __global__ __launch_bounds__(64 * UP_WAVES) void convex_upsample_kernel(UpArgs p
     float m[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) m[k] = mk[k * 64];
+    // the nine neighbours' coarse values: wave-uniform -> scalar loads, ALL issued here, branch-free (an outside
+    // neighbour is read at a clamped address and weighted 0) -- as a chain of nine bounds-checked round trips
+    // behind the softmax they were the kernel's critical path
+    float nfx[9], nfy[9], nl0[9], nl1[9], nu[9];
+    bool nok[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int ny = y + k / 3 - 1, nx = x + k % 3 - 1;
+        nok[k] = ny >= 0 && ny < p.h && nx >= 0 && nx < p.w;
+        const int cy = min(max(ny, 0), p.h - 1), cx = min(max(nx, 0), p.w - 1);
+        const long long nc = ((long long)img * p.h + cy) * p.w + cx;
+        const float2 f = reinterpret_cast<const float2 *>(p.flow_lr)[nc];
+        const float *o = p.ou + nc * p.ld_ou;
+        nfx[k] = f.x; nfy[k] = f.y; nl0[k] = o[0]; nl1[k] = o[1]; nu[k] = o[2];
+    }
     float mx = m[0];
 #pragma unroll
     for (int k = 1; k < 9; ++k) mx = fmaxf(mx, m[k]);
@@ -54,17 +69,12 @@ __global__ __launch_bounds__(64 * UP_WAVES) void convex_upsample_kernel(UpArgs p
     float fxv = 0.f, fyv = 0.f, l0 = 0.f, l1 = 0.f, u = 0.f;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-        const int ny = y + k / 3 - 1, nx = x + k % 3 - 1;          // wave-uniform: scalar branch, scalar loads
-        if (ny < 0 || ny >= p.h || nx < 0 || nx >= p.w) continue;
-        const long long nc = ((long long)img * p.h + ny) * p.w + nx;
-        const float wk = m[k] / den;
-        const float2 f = reinterpret_cast<const float2 *>(p.flow_lr)[nc];
-        const float *o = p.ou + nc * p.ld_ou;
-        fxv += wk * (8.f * f.x);
-        fyv += wk * (8.f * f.y);
-        l0 += wk * o[0];
-        l1 += wk * o[1];
-        u += wk * o[2];
+        const float wk = nok[k] ? m[k] / den : 0.f;              // zeros outside (core/raft.py:88: unfold pads with 0)
+        fxv += wk * (8.f * nfx[k]);
+        fyv += wk * (8.f * nfy[k]);
+        l0 += wk * nl0[k];
+        l1 += wk * nl1[k];
+        u += wk * nu[k];
     }
     const int Y0 = 8 * y + (lane >> 3) - p.pt, X0 = 8 * x + (lane & 7) - p.pl;   // unpadded coordinates
     if (Y0 < 0 || Y0 >= p.H0 || X0 < 0 || X0 >= p.W0) return;
