@@ -302,6 +302,41 @@ def test_compute_flow_540p_odd_pyramid_vs_oracle(flower, weights_cpu):
     assert ((extra["sigma"].cpu() - rs).abs() / rs).max() < 2e-3
 
 
+@pytest.mark.timeout(900)
+def test_c5_1080p_pair_vs_oracle(flower, weights_np, weights_cpu):
+    """BASELINE.json configs[4] size: one 1080x1920 pair (135x240 grid, 32 400 query cells, 4.2 GB level-0 volume),
+    2 iterations, against the CPU oracle -- with the stored pyramid and with the on-demand correlation
+    (raft_params.alternate_corr), the memory-light mode meant for this size."""
+    import os
+    from mft_amd.config import AttrDict, Config
+    from mft_amd.raft import RAFTWrapper
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+    vid = SyntheticVideo(1080, 1920, n_frames=3, seed=17)
+    with torch.no_grad():
+        rf, ro, rs = O.compute_flow(weights_cpu, vid[0], vid[2], 2)
+    flower.C.flow_iters = 2
+    try:
+        flow, extra = flower.compute_flow(vid[0], vid[2], mode="flow")
+    finally:
+        flower.C.flow_iters = 12
+    e = epe(flow.cpu(), rf)
+    assert e.mean() <= 1e-3 and e.max() < 1e-2, (float(e.mean()), float(e.max()))
+    assert (extra["occlusion"].cpu() - ro).abs().max() < 2e-3
+    assert ((extra["sigma"].cpu() - rs).abs() / rs).max() < 2e-3
+    del flow, extra
+    torch.cuda.empty_cache()
+    c = Config()
+    c.flow_iters = 2
+    c.raft_params = AttrDict(alternate_corr=True)
+    alt = RAFTWrapper(c, state_dict=weights_np)
+    flow, extra = alt.compute_flow(vid[0], vid[2], mode="flow")
+    e = epe(flow.cpu(), rf)
+    assert e.mean() <= 1e-3 and e.max() < 1e-2, (float(e.mean()), float(e.max()))
+    assert (extra["occlusion"].cpu() - ro).abs().max() < 2e-3
+    del alt, flow, extra
+    torch.cuda.empty_cache()
+
+
 def test_compute_flow_1080p_smoke(flower):
     """BASELINE config 5 size (1080x1920, 135x240 grid, 4.2 GB level-0 volume per
     pair): runs, is finite, and a pair's result does not depend on batching."""
