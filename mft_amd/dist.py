@@ -11,8 +11,8 @@ never depend on tracker state -- RAFT sees only the two images, ``flow_init`` is
      a frame another rank already encoded;
   2. the units, in (frame, selection-order) order, are cut into G contiguous, equally sized
      shares (sizes differ by at most one); every rank runs its share through the native RAFT
-     engine in batches of up to 7 pairs -- the batch size at which the conv GEMMs reach their
-     single-GPU rate (``profiles/r1k_bench_pairs.txt``) -- whatever G is;
+     engine in equal batches of up to 16 pairs -- at or above the single-GPU tracker's 7, where the
+     conv GEMMs run at their full rate -- whatever G is;
   3. ONE all-gather of the raw FlowOU results in the packed per-pixel format (fx, fy, occl, sigma:
      16 B per pixel and unit; written into the send buffer by the engine itself; the last slot of a
      short share is simply not read -- nothing is zero-filled, nothing is staged);
@@ -56,8 +56,10 @@ def frame_owner(j: int, world_size: int) -> int:
 
 
 class WindowSharder:
-    #: pairs per engine call (the single-GPU tracker's batch at steady state)
-    MAX_BATCH = 7
+    #: most pairs per engine call.  Per-pair time of a call (512 x 512, 12 iterations, two half-batches on two
+    #: streams): 2.08 ms at 7 pairs, 2.03 at 8, 1.99 at 14, 1.97 at 16 (the 64-row tiles of 8 k pairs divide the 256 CUs
+    #: evenly for every layer) -- a share is cut into equal batches of at most this many pairs
+    MAX_BATCH = 16
 
     def __init__(self, group=None):
         if not dist.is_initialized():
@@ -135,8 +137,10 @@ class WindowSharder:
         # receive buffer -- no staging copies on either side
         send = torch.empty(max(slots, 1), H, W, 4, dtype=torch.float32, device=dev)
         mine = units[off: off + cnt]
-        for b0 in range(0, cnt, self.MAX_BATCH):
-            batch = mine[b0: b0 + self.MAX_BATCH]
+        n_batches = -(-cnt // self.MAX_BATCH) if cnt else 0
+        bounds = [(cnt * i) // n_batches for i in range(n_batches + 1)] if cnt else [0]
+        for b0, b1 in zip(bounds[:-1], bounds[1:]):
+            batch = mine[b0: b1]
             pairs = []
             for j, k in batch:
                 left_id = plans[j][k][1]
