@@ -244,7 +244,8 @@ def run_frames(tracker, frames, first, count, window):
     i = first
     while i < first + count:
         n = min(window, first + count - i)
-        tracker.track_window(frames[i: i + n])
+        nxt = frames[i + n: min(i + 2 * n, first + count)]          # the following window: its encoders start early
+        tracker.track_window(frames[i: i + n], next_imgs=nxt)
         pairs += [len(tracker._plan(k)) for k in range(i, i + n)]
         i += n
     return pairs

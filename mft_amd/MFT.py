@@ -136,13 +136,14 @@ class MFT():
         lefts = [self.memory[left_id]['result'].planes() for _, left_id, _ in plan]
         return self._finish_frame(frame_i, input_img, plan, lefts, rights)
 
-    def track_window(self, imgs):
+    def track_window(self, imgs, next_imgs=None):
         """Track the next ``len(imgs)`` frames and return their metas in order.  Same results as calling
         ``track`` on each; with ``C.delta_sharding`` and several ranks the (frame, delta) flow
-        computations of the whole window are sharded over the GPUs (``mft_amd/dist.py``)."""
+        computations of the whole window are sharded over the GPUs (``mft_amd/dist.py``).  ``next_imgs``
+        (optional): the frames of the window after this one, so that their encoding can start early."""
         imgs = list(imgs)
         if self._sharded() and imgs:
-            return self.sharder.track_window(self, imgs)
+            return self.sharder.track_window(self, imgs, next_imgs=list(next_imgs) if next_imgs else None)
         return [self.track(img) for img in imgs]
 
     def _finish_frame(self, frame_i, input_img, plan, lefts, rights):

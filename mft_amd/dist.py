@@ -55,6 +55,11 @@ def frame_owner(j: int, world_size: int) -> int:
     return j % world_size
 
 
+class _NullCtx:
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+
+
 class WindowSharder:
     #: most pairs per engine call.  Per-pair time of a call (512 x 512, 12 iterations, two half-batches on two
     #: streams): 2.08 ms at 7 pairs, 2.03 at 8, 1.99 at 14, 1.97 at 16 (the 64-row tiles of 8 k pairs divide the 256 CUs
@@ -68,6 +73,8 @@ class WindowSharder:
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
         self.stats = {"windows": 0, "units": 0, "my_units": 0, "encoded": 0}
+        self._prefetch = None          # feature exchange of the next window, started early
+        self._side = None              # side stream for it
 
     @classmethod
     def from_environment(cls):
@@ -82,35 +89,57 @@ class WindowSharder:
         return recv
 
     # ------------------------------------------------------------------ features
-    def _exchange_features(self, tracker, frame_ids, imgs):
-        """Encode each window frame on its owner and all-gather (fmap | net | inp); afterwards the
-        flow plugin's per-frame cache holds every window frame on every rank."""
+    def _start_feature_exchange(self, tracker, frame_ids, imgs, side=False):
+        """Encode the window frames this rank owns and start the all-gather of (fmap | net | inp).  With ``side`` the
+        encoders and the collective run off the caller's stream (a side stream; the collective is asynchronous), so
+        that the NEXT window's features are produced while the current window's RAFT batches run.  Returns a handle
+        for ``_finish_feature_exchange`` (None: nothing to exchange)."""
         flower = tracker.flower
         G, L = self.world_size, len(frame_ids)
-        if not hasattr(flower, "encode_packed"):
-            return                                   # reference-style plugin: nothing to exchange
-        if L < G:
-            return                                   # fewer frames than ranks: everyone encodes what it needs
+        if not hasattr(flower, "encode_packed") or L < G:
+            return None              # a reference-style plugin, or fewer frames than ranks: everyone encodes what it needs
+        on_gpu = torch.device(tracker.device).type == "cuda"
+        stream = None
+        if side and on_gpu:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=tracker.device)
+            stream = self._side
         slots = -(-L // G)
         mine = [j for j in range(L) if frame_owner(j, G) == self.rank]
-        send = None
-        for s, j in enumerate(mine):
-            packed, geom = flower.encode_packed(imgs[j])          # [N, 512]
-            if send is None:
-                send = torch.empty((slots,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-            send[s] = packed
-            self.stats["encoded"] += 1
-        if send is None:                              # cannot happen for L >= G, kept for clarity
-            packed, geom = flower.encode_packed(imgs[0])
-            send = torch.empty((slots,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-        recv = self._all_gather(send)                 # [G, slots, N, 512]
-        for j in range(L):
-            flower.adopt_packed(frame_ids[j], recv[frame_owner(j, G), j // G], imgs[j])
+        ctx = torch.cuda.stream(stream) if stream is not None else _NullCtx()
+        with ctx:
+            send = None
+            for s_, j in enumerate(mine):
+                packed, _ = flower.encode_packed(imgs[j])              # [N * 512]
+                if send is None:
+                    send = torch.empty((slots,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+                send[s_] = packed
+                self.stats["encoded"] += 1
+            recv = torch.empty((G,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+            # (NCCL orders the collective behind the work already on the CURRENT stream -- the side stream here)
+            work = dist.all_gather_into_tensor(recv.view(G * send.shape[0], *send.shape[1:]), send, group=self.group,
+                                               async_op=side)
+        return dict(ids=list(frame_ids), imgs=list(imgs), recv=recv, send=send, work=work, stream=stream)
+
+    def _finish_feature_exchange(self, tracker, h):
+        """Wait for the exchange and install the features in the flow plugin's per-frame cache (all ranks)."""
+        if h is None:
+            return
+        if h["work"] is not None:
+            h["work"].wait()                          # the caller's stream now waits for the collective
+        if h["stream"] is not None:
+            cur = torch.cuda.current_stream(h["recv"].device)
+            cur.wait_stream(h["stream"])
+            h["recv"].record_stream(cur)
+        G = self.world_size
+        for j, fid in enumerate(h["ids"]):
+            tracker.flower.adopt_packed(fid, h["recv"][frame_owner(j, G), j // G], h["imgs"][j])
 
     # ------------------------------------------------------------------ the window
-    def track_window(self, tracker, imgs):
+    def track_window(self, tracker, imgs, next_imgs=None):
         """Track ``imgs`` (the next L frames); returns their metas in order.  Identical results and
-        tracker state on every rank."""
+        tracker state on every rank.  ``next_imgs``: the frames of the FOLLOWING window, if known -- their
+        encoding and feature exchange are started on a side stream now and overlap this window's RAFT batches."""
         G, r = self.world_size, self.rank
         L = len(imgs)
         d = tracker.time_direction
@@ -127,7 +156,16 @@ class WindowSharder:
         slots = max(c for _, c in shares)
 
         tracker._window_ids = set(frame_ids)
-        self._exchange_features(tracker, frame_ids, imgs)
+        pre = self._prefetch
+        self._prefetch = None
+        if pre is not None and pre["ids"] == frame_ids:
+            self._finish_feature_exchange(tracker, pre)                      # started during the previous window
+        else:
+            self._finish_feature_exchange(tracker, self._start_feature_exchange(tracker, frame_ids, imgs))
+        if next_imgs:
+            nxt_ids = [frame_ids[-1] + d * (j + 1) for j in range(len(next_imgs))]
+            tracker._window_ids |= set(nxt_ids)
+            self._prefetch = self._start_feature_exchange(tracker, nxt_ids, list(next_imgs), side=True)
 
         # ---- my share, in engine batches
         H, W = tracker.img_H, tracker.img_W
@@ -169,8 +207,8 @@ class WindowSharder:
                 u += 1
                 rights.append(recv[rr, s])            # packed [H, W, 4]
                 lefts.append(tracker.memory[plan[k][1]]['result'].planes())
-            if j == L - 1:
-                tracker._window_ids = set()
+            if j == L - 1:                             # (a prefetched next window's features stay until it is tracked)
+                tracker._window_ids = set(self._prefetch["ids"]) if self._prefetch is not None else set()
             metas.append(tracker._finish_frame(fid, imgs[j], plan, lefts, rights))
         return metas
 

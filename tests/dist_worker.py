@@ -49,13 +49,14 @@ class ExchangingFlower:
         return out
 
 
-def run(sharded, window, flower):
+def run(sharded, window, flower, prefetch=False):
     tr = make_tracker(flower, delta_sharding=sharded)
     tr.init(gi.id_image(0))
     out, i = {}, 1
     while i < N_FRAMES:
         imgs = [gi.id_image(k) for k in range(i, min(i + window, N_FRAMES))]
-        metas = tr.track_window(imgs) if window > 1 else [tr.track(imgs[0])]
+        nxt = [gi.id_image(k) for k in range(i + window, min(i + 2 * window, N_FRAMES))] if prefetch else None
+        metas = tr.track_window(imgs, next_imgs=nxt) if window > 1 else [tr.track(imgs[0])]
         for k, m in enumerate(metas):
             res = m.result
             out[f"flow{i + k}"] = res.flow.numpy()
@@ -72,10 +73,11 @@ if __name__ == "__main__":
     torch.set_num_threads(2)
     dist.init_process_group("gloo")
     rank = dist.get_rank()
-    for mode, window, mk in (("L1", 1, StubFlower), ("L8", 8, StubFlower), ("L5x", 5, ExchangingFlower)):
+    for mode, window, mk in (("L1", 1, StubFlower), ("L8", 8, StubFlower), ("L5x", 5, ExchangingFlower),
+                             ("L5p", 5, ExchangingFlower)):
         fl = mk()
-        res, tr = run(True, window, fl)
-        if mode == "L5x":
+        res, tr = run(True, window, fl, prefetch=(mode == "L5p"))      # L5p: next window's features exchanged early
+        if mode in ("L5x", "L5p"):
             st = tr.sharder.stats
             res.update(_encoded=np.array(fl.encoded), _frames=np.array(N_FRAMES - 1), _my_units=np.array(st["my_units"]),
                        _windows=np.array(st["windows"]))

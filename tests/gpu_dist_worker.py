@@ -20,7 +20,7 @@ from mft_amd.weights import make_weights  # noqa: E402
 N_FRAMES = 14
 
 
-def run(flower, sharding, window):
+def run(flower, sharding, window, prefetch=False):
     c = Config()
     c.deltas = [np.inf, 1, 2, 4, 8]
     c.occlusion_threshold = 0.02
@@ -33,7 +33,8 @@ def run(flower, sharding, window):
     out, i = {}, 1
     while i < N_FRAMES:
         imgs = [vid[k] for k in range(i, min(i + window, N_FRAMES))]
-        metas = tr.track_window(imgs) if window > 1 else [tr.track(imgs[0])]
+        nxt = [vid[k] for k in range(i + window, min(i + 2 * window, N_FRAMES))] if prefetch else None
+        metas = tr.track_window(imgs, next_imgs=nxt) if window > 1 else [tr.track(imgs[0])]
         for k, m in enumerate(metas):
             res = m.result
             out[f"flow{i + k}"], out[f"occl{i + k}"], out[f"sigma{i + k}"] = \
@@ -54,8 +55,8 @@ if __name__ == "__main__":
     flower = RAFTWrapper(fc, state_dict=make_weights(7))
     rank, world = dist.get_rank(), dist.get_world_size()
     sharding = "force" if world == 1 else True
-    for mode, window in (("L1", 1), ("L6", 6)):
-        res, tr = run(flower, sharding, window)
+    for mode, window in (("L1", 1), ("L6", 6), ("L6p", 6)):
+        res, tr = run(flower, sharding, window, prefetch=(mode == "L6p"))   # L6p: next window's encoders + exchange on a side stream
         res["_encoded"] = np.array(tr.sharder.stats["encoded"])
         np.savez(outdir / f"rank{rank}_{mode}.npz", **res)
     if rank == 0:
