@@ -74,7 +74,6 @@ class WindowSharder:
         self.world_size = dist.get_world_size(group)
         self.stats = {"windows": 0, "units": 0, "my_units": 0, "encoded": 0}
         self._prefetch = None          # feature exchange of the next window, started early
-        self._side = None              # side stream for it
 
     @classmethod
     def from_environment(cls):
@@ -98,19 +97,16 @@ class WindowSharder:
         G, L = self.world_size, len(frame_ids)
         if not hasattr(flower, "encode_packed") or L < G:
             return None              # a reference-style plugin, or fewer frames than ranks: everyone encodes what it needs
-        on_gpu = torch.device(tracker.device).type == "cuda"
         stream = None
-        if side and on_gpu:
-            if self._side is None:
-                self._side = torch.cuda.Stream(device=tracker.device)
-            stream = self._side
+        if side and hasattr(flower, "ensure_encode_stream"):
+            stream = flower.ensure_encode_stream()   # all encoder work of the plugin is serialised on this stream
         slots = -(-L // G)
         mine = [j for j in range(L) if frame_owner(j, G) == self.rank]
         ctx = torch.cuda.stream(stream) if stream is not None else _NullCtx()
         with ctx:
             send = None
             for s_, j in enumerate(mine):
-                packed, _ = flower.encode_packed(imgs[j])              # [N * 512]
+                packed, _ = flower.encode_packed(imgs[j])              # [N * 512]; on the encode stream if there is one
                 if send is None:
                     send = torch.empty((slots,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
                 send[s_] = packed

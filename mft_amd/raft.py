@@ -116,17 +116,39 @@ class RAFTWrapper:
             net, inp = self.cnet_engine.forward(img)
         return FrameFeatures(fmap, net, inp, h, w, pads, (H0, W0))
 
+    def ensure_encode_stream(self):
+        """The stream every encoder launch of this plugin runs on from now on (the encoder engines own ONE workspace
+        each: encodes issued from different streams would race on it)."""
+        if self._enc_stream is None:
+            self._enc_stream = torch.cuda.Stream(device=self.device)
+            self._enc_stream.wait_stream(torch.cuda.current_stream(self.device))   # encodes already queued elsewhere finish first
+        return self._enc_stream
+
     @torch.no_grad()
-    def encode_packed(self, img_bgr):
+    def encode_packed(self, img_bgr, wait=True):
         """All features of a frame in ONE buffer [h*w*512] = fmap [N,256] | net [N,128] | inp [N,128]
-        (each block contiguous), the unit the multi-GPU path all-gathers.  -> (buffer, (h, w))."""
+        (each block contiguous), the unit the multi-GPU path all-gathers.  -> (buffer, (h, w)).
+        Runs on the encode stream when there is one; wait=False leaves the caller's stream un-synchronised with it
+        (the caller orders later consumers itself, e.g. behind a collective issued on the encode stream)."""
         H0, W0 = img_bgr.shape[:2]
-        img = self._device_image(img_bgr)
         h, w, _ = self._geometry(H0, W0)
         N = h * w
-        buf = torch.empty(N * 512, dtype=torch.float32, device=self.device)
-        self.fnet_engine.forward(img, out=(buf[: N * 256].view(N, 256), None))
-        self.cnet_engine.forward(img, out=(buf[N * 256: N * 384].view(N, 128), buf[N * 384:].view(N, 128)))
+
+        def run():
+            img = self._device_image(img_bgr)
+            buf = torch.empty(N * 512, dtype=torch.float32, device=self.device)
+            self.fnet_engine.forward(img, out=(buf[: N * 256].view(N, 256), None))
+            self.cnet_engine.forward(img, out=(buf[N * 256: N * 384].view(N, 128), buf[N * 384:].view(N, 128)))
+            return buf
+
+        if self._enc_stream is None or torch.cuda.current_stream(self.device) == self._enc_stream:
+            return run(), (h, w)
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self._enc_stream):
+            buf = run()
+        if wait:
+            main.wait_stream(self._enc_stream)
+            buf.record_stream(main)
         return buf, (h, w)
 
     def adopt_packed(self, frame_id, buf, img_bgr):
