@@ -180,9 +180,9 @@ class WindowSharder:
                 left_id = plans[j][k][1]
                 pairs.append((left_id, img_of(left_id), frame_ids[j], imgs[j]))
             res = tracker._flows_for_pairs(pairs, packed_out=send[b0: b0 + len(batch)], planar=False)
-            for s, r in enumerate(res):
-                if len(r) < 4:                        # a plugin without packed output: interleave here
-                    send[b0 + s].copy_(torch.cat([r[0], r[1], r[2]], 0).permute(1, 2, 0))
+            for s, out in enumerate(res):
+                if len(out) < 4:                      # a plugin without packed output: interleave here
+                    send[b0 + s].copy_(torch.cat([out[0], out[1], out[2]], 0).permute(1, 2, 0))
         recv = self._all_gather(send)                 # [G, slots, H, W, 4]
         self.stats["windows"] += 1
         self.stats["units"] += len(units)
