@@ -36,6 +36,15 @@ from pathlib import Path
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+# stdout must carry ONE JSON line and nothing else.  Native libraries print to fd 1 from C (the RCCL version banner, some
+# of it only when the process exits, through descriptors they set up when they are loaded), so fd 1 is pointed at stderr
+# BEFORE torch is imported and the JSON line goes to the saved real stdout at the end.
+REAL_STDOUT = None
+if __name__ == "__main__" and not {"-h", "--help"} & set(sys.argv[1:]):
+    sys.stdout.flush()
+    REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -229,7 +238,7 @@ def respawn_under_torchrun(n):
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     log(f"--gpus {n} without a launcher: re-executing as {' '.join(cmd[1:8])} ...")
-    return subprocess.run(cmd, env=env).returncode
+    return subprocess.run(cmd, env=env, stdout=REAL_STDOUT if REAL_STDOUT is not None else None).returncode
 
 
 def run_frames(tracker, frames, first, count, window):
@@ -277,12 +286,6 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(respawn_under_torchrun(args.gpus))
-    # stdout must carry ONE JSON line and nothing else: native libraries (the RCCL version banner, ...) print to fd 1
-    # from C, some of it only when the process exits -- so fd 1 is pointed at stderr for the whole run and the JSON
-    # line goes to the real stdout at the end
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -403,7 +406,7 @@ def main():
                 result.setdefault("parity", {}).update(track_parity(args, vid, oracle_meta))
                 log(f"track() parity vs oracle: {result['parity']}")
     if rank == 0:
-        os.write(real_stdout, (json.dumps(result) + "\n").encode())
+        os.write(REAL_STDOUT if REAL_STDOUT is not None else 1, (json.dumps(result) + "\n").encode())
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
