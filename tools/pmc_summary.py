@@ -79,4 +79,30 @@ if p.exists():
             r = list(r)
             r[0] = r[0][:120]
             w.writerow(r)
+# ---- steady-state kernel table from the raw trace: the tracker issues the same number of launches per kernel for every
+# frame (only the pair count, i.e. the grid, grows over the 32 pre-roll frames), so the LAST third of every kernel's
+# dispatches (by start time) belongs to the 7-pair frames bench.py times -- comparable with its HIP-event averages
+p = src / "trace" / "bench_kernel_trace.csv"
+if p.exists():
+    per = collections.defaultdict(list)
+    with open(p) as f:
+        for r in csv.DictReader(f):
+            if "mftx" in r["Kernel_Name"]:
+                per[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    rows = []
+    for k, v in per.items():
+        v.sort()
+        tail = [d for _, d in v[len(v) - max(1, len(v) // 3):]]
+        rows.append((sum(tail), k, len(v), len(tail), sum(tail) / len(tail) / 1e3))
+    tot = sum(r[0] for r in rows)
+    with open(out / "kernel_stats_steady.csv", "w") as f:
+        f.write("# steady-state (7 pairs per frame) launches only: last third of each kernel's dispatches in the rocprofv3\n"
+                "# --kernel-trace of tools/gpu_profile.sh's bench command (one batch on one stream, encoders on the main stream)\n"
+                "kernel,dispatches_total,dispatches_steady,avg_us_steady,share_of_steady_gpu_time\n")
+        for t, k, n, m, avg in sorted(rows, reverse=True):
+            f.write(f'"{k}",{n},{m},{avg:.1f},{t / tot:.4f}\n')
+        gemm = [(t, m) for t, k, n, m, avg in rows if "conv_gemm" in k and ", 4, 32>" not in k]
+        if gemm:
+            f.write(f"# all conv-GEMM launches except the volume GEMM: {sum(t for t, _ in gemm) / sum(m for _, m in gemm) / 1e3:.1f} us "
+                    f"average -- the figure bench.py reports as kernels.conv_gemm.avg_us (HIP events, + ~1.5 us of bracket)\n")
 print("wrote", sorted(x.name for x in out.iterdir()))
