@@ -174,29 +174,6 @@ struct PackedSet {
     const float4 *R[MFTX_MAX_CANDIDATES];
 };
 
-template <class TapFn>
-__device__ __forceinline__ Chained chain_core(float lfx, float lfy, float locc, float lsig, int H, int W, int x, int y,
-                                              float sx, float sy, TapFn tap4) {
-    const float gx = (float)x, gy = (float)y;
-    const float px = gx + lfx;
-    const float py = gy + lfy;
-    const float ix = ((px * sx - 1.f) + 1.f) / 2.f * (float)(W - 1);
-    const float iy = ((py * sy - 1.f) + 1.f) / 2.f * (float)(H - 1);
-    const float flx = floorf(ix), fly = floorf(iy);
-    const float wx = ix - flx, wy = iy - fly;
-    const int x0 = (int)fminf(fmaxf(flx, -1.0e6f), 1.0e6f);
-    const int y0 = (int)fminf(fmaxf(fly, -1.0e6f), 1.0e6f);
-    const float w00 = (1.f - wx) * (1.f - wy), w01 = wx * (1.f - wy), w10 = (1.f - wx) * wy, w11 = wx * wy;
-    const float4 a = tap4(y0, x0), b = tap4(y0, x0 + 1), c = tap4(y0 + 1, x0), d = tap4(y0 + 1, x0 + 1);
-    Chained o;
-    o.fx = (px + (a.x * w00 + b.x * w01 + c.x * w10 + d.x * w11)) - gx;
-    o.fy = (py + (a.y * w00 + b.y * w01 + c.y * w10 + d.y * w11)) - gy;
-    o.occ = max_nanprop(locc, a.z * w00 + b.z * w01 + c.z * w10 + d.z * w11);
-    const float sr = a.w * w00 + b.w * w01 + c.w * w10 + d.w * w11;
-    o.sig = sqrtf(lsig * lsig + sr * sr);
-    return o;
-}
-
 __device__ __forceinline__ void write_selected4(const Best (&b)[4], int H, int W, int x, int y, float *flowO,
                                                 float *occlO, float *sigmaO, int8_t *chosen) {
     const long long pix = (long long)y * W + x, plane = (long long)H * W;
