@@ -1,4 +1,4 @@
-"""Worker for the 2-rank gloo test of the window-sharded tracker (CPU)."""
+"""Worker for the multi-rank gloo test of the window-sharded tracker (CPU)."""
 import sys
 from pathlib import Path
 
@@ -21,7 +21,7 @@ class ExchangingFlower:
     a pair may only be computed from features this rank encoded itself or adopted from a peer."""
 
     def __init__(self):
-        self.features, self.encoded = {}, 0
+        self.features, self.encoded, self.local = {}, 0, 0
 
     def encode_packed(self, img):
         self.encoded += 1
@@ -41,8 +41,8 @@ class ExchangingFlower:
         out = []
         for lk, limg, rk, rimg in pairs:
             for k, img in ((lk, limg), (rk, rimg)):
-                if k not in self.features:              # only the start frame is ever encoded locally
-                    assert k == 0, f"frame {k} was not exchanged"
+                if k not in self.features:              # the start frame, and the frames of a window shorter than the
+                    self.local += k != 0                # world size (no exchange: every rank encodes what it needs)
                     self.features[k] = torch.full((6,), float(k))
             flow, occl, sigma = gi.stub_flowou(int(self.features[lk][0]), int(self.features[rk][0]))
             out.append((T(flow), T(occl), T(sigma)))
@@ -73,13 +73,14 @@ if __name__ == "__main__":
     torch.set_num_threads(2)
     dist.init_process_group("gloo")
     rank = dist.get_rank()
-    for mode, window, mk in (("L1", 1, StubFlower), ("L8", 8, StubFlower), ("L5x", 5, ExchangingFlower),
-                             ("L5p", 5, ExchangingFlower)):
+    wx = max(5, dist.get_world_size())       # the feature exchange needs at least one frame per rank in a window
+    for mode, window, mk in (("L1", 1, StubFlower), ("L8", 8, StubFlower), ("L5x", wx, ExchangingFlower),
+                             ("L5p", wx, ExchangingFlower)):
         fl = mk()
         res, tr = run(True, window, fl, prefetch=(mode == "L5p"))      # L5p: next window's features exchanged early
         if mode in ("L5x", "L5p"):
             st = tr.sharder.stats
-            res.update(_encoded=np.array(fl.encoded), _frames=np.array(N_FRAMES - 1), _my_units=np.array(st["my_units"]),
+            res.update(_encoded=np.array(fl.encoded), _local=np.array(fl.local), _frames=np.array(N_FRAMES - 1), _my_units=np.array(st["my_units"]),
                        _windows=np.array(st["windows"]))
         np.savez(outdir / f"rank{rank}_{mode}.npz", **res)
     if rank == 0:

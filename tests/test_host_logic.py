@@ -289,31 +289,35 @@ def test_shard_plan():
 
 
 @pytest.mark.timeout(300)
-def test_window_sharding_two_ranks_gloo(tmp_path):
-    """World size 2 over gloo: the per-frame mode (L = 1), look-ahead windows (L = 8, ragged last
-    window) and the feature-exchanging path (L = 5) all reproduce the single-rank tracker bit for bit,
-    on every rank; with exchanged features no rank encodes a frame another rank owns."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_window_sharding_gloo(tmp_path, world):
+    """World size 2 and 4 over gloo: the per-frame mode (L = 1; at world 4 some ranks own no unit of a
+    frame), look-ahead windows (L = 8, ragged last window) and the feature-exchanging path (L = 5) all
+    reproduce the single-rank tracker bit for bit, on every rank; with exchanged features no rank
+    encodes a frame another rank owns."""
     script = REPO / "tests" / "dist_worker.py"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    port = str(29609 + world)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     out = tmp_path / "out"
     out.mkdir()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29611", str(script), str(out)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", port, str(script), str(out)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     single = np.load(out / "single.npz")
     for mode in ("L1", "L8", "L5x", "L5p"):
-        r0 = np.load(out / f"rank0_{mode}.npz")
-        r1 = np.load(out / f"rank1_{mode}.npz")
+        rk = [np.load(out / f"rank{r}_{mode}.npz") for r in range(world)]
         for k in single.files:
-            assert np.array_equal(r0[k], r1[k]), (mode, k)          # replicas stay identical
-            assert np.array_equal(r0[k], single[k]), (mode, k)      # and equal to the unsharded run
+            for r in range(world):                                      # replicas stay identical, and equal to the unsharded run
+                assert np.array_equal(rk[r][k], single[k]), (mode, r, k)
     for mode in ("L5x", "L5p"):
-        st = [np.load(out / f"rank{r}_{mode}.npz") for r in range(2)]
-        # every window frame was encoded exactly once across the two ranks (also when the next window's exchange is
-        # started early, L5p)
-        assert int(st[0]["_encoded"]) + int(st[1]["_encoded"]) == int(st[0]["_frames"]), mode
-        assert abs(int(st[0]["_my_units"]) - int(st[1]["_my_units"])) <= int(st[0]["_windows"])
+        st = [np.load(out / f"rank{r}_{mode}.npz") for r in range(world)]
+        # every window frame was encoded exactly once across the ranks (also when the next window's exchange is
+        # started early, L5p), none outside the exchange
+        assert sum(int(s["_encoded"]) for s in st) == int(st[0]["_frames"]), mode
+        assert all(int(s["_local"]) == 0 for s in st), mode
+        units = [int(s["_my_units"]) for s in st]
+        assert max(units) - min(units) <= int(st[0]["_windows"])
 
 
 def oracle_flow_cache():
