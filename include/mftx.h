@@ -119,8 +119,18 @@ typedef struct mftx_conv_desc {
      * "same" zero padding.  stride: 1..4; hin, win: input grid per image (0 = h, w); pad_y, pad_x: 0 = k/2,
      * -1 = no padding, else explicit; residual_mode 1: out = relu(act(conv + bias) + addend). */
     int stride, hin, win, pad_y, pad_x, residual_mode;
+    /* arithmetic of the products: MFTX_ARITH_F32 = fp32 MFMA (exact fp32 products); MFTX_ARITH_SPLIT = every fp32
+     * operand as two fp16 halves, three fp16 MFMAs per product with fp32 accumulation (error of a product
+     * <= ~2^-23 relative: the same grade as fp32) -- wpk must then be the output of
+     * mftx_split_weights, and all operands below 65504 in magnitude. */
+    int arith;
 } mftx_conv_desc;
+#define MFTX_ARITH_F32 0
+#define MFTX_ARITH_SPLIT 1
 int mftx_conv2d(const mftx_conv_desc *d, void *stream);
+/* packed fp32 weights (n_floats of them, a multiple of 8) -> the split form MFTX_ARITH_SPLIT streams: same size,
+ * every 8 consecutive floats replaced by their 8 fp16 high halves and 8 fp16 low halves (x 2048) */
+int mftx_split_weights(const float *wpk, void *out, long long n_floats, void *stream);
 
 /* ---- a2, a7-a12: the whole RAFT refinement loop ----------------------------
  * Replaces RAFT.forward from the correlation volume on (core/raft.py:141-226)
@@ -136,6 +146,12 @@ size_t mftx_raft_workspace_bytes(int P, int h, int w);
  * the workspace (29.8 GB per 7-pair 1080p frame), 4-5x more time per lookup at 512x512, about even at 1080p.
  * mftx_raft_workspace_bytes_for gives the workspace size for the handle's current mode. */
 int mftx_raft_set_ondemand(mftx_raft *r, int on);
+/* Arithmetic of the update block's / OU heads' matrix products (mftx_conv_desc.arith).  split: MFTX_RAFT_NUM_WEIGHTS
+ * pointers, the mftx_split_weights form of every weight that feeds a GEMM layer (NULL in the other slots: biases, the
+ * 7x7 flow conv and the two N <= 3 output layers stay fp32) -> MFTX_ARITH_SPLIT; split = NULL -> back to
+ * MFTX_ARITH_F32 (the state after mftx_raft_create).  The pointers are kept, not copied.  mftx_raft_arith: current mode. */
+int mftx_raft_set_split_weights(mftx_raft *r, const void *const *split, int n);
+int mftx_raft_arith(const mftx_raft *r);
 size_t mftx_raft_workspace_bytes_for(const mftx_raft *r, int P, int h, int w);
 /* Byte offsets (19 of them) of the workspace regions lvl0..3, coords1, corr,
  * cor1, corflo, flo1, hx, z, rh, fh, delta, mask, ouin, ouh, ou, flow_lr: after

@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
                 ("act", C.c_int), ("out_scale", C.c_float),
                 ("addend", C.c_void_p), ("ld_addend", C.c_int),
                 ("stride", C.c_int), ("hin", C.c_int), ("win", C.c_int), ("pad_y", C.c_int), ("pad_x", C.c_int),
-                ("residual_mode", C.c_int)]
+                ("residual_mode", C.c_int), ("arith", C.c_int)]
 
 
 _PP = C.POINTER(C.c_void_p)
@@ -43,6 +43,9 @@ SIGNATURES = {
     "mftx_raft_set_ondemand": (C.c_int, [C.c_void_p, C.c_int]),
     "mftx_raft_workspace_bytes_for": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mftx_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "mftx_raft_set_split_weights": (C.c_int, [C.c_void_p, _PP, C.c_int]),
+    "mftx_raft_arith": (C.c_int, [C.c_void_p]),
+    "mftx_split_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     "mftx_raft_create": (C.c_int, [_PP, C.c_int, C.POINTER(C.c_void_p)]),
     "mftx_raft_destroy": (None, [C.c_void_p]),
     "mftx_raft_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

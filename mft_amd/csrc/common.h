@@ -71,6 +71,7 @@ struct GruEpilogue {
     float *rh;         // [M][128]
 };
 int launch_conv_gru(const mftx_conv_desc &d, const GruEpilogue &g, hipStream_t s);
+int launch_split_weights(const float *wpk, void *out, long long n_floats, hipStream_t s);
 bool conv_small_applicable(const mftx_conv_desc &d);
 int launch_conv_small(const mftx_conv_desc &d, hipStream_t s, float *accum = nullptr, int ld_accum = 0);
 // all-pairs correlation volume + its 3 pooled levels in one launch (pyramid layout above)

@@ -37,6 +37,54 @@ namespace mftx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// Arithmetic of the matrix products (template parameter AR):
+//   AR_F32  : v_mfma_f32_32x32x2_f32, exact fp32 products, 157 TF peak;
+//   AR_SPLIT: every fp32 operand x is split into two halves, x = hi + lo / 2048 with hi = fp16(x) and
+//             lo = fp16((x - hi) * 2048) (|x - hi - lo / 2048| <= 2^-24 |x|: half an fp32 ulp), and
+//             a b = hi_a hi_b + (hi_a lo_b + lo_a hi_b) / 2048 + O(2^-24 |a b|) is formed by three
+//             v_mfma_f32_32x32x16_f16 (2.5 PF peak, fp32 accumulation; each fp16 product is exact in fp32).
+//             The cross terms have their own accumulator, scaled once in the epilogue: the lo halves stay
+//             normal fp16 numbers whatever the magnitude of x.  Operands must be below 65504 in magnitude.
+enum Arith { AR_F32 = 0, AR_SPLIT = 1 };
+
+// hi / lo halves of 8 consecutive k of an activation row, 2.5 instructions per value: v_cvt_pk_f16_f32 for two
+// (round to nearest), the exact residual as one mixed-precision fma each (x - hi, hi read as fp16), and the scaled
+// low half as v_fma_mixlo/mixhi_f16 (r * 2048 rounded to fp16 into one half of the destination).  Written as one
+// assembly block: the compiler's own selection for this arithmetic takes 4 instructions per value, and does not
+// know the mixed forms.  The block ends with the two wait states a VALU result needs before an MFMA reads it
+// (the hazard recognizer does not see into inline assembly).
+__device__ __forceinline__ void split8(const f32x4 &u, const f32x4 &v, float k2048, f16x8 &hi, f16x8 &lo) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    float r0, r1, r2, r3, r4, r5, r6, r7;
+    asm("v_cvt_pk_f16_f32 %0, %16, %17\n\t"
+        "v_cvt_pk_f16_f32 %1, %18, %19\n\t"
+        "v_cvt_pk_f16_f32 %2, %20, %21\n\t"
+        "v_cvt_pk_f16_f32 %3, %22, %23\n\t"
+        "v_fma_mix_f32 %8, %0, -1.0, %16 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %9, %0, -1.0, %17 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %10, %1, -1.0, %18 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %11, %1, -1.0, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %12, %2, -1.0, %20 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %13, %2, -1.0, %21 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %14, %3, -1.0, %22 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %15, %3, -1.0, %23 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %4, %8, %24, 0\n\t"
+        "v_fma_mixlo_f16 %5, %10, %24, 0\n\t"
+        "v_fma_mixlo_f16 %6, %12, %24, 0\n\t"
+        "v_fma_mixlo_f16 %7, %14, %24, 0\n\t"
+        "v_fma_mixhi_f16 %4, %9, %24, 0\n\t"
+        "v_fma_mixhi_f16 %5, %11, %24, 0\n\t"
+        "v_fma_mixhi_f16 %6, %13, %24, 0\n\t"
+        "v_fma_mixhi_f16 %7, %15, %24, 0\n\t"
+        "s_nop 1"
+        : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3),
+          "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(k2048));
+    hi = __builtin_bit_cast(f16x8, u32x4{h0, h1, h2, h3});
+    lo = __builtin_bit_cast(f16x8, u32x4{l0, l1, l2, l3});
+}
 
 constexpr int BK = 32;
 constexpr int LDK = BK;                  // LDS row (floats): unpadded, XOR-swizzled 16-byte chunks
@@ -58,6 +106,7 @@ struct ConvArgs {
     int residual_mode;                    // 1: out = relu(act(.) + addend) (residual block tail) instead of a pre-activation addend
     int w_rows;               // valid rows of the W operand
     int act;
+    int arith;                // Arith
     float out_scale;
     int batch;                                  // correlation volume: one GEMM per pair
     long long a_bstride, w_bstride, o_bstride;  // per batch element
@@ -75,6 +124,11 @@ struct ConvArgs {
 // every MFMA group.
 #ifndef MFTX_ABLATE
 #define MFTX_ABLATE 0
+#endif
+// split-arithmetic loop (timing only, results are garbage): bit 0 operands taken as if they arrived split, 1 no
+// refills after the prologue, 2 no waits / barriers, 3 no LDS reads, 4 no MFMAs
+#ifndef MFTX_SABL
+#define MFTX_SABL 0
 #endif
 
 // Gate non-linearities of the GRU epilogues on the hardware exponential (v_exp_f32, ~1 ulp) and
@@ -124,6 +178,8 @@ __device__ __forceinline__ void wait_vmcnt() {   // counted wait: leaves N LDS-D
 #define MFTX_MINW1 4      // 128 registers: nothing spills; 5 (96 registers, spills in the GRU epilogues) measures 0.5 % slower
 #endif
 constexpr int min_waves(int wave_tiles) { return wave_tiles == 1 ? MFTX_MINW1 : wave_tiles == 2 ? 3 : 2; }
+// split arithmetic: two accumulator sets and raw + split fragments
+constexpr int min_waves_split(int wave_tiles, int waves) { return waves == 8 ? 2 : wave_tiles == 1 ? 3 : wave_tiles == 2 ? 2 : 1; }
 
 // Epilogue of the correlation-volume GEMM: one wave holds 32 query rows x one super-block (2 x 2 blocks of
 // 8 x 4 target cells, 128 columns) in acc[4].  The tile goes through the wave's private 16 KiB of LDS once:
@@ -221,9 +277,13 @@ __device__ __forceinline__ void volume_epilogue(const ConvArgs &p, const f32x16 
 // form consumes -- (k, k+4, k+1, k+5), (k+2, k+6, k+3, k+7) across its four lane groups -- the 16x16x4
 // form rounds bit-identically (both are sequential fmaf chains; tools/micro/mfma_order.hip), so the
 // tile choice still does not show in the results.
-template <int BM, int BN, int WM, int WN, int EPI, int MT = 32>
+template <int BM, int BN, int WM, int WN, int EPI, int MT = 32, int AR = AR_F32, int NS = 2>
 __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
-    constexpr int NS = 2;                       // LDS ring of two K chunks (deeper rings were measured: no gain)
+    static_assert(AR == AR_F32 || (MT == 32 && EPI != EPI_VOLUME), "split arithmetic: 32x32 tiles of the conv layers");
+    // NS: LDS ring of K chunks.  fp32 MFMA: two (a chunk is > 1000 matrix cycles per wave, deeper rings were
+    // measured: no gain).  Split arithmetic: a chunk is 192 matrix cycles per MFMA tile, well below the L2 latency:
+    // three or four chunks are kept in flight.
+    static_assert(AR == AR_SPLIT || NS == 2, "ring depth");
     constexpr int TM = BM / WM / MT, TN = BN / WN / MT;
     constexpr int NR = MT == 32 ? 16 : 4;       // accumulator registers per MFMA tile
     constexpr int RPP = 8 * WM * WN;            // rows staged per pass: 8 per wave (one 1 KiB LDS-DMA)
@@ -284,6 +344,16 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         a_frag[kk] = As + a_row0 * LDK + (((kk * 2 + khalf) ^ a_sw) * 4);
         b_frag[kk] = Bs + b_row0 * LDK + (((kk * 2 + khalf) ^ b_sw) * 4);
     }
+    // split arithmetic: a lane reads the 8 consecutive k (two 16-byte chunks) of its row and of its half of a 16-wide
+    // k group g = 0, 1 of the chunk: chunks 4 g + 2 (lane >> 5) + {0, 1}
+    const float *a_frag2[2][2], *b_frag2[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            a_frag2[g][c] = As + a_row0 * LDK + (((4 * g + 2 * khalf + c) ^ a_sw) * 4);
+            b_frag2[g][c] = Bs + b_row0 * LDK + (((4 * g + 2 * khalf + c) ^ b_sw) * 4);
+        }
     // LDS-DMA destinations: wave `wid` fills rows [RPP i + 8 wid, +8) of each RPP-row group (1 KiB, lane-linear)
     float *const a_dst = As + wid * 8 * LDK;
     float *const b_dst = Bs + wid * 8 * LDK;
@@ -396,6 +466,72 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) acc[i][j][r] = 0.f;
 
+    acc_t accx[AR == AR_SPLIT ? TM : 1][AR == AR_SPLIT ? TN : 1];      // cross terms (x 2048)
+    if constexpr (AR == AR_SPLIT) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) accx[i][j][r] = 0.f;
+    }
+    // ---- split arithmetic: raw fp32 fragments double buffered in registers, split right before their MFMAs
+    f32x4 ra[2][AR == AR_SPLIT ? TM : 1][2], rb[2][AR == AR_SPLIT ? TN : 1][2];
+    auto read_raw = [&](int buf, int g, int slot) {
+        if constexpr (AR == AR_SPLIT && !(MFTX_SABL & 8)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    ra[slot][i][c] = *reinterpret_cast<const f32x4 *>(a_frag2[g][c] + buf * BM * LDK + MT * i * LDK);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    rb[slot][j][c] = *reinterpret_cast<const f32x4 *>(b_frag2[g][c] + buf * BN * LDK + MT * j * LDK);
+        }
+    };
+    const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));   // scalar register operand
+    auto mma_split = [&](int slot) {
+        if constexpr (AR == AR_SPLIT) {
+            // the weights arrive split (pack_split_weights: [hi x 8 | lo x 8] per 8 k = the two chunks read)
+            f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (MFTX_SABL & 1) {
+                    ah[i] = __builtin_bit_cast(f16x8, ra[slot][i][0]);
+                    al[i] = __builtin_bit_cast(f16x8, ra[slot][i][1]);
+                } else {
+                    split8(ra[slot][i][0], ra[slot][i][1], k2048, ah[i], al[i]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = __builtin_bit_cast(f16x8, rb[slot][j][0]);
+                bl[j] = __builtin_bit_cast(f16x8, rb[slot][j][1]);
+            }
+            // product by product: consecutive MFMAs never wait for each other's accumulator
+            if (MFTX_SABL & 16) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) { acc[i][j][0] += (float)ah[i][0] * (float)bh[j][0]; accx[i][j][0] += (float)al[i][0] * (float)bl[j][0]; }
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+        }
+    };
     f32x4 fa[2][TM], fb[2][TN];              // register double buffer of MFMA fragments
     auto read_frags = [&](int buf, int kk, int slot) {
         if (MFTX_ABLATE == 3) return;
@@ -469,6 +605,44 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    if constexpr (AR == AR_SPLIT) {
+        // Ring of NS chunks, slot of chunk c = c % NS (run-time index: the K loop is not unrolled over the slots).
+        // Per chunk: two 16-wide k groups; the raw fragments of the next group are read from LDS before the
+        // current group is split and multiplied; ONE barrier per chunk, taken before the last group's MFMAs --
+        // it certifies both that chunk c + 1 has landed (each lane waits for its own DMA pieces: counted vmcnt,
+        // NS - 2 younger chunks may still fly) and that every wave has read the last of chunk c, whose slot
+        // is then refilled with chunk c + NS.
+        static_assert(BM % RPP == 0 && BN % RPP == 0, "counted waits: every wave issues all RA + RB pieces of a chunk");
+        constexpr int L = RA + RB;
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+            if (i < T) fetch(i);
+        if (T >= NS) wait_vmcnt<(NS - 1) * L>(); else wait_vmcnt<0>();
+        block_barrier();
+        read_raw(0, 0, 0);
+        int slot = 0;
+        for (int c = 0; c < T; ++c) {
+            const int nslot = slot + 1 == NS ? 0 : slot + 1;
+            read_raw(slot, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_split(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < T) {
+                if (!(MFTX_SABL & 4)) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (c + NS - 1 < T) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+                    block_barrier();
+                }
+                read_raw(nslot, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_split(1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + NS < T && !(MFTX_SABL & 2)) fetch(slot);
+            __builtin_amdgcn_sched_barrier(0);
+            slot = nslot;
+        }
+    } else {
     // prologue: chunks 0 and 1 in flight, chunk 0 landed, first fragments -> slot 0
     fetch(0);
     if (T > 1) {
@@ -495,6 +669,15 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         step(1, false, false);
     } else {
         step(0, false, false);
+    }
+    }
+    if constexpr (AR == AR_SPLIT) {          // fold the cross terms in
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) acc[i][j][r] += accx[i][j][r] * (1.f / 2048.f);
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -566,10 +749,10 @@ __device__ __forceinline__ int n_virtual_tiles(const ConvArgs &p, int BM, int BN
     return 8 * (((p.M + BM - 1) / BM + 7) / 8) * ((p.N + BN - 1) / BN) * p.batch;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int MT = 32>
-__global__ __launch_bounds__(64 * WM * WN, min_waves((BM / WM / MT) * (BN / WN / MT)))
+template <int BM, int BN, int WM, int WN, int EPI, int MT = 32, int AR = AR_F32, int NS = 2>
+__global__ __launch_bounds__(64 * WM * WN, AR == AR_SPLIT ? min_waves_split((BM / WM / MT) * (BN / WN / MT), WM * WN) : min_waves((BM / WM / MT) * (BN / WN / MT)))
 void conv_gemm_kernel(ConvArgs p) {
-    conv_gemm_body<BM, BN, WM, WN, EPI, MT>(p, blockIdx.x);
+    conv_gemm_body<BM, BN, WM, WN, EPI, MT, AR, NS>(p, blockIdx.x);
 }
 
 // Two independent convolutions in one launch (the two branches of the motion encoder, convc2 and convf2):
@@ -599,11 +782,11 @@ static int num_cus() {
     return n;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int MT = 32>
+template <int BM, int BN, int WM, int WN, int EPI, int MT = 32, int AR = AR_F32, int NS = 2>
 static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat, double work = -1.0) {
-    constexpr size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+    constexpr size_t lds = (size_t)NS * (BM + BN) * LDK * sizeof(float);
     static bool attr_set = false;
-    auto kern = conv_gemm_kernel<BM, BN, WM, WN, EPI, MT>;
+    auto kern = conv_gemm_kernel<BM, BN, WM, WN, EPI, MT, AR, NS>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -631,6 +814,18 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat, 
 // the ring is fixed at two chunks, which lets the K loop be unrolled over the slots.
 template <int EPI>
 static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) {
+    if (a.arith == AR_SPLIT) {
+        switch (tile) {
+            case 0: return launch_cfg<128, 128, 2, 2, EPI, 32, AR_SPLIT, 4>(a, batch, s, cat);   // one wave per SIMD
+            case 1: return launch_cfg<128, 64, 2, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
+            case 4: return launch_cfg<64, 128, 2, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
+            case 6: return launch_cfg<128, 128, 4, 2, EPI, 32, AR_SPLIT, 4>(a, batch, s, cat);   // eight waves of 32 x 64
+            case 7: return launch_cfg<64, 128, 2, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);
+            case 8: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);
+            case 9: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
+            default: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 4>(a, batch, s, cat);
+        }
+    }
     switch (tile) {
         case 0: return launch_cfg<128, 128, 2, 2, EPI>(a, batch, s, cat);
         case 1: return launch_cfg<128, 64, 2, 2, EPI>(a, batch, s, cat);
@@ -642,9 +837,18 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
 }
 
 static int pick_tile(const ConvArgs &a, int batch) {
-    // debug/tuning override: MFTX_CONV_TILE=0..3
+    // debug/tuning override: MFTX_CONV_TILE=0..9
     static const int forced = [] { const char *e = getenv("MFTX_CONV_TILE"); return e ? atoi(e) : -1; }();
-    if (forced >= 0 && forced <= 5) return forced;
+    if (forced >= 0 && forced <= 9) return forced;
+    if (a.arith == AR_SPLIT) {
+        // Measured (tools/bench_conv.py --arith 1, M = 7 x 4096): eight waves on 128 x 128 (32 flop per byte staged)
+        // win wherever N fills whole 128-column tiles and there are enough tiles for the chip; 64 x 64
+        // otherwise (N = 64, 192, 576; one or two flow pairs per GPU).
+        const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128);
+        if (a.N % 128 != 0 && a.N % 128 <= 64) return 8;
+        if (t128 < num_cus() * 3 / 4) return 8;
+        return 6;
+    }
     // Measured on MI355X (tools/bench_conv.py, M = 7 x 4096 and 4096): the 64x64
     // tile (4 workgroups per CU) wins or ties on every layer -- 7 x 2^k rows tile
     // the 256 CUs more evenly in small tiles than bigger tiles save on operand
@@ -688,6 +892,7 @@ static int validate(const mftx_conv_desc &d) {
     if (d.lda0 % 4 || (d.c1 > 0 && d.lda1 % 4) || !aligned16(d.a0) || (d.c1 > 0 && !aligned16(d.a1)) || !aligned16(d.wpk))
         return fail(MFTX_E_ALIGN, "conv2d: operands must be 16-byte aligned");
     if (d.act < 0 || d.act > 3) return fail(MFTX_E_ARG, "conv2d: bad activation");
+    if (d.arith != AR_F32 && d.arith != AR_SPLIT) return fail(MFTX_E_ARG, "conv2d: bad arithmetic");
     const long long M = (long long)d.P * d.h * d.w;
     const long long Min = (long long)d.P * (d.hin ? d.hin : d.h) * (d.win ? d.win : d.w);
     const long long lim = 0x7fffffffLL;      // buffer offsets are 32-bit, bit 31 marks "out of range"
@@ -706,6 +911,7 @@ static ConvArgs to_args(const mftx_conv_desc &d) {
     a.cin_pad = round_up(d.c0 + d.c1, BK);
     a.w_rows = round_up(d.N, 128);
     a.act = d.act; a.out_scale = d.out_scale;
+    a.arith = d.arith;
     a.addend = d.addend; a.ld_addend = d.ld_addend; a.residual_mode = d.residual_mode;
     a.stride = d.stride ? d.stride : 1;
     a.hin = d.hin ? d.hin : d.h; a.win = d.win ? d.win : d.w;
@@ -721,7 +927,10 @@ static ConvArgs to_args(const mftx_conv_desc &d) {
 
 int launch_conv(const mftx_conv_desc &d, hipStream_t s) {
     if (int e = validate(d)) return e;
-    if (d.addend == nullptr && d.stride <= 1 && d.hin == 0 && conv_small_applicable(d)) return launch_conv_small(d, s);   // N <= 4: VALU kernel, no MFMA padding waste
+    if (d.addend == nullptr && d.stride <= 1 && d.hin == 0 && conv_small_applicable(d)) {
+        if (d.arith != AR_F32) return fail(MFTX_E_ARG, "conv2d: split arithmetic is for the matrix path (N > 4); this layer runs on the VALU kernel, with fp32 weights");
+        return launch_conv_small(d, s);
+    }   // N <= 4: VALU kernel, no MFMA padding waste
     const bool relu = d.act == 1 && d.residual_mode == 0;   // the residual tail lives in the generic epilogue
     return dispatch(to_args(d), relu ? EPI_RELU : EPI_GENERIC, 1, s, PC_CONV_GEMM);
 }
@@ -729,8 +938,8 @@ int launch_conv(const mftx_conv_desc &d, hipStream_t s) {
 int launch_conv_pair(const mftx_conv_desc &da, const mftx_conv_desc &db, hipStream_t s) {
     if (int e = validate(da)) return e;
     if (int e = validate(db)) return e;
-    if (da.act != 1 || db.act != 1 || da.residual_mode || db.residual_mode || da.N <= 32 || db.N <= 32)
-        return fail(MFTX_E_ARG, "conv pair: two ReLU convolutions with more than 32 output channels");
+    if (da.act != 1 || db.act != 1 || da.residual_mode || db.residual_mode || da.N <= 32 || db.N <= 32 || da.arith != AR_F32 || db.arith != AR_F32)
+        return fail(MFTX_E_ARG, "conv pair: two fp32-MFMA ReLU convolutions with more than 32 output channels");
     ConvArgs a = to_args(da), b = to_args(db);
     a.batch = b.batch = 1;
     constexpr int BM = 64, BN = 64;
@@ -759,6 +968,33 @@ int launch_conv_gru(const mftx_conv_desc &d, const GruEpilogue &g, hipStream_t s
     a.hx = g.hx; a.ld_hx = g.ld_hx; a.z = g.z; a.rh = g.rh;
     if ((g.mode == 1 && d.N != 256) || (g.mode == 2 && d.N != 128)) return fail(MFTX_E_ARG, "gru epilogue: bad N");
     return dispatch(a, g.mode == 1 ? EPI_GRU_ZR : EPI_GRU_Q, 1, s, PC_CONV_GEMM);
+}
+
+// Packed fp32 weights [rows][taps * cin_pad] -> the split form the AR_SPLIT kernels stream: the same index space
+// and size, every 8 consecutive k (32 bytes) holding [hi x 8 | lo x 8] as fp16, hi = fp16(w), lo = fp16((w - hi) * 2048)
+__global__ void split_weights_kernel(const float *__restrict__ in, uint4 *__restrict__ out, long long n8) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    _Float16 hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = in[i * 8 + e];
+        hi[e] = (_Float16)x;
+        lo[e] = (_Float16)((x - (float)hi[e]) * 2048.f);
+    }
+    uint4 h, l;
+    __builtin_memcpy(&h, hi, 16);
+    __builtin_memcpy(&l, lo, 16);
+    out[2 * i] = h;
+    out[2 * i + 1] = l;
+}
+
+int launch_split_weights(const float *wpk, void *out, long long n, hipStream_t s) {
+    if (n <= 0 || n % 8) return fail(MFTX_E_ARG, "split_weights: the packed weight size must be a positive multiple of 8 floats");
+    if (!aligned16(wpk) || !aligned16(out)) return fail(MFTX_E_ALIGN, "split_weights: operands must be 16-byte aligned");
+    const long long n8 = n / 8;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)cdiv(n8, 256)), dim3(256), 0, s, wpk, reinterpret_cast<uint4 *>(out), n8);
+    return check_launch("split_weights");
 }
 
 // lvl[0][p][i][.] = <f1[p][i][:], f2[p][j][:]> / sqrt(C) over all target cells j (blocked layout), and the

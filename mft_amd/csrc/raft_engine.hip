@@ -143,8 +143,13 @@ using namespace mftx;
 struct mftx_raft {
     uint32_t magic;
     int ondemand;                  // 1: on-demand correlation (no volume), see csrc/corr_ondemand.hip
+    int arith;                     // MFTX_ARITH_*: arithmetic of the update block's matrix products
     const float *w[W_COUNT];
+    const float *wg[W_COUNT];      // what the GEMM layers stream: w, or the split form of it (arith = MFTX_ARITH_SPLIT)
 };
+// weights that go through the conv GEMM (the others feed VALU kernels and stay fp32)
+static constexpr int GEMM_SLOTS[] = {W_CONVC1, W_CONVC2, W_CONVF2, W_CONV, W_ZR1_DYN, W_ZR1_INP, W_Q1_DYN, W_Q1_INP,
+                                     W_ZR2_DYN, W_ZR2_INP, W_Q2_DYN, W_Q2_INP, W_FH1, W_MASK0, W_MASK2, W_OU1};
 static constexpr uint32_t RAFT_MAGIC = 0x4d465458;  // "MFTX"
 
 extern "C" int mftx_raft_create(const float *const *weights, int n_weights, mftx_raft **out) {
@@ -158,7 +163,8 @@ extern "C" int mftx_raft_create(const float *const *weights, int n_weights, mftx
     if (!r) return fail(MFTX_E_ARG, "raft_create: out of host memory");
     r->magic = RAFT_MAGIC;
     r->ondemand = 0;
-    for (int i = 0; i < W_COUNT; ++i) r->w[i] = weights[i];
+    r->arith = MFTX_ARITH_F32;
+    for (int i = 0; i < W_COUNT; ++i) r->w[i] = r->wg[i] = weights[i];
     *out = r;
     return 0;
 }
@@ -176,6 +182,27 @@ extern "C" int mftx_raft_set_ondemand(mftx_raft *r, int on) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_ondemand: bad handle");
     r->ondemand = on ? 1 : 0;
     return 0;
+}
+
+extern "C" int mftx_raft_set_split_weights(mftx_raft *r, const void *const *split, int n) {
+    if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_split_weights: bad handle");
+    if (!split) {                                    // back to fp32 MFMA
+        for (int i = 0; i < W_COUNT; ++i) r->wg[i] = r->w[i];
+        r->arith = MFTX_ARITH_F32;
+        return 0;
+    }
+    if (n != W_COUNT) return fail(MFTX_E_ARG, "raft_set_split_weights: expected %d slots, got %d", (int)W_COUNT, n);
+    for (int slot : GEMM_SLOTS) {
+        if (!split[slot]) return fail(MFTX_E_ARG, "raft_set_split_weights: slot %d (a GEMM layer) is null", slot);
+        if (!aligned16(split[slot])) return fail(MFTX_E_ALIGN, "raft_set_split_weights: slot %d not 16-byte aligned", slot);
+    }
+    for (int slot : GEMM_SLOTS) r->wg[slot] = static_cast<const float *>(split[slot]);
+    r->arith = MFTX_ARITH_SPLIT;
+    return 0;
+}
+
+extern "C" int mftx_raft_arith(const mftx_raft *r) {
+    return (r && r->magic == RAFT_MAGIC) ? r->arith : -1;
 }
 
 extern "C" size_t mftx_raft_workspace_bytes_for(const mftx_raft *r, int P, int h, int w) {
@@ -236,6 +263,9 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     hipStream_t s = (hipStream_t)stream;
     const int N = h * w, M = P * N;
     const float *const *W = r->w;
+    const float *const *G = r->wg;          // GEMM layers: fp32 or split weights, by the handle's arithmetic
+    const int AR = r->arith;
+    auto gemm = [AR](mftx_conv_desc d) { d.arith = AR; return d; };
 
     // correlation volume + pyramid (core/corr.py:14-28)
     const float *f2lv[4] = {fmap2, ws.f2l[0], ws.f2l[1], ws.f2l[2]};
@@ -253,8 +283,8 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     // once here and enters the per-iteration GEMMs as an epilogue addend.  Same terms, summed once.
     for (int pass = 0; pass < 2; ++pass) {
         const int kh = pass ? 5 : 1, kw = pass ? 1 : 5;
-        TRY(launch_conv(conv_desc(ws.hx + 128, 384, 128, nullptr, 0, 0, W[pass ? W_ZR2_INP : W_ZR1_INP], W[pass ? B_ZR2 : B_ZR1], ws.pre_zr[pass], 256, P, h, w, 256, kh, kw, 0), s));
-        TRY(launch_conv(conv_desc(ws.hx + 128, 384, 128, nullptr, 0, 0, W[pass ? W_Q2_INP : W_Q1_INP], W[pass ? B_Q2 : B_Q1], ws.pre_q[pass], 128, P, h, w, 128, kh, kw, 0), s));
+        TRY(launch_conv(gemm(conv_desc(ws.hx + 128, 384, 128, nullptr, 0, 0, G[pass ? W_ZR2_INP : W_ZR1_INP], W[pass ? B_ZR2 : B_ZR1], ws.pre_zr[pass], 256, P, h, w, 256, kh, kw, 0)), s));
+        TRY(launch_conv(gemm(conv_desc(ws.hx + 128, 384, 128, nullptr, 0, 0, G[pass ? W_Q2_INP : W_Q1_INP], W[pass ? B_Q2 : B_Q1], ws.pre_q[pass], 128, P, h, w, 128, kh, kw, 0)), s));
     }
     const float *lv[4] = {ws.lvl[0], ws.lvl[1], ws.lvl[2], ws.lvl[3]};
     const int strips = cdiv(w, F1_CELLS);
@@ -280,26 +310,26 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
             TRY(check_launch("lookup + convf1"));
         }
         // motion encoder (core/update.py:152-160)
-        TRY(launch_conv(conv_desc(ws.corr, 324, 324, nullptr, 0, 0, W[W_CONVC1], W[B_CONVC1], ws.cor1, 256, P, h, w, 256, 1, 1, 1), s));
+        TRY(launch_conv(gemm(conv_desc(ws.corr, 324, 324, nullptr, 0, 0, G[W_CONVC1], W[B_CONVC1], ws.cor1, 256, P, h, w, 256, 1, 1, 1)), s));
         // second layers of the two branches, independent of each other: one launch (core/update.py:153,155)
         {
             static const bool nopair = getenv("MFTX_RAFT_NOPAIR") != nullptr;
-            const mftx_conv_desc c2 = conv_desc(ws.cor1, 256, 256, nullptr, 0, 0, W[W_CONVC2], W[B_CONVC2], ws.corflo, 256, P, h, w, 192, 3, 3, 1);
-            const mftx_conv_desc f2 = conv_desc(ws.flo1, 128, 128, nullptr, 0, 0, W[W_CONVF2], W[B_CONVF2], ws.corflo + 192, 256, P, h, w, 64, 3, 3, 1);
-            if (nopair) { TRY(launch_conv(c2, s)); TRY(launch_conv(f2, s)); }
+            const mftx_conv_desc c2 = gemm(conv_desc(ws.cor1, 256, 256, nullptr, 0, 0, G[W_CONVC2], W[B_CONVC2], ws.corflo, 256, P, h, w, 192, 3, 3, 1));
+            const mftx_conv_desc f2 = gemm(conv_desc(ws.flo1, 128, 128, nullptr, 0, 0, G[W_CONVF2], W[B_CONVF2], ws.corflo + 192, 256, P, h, w, 64, 3, 3, 1));
+            if (nopair || AR != MFTX_ARITH_F32) { TRY(launch_conv(c2, s)); TRY(launch_conv(f2, s)); }
             else TRY(launch_conv_pair(c2, f2, s));
         }
-        TRY(launch_conv(conv_desc(ws.corflo, 256, 256, nullptr, 0, 0, W[W_CONV], W[B_CONV], ws.hx + 256, 384, P, h, w, 126, 3, 3, 1), s));
+        TRY(launch_conv(gemm(conv_desc(ws.corflo, 256, 256, nullptr, 0, 0, G[W_CONV], W[B_CONV], ws.hx + 256, 384, P, h, w, 126, 3, 3, 1)), s));
         // SepConvGRU (core/update.py:108-123): horizontal 1x5 then vertical 5x1
         for (int pass = 0; pass < 2; ++pass) {
             const int kh = pass ? 5 : 1, kw = pass ? 1 : 5;
             GruEpilogue g1{1, ws.hx, 384, ws.z, ws.rh};
-            TRY(launch_conv_gru(conv_desc(ws.hx, 384, 128, ws.hx + 256, 384, 128, W[pass ? W_ZR2_DYN : W_ZR1_DYN], nullptr, ws.z, 128, P, h, w, 256, kh, kw, 2, 1.f, ws.pre_zr[pass], 256), g1, s));
+            TRY(launch_conv_gru(gemm(conv_desc(ws.hx, 384, 128, ws.hx + 256, 384, 128, G[pass ? W_ZR2_DYN : W_ZR1_DYN], nullptr, ws.z, 128, P, h, w, 256, kh, kw, 2, 1.f, ws.pre_zr[pass], 256)), g1, s));
             GruEpilogue g2{2, ws.hx, 384, ws.z, ws.rh};
-            TRY(launch_conv_gru(conv_desc(ws.rh, 128, 128, ws.hx + 256, 384, 128, W[pass ? W_Q2_DYN : W_Q1_DYN], nullptr, ws.hx, 384, P, h, w, 128, kh, kw, 3, 1.f, ws.pre_q[pass], 128), g2, s));
+            TRY(launch_conv_gru(gemm(conv_desc(ws.rh, 128, 128, ws.hx + 256, 384, 128, G[pass ? W_Q2_DYN : W_Q1_DYN], nullptr, ws.hx, 384, P, h, w, 128, kh, kw, 3, 1.f, ws.pre_q[pass], 128)), g2, s));
         }
         // flow head (core/update.py:6-14) and coordinate update (core/raft.py:184)
-        TRY(launch_conv(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, W[W_FH1], W[B_FH1], ws.fh, 256, P, h, w, 256, 3, 3, 1), s));
+        TRY(launch_conv(gemm(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, G[W_FH1], W[B_FH1], ws.fh, 256, P, h, w, 256, 3, 3, 1)), s));
         // last layer of the flow head, fused with coords1 += delta_flow (core/raft.py:184)
         {
             const mftx_conv_desc fh2 = conv_desc(ws.fh, 256, 256, nullptr, 0, 0, W[W_FH2], W[B_FH2], ws.delta, 2, P, h, w, 2, 3, 3, 0);
@@ -309,8 +339,8 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         if (!last) continue;
         // The upsampling mask is consumed only after the last iteration in test
         // mode (core/raft.py:190-196,234-239), so it is computed once.
-        TRY(launch_conv(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, W[W_MASK0], W[B_MASK0], ws.fh, 256, P, h, w, 256, 3, 3, 1), s));
-        TRY(launch_conv(conv_desc(ws.fh, 256, 256, nullptr, 0, 0, W[W_MASK2], W[B_MASK2], ws.mask, 576, P, h, w, 576, 1, 1, 0, 0.25f), s));
+        TRY(launch_conv(gemm(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, G[W_MASK0], W[B_MASK0], ws.fh, 256, P, h, w, 256, 3, 3, 1)), s));
+        TRY(launch_conv(gemm(conv_desc(ws.fh, 256, 256, nullptr, 0, 0, G[W_MASK2], W[B_MASK2], ws.mask, 576, P, h, w, 576, 1, 1, 0, 0.25f)), s));
         // occlusion + uncertainty heads (core/update.py:196-214)
         float *flow_lr = flow_lr_out ? flow_lr_out : ws.flow_lr;
         {
@@ -320,7 +350,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
                                ws.corr, ws.coords1, ws.delta, ws.ouin, flow_lr, M, h, w);
             TRY(check_launch("ou_gather"));
         }
-        TRY(launch_conv(conv_desc(ws.ouin, 712, 712, nullptr, 0, 0, W[W_OU1], W[B_OU1], ws.ouh, 256, P, h, w, 256, 3, 3, 1), s));
+        TRY(launch_conv(gemm(conv_desc(ws.ouin, 712, 712, nullptr, 0, 0, G[W_OU1], W[B_OU1], ws.ouh, 256, P, h, w, 256, 3, 3, 1)), s));
         TRY(launch_conv(conv_desc(ws.ouh, 256, 256, nullptr, 0, 0, W[W_OU2], W[B_OU2], ws.ou, 4, P, h, w, 3, 3, 3, 0), s));
         TRY(launch_convex_upsample(flow_lr, ws.ou, 4, ws.mask, P, h, w, pad_left, pad_right, pad_top, pad_bottom,
                                    flow, occl, sigma, packed, s));
@@ -381,6 +411,11 @@ extern "C" int mftx_corr_lookup_ondemand(const float *f1, const float *f2l0, con
         return fail(MFTX_E_ALIGN, "corr_lookup_ondemand: feature maps must be 16-byte aligned");
     const float *lv[4] = {f2l0, f2l1, f2l2, f2l3};
     return launch_corr_ondemand(f1, lv, coords, P, h, w, out, ld_out, (hipStream_t)stream);
+}
+
+extern "C" int mftx_split_weights(const float *wpk, void *out, long long n_floats, void *stream) {
+    if (!wpk || !out) return fail(MFTX_E_ARG, "split_weights: null pointer");
+    return launch_split_weights(wpk, out, n_floats, (hipStream_t)stream);
 }
 
 extern "C" int mftx_conv2d(const mftx_conv_desc *d, void *stream) {

@@ -49,6 +49,18 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     return out.contiguous()
 
 
+ARITH_F32, ARITH_SPLIT = 0, 1
+
+
+def split_weights(wpk: torch.Tensor) -> torch.Tensor:
+    """Packed fp32 conv weights -> the split-fp16 form (same shape and size) that ``conv2d(arith=ARITH_SPLIT)``
+    and the refinement engine's split arithmetic stream (csrc/conv_gemm.hip: split_weights_kernel)."""
+    lib = _lib.load()
+    out = torch.empty_like(wpk)
+    check(lib.mftx_split_weights(_chk(wpk, "wpk"), out.data_ptr(), wpk.numel(), _stream()), "mftx_split_weights")
+    return out
+
+
 def pack_raft_weights(sd: dict, device) -> list:
     """The 30 tensors ``mftx_raft_create`` expects, in WeightSlot order
     (csrc/raft_engine.hip).  z|r gates and the two OU heads are fused into single
@@ -284,9 +296,9 @@ def corr_lookup_ondemand(f1: torch.Tensor, f2_levels, coords: torch.Tensor, h: i
 
 
 def conv2d(x: torch.Tensor, wpk: torch.Tensor, bias, P, h, w, N, kh, kw, act=None, out_scale=1.0, x2=None,
-           addend=None, stride=0, hin=0, win=0, pad_y=0, pad_x=0, residual_mode=0):
+           addend=None, stride=0, hin=0, win=0, pad_y=0, pad_x=0, residual_mode=0, arith=ARITH_F32):
     """x: pixel-major [P*h*w, C0] (optionally concatenated with x2 [P*h*w, C1]) ->
-    [P*h*w, N]."""
+    [P*h*w, N].  arith = ARITH_SPLIT: wpk is the output of ``split_weights``."""
     lib = _lib.load()
     out = torch.empty(P * h * w, N, dtype=torch.float32, device=x.device)
     d = ConvDesc()
@@ -302,6 +314,7 @@ def conv2d(x: torch.Tensor, wpk: torch.Tensor, bias, P, h, w, N, kh, kw, act=Non
     d.act, d.out_scale = ACT[act], out_scale
     d.addend, d.ld_addend = (_chk(addend, "addend"), addend.shape[1]) if addend is not None else (None, 0)
     d.stride, d.hin, d.win, d.pad_y, d.pad_x, d.residual_mode = stride, hin, win, pad_y, pad_x, residual_mode
+    d.arith = arith
     check(lib.mftx_conv2d(C.byref(d), _stream()), "mftx_conv2d")
     return out
 
@@ -449,7 +462,10 @@ def dequantize_u16(q, lo, hi):
 class RaftEngine:
     """Handle on the native refinement runtime (``mftx_raft_*``)."""
 
-    def __init__(self, state_dict: dict, device, ondemand_corr=False):
+    # WeightSlot indices (csrc/raft_engine.hip) of the weights that feed GEMM layers
+    GEMM_SLOTS = (0, 2, 6, 8, 10, 11, 13, 14, 16, 17, 19, 20, 22, 26, 28, 30)
+
+    def __init__(self, state_dict: dict, device, ondemand_corr=False, arith=ARITH_SPLIT):
         lib = _lib.load()
         self.device = torch.device(device)
         self.weights = pack_raft_weights(state_dict, self.device)   # keep alive: the engine holds raw pointers
@@ -458,6 +474,13 @@ class RaftEngine:
         check(lib.mftx_raft_create(arr, len(self.weights), C.byref(handle)), "mftx_raft_create")
         self._h = handle
         self._ws = None
+        self.arith = int(arith)
+        if self.arith == ARITH_SPLIT:          # split-fp16 products: the GEMM layers stream split weights
+            self.split = [split_weights(t) if i in self.GEMM_SLOTS else None for i, t in enumerate(self.weights)]
+            sarr, self._keep_split = _lib.ptr_array([t.data_ptr() if t is not None else None for t in self.split])
+            check(lib.mftx_raft_set_split_weights(self._h, sarr, len(self.split)), "mftx_raft_set_split_weights")
+        elif self.arith != ARITH_F32:
+            raise MftxError(f"unknown arithmetic {arith!r}")
         self.ondemand_corr = bool(ondemand_corr)
         if self.ondemand_corr:                 # raft_params.alternate_corr: no stored correlation volume
             check(lib.mftx_raft_set_ondemand(self._h, 1), "mftx_raft_set_ondemand")

@@ -60,7 +60,14 @@ class RAFTWrapper:
         self.cnet_engine = ops.EncoderEngine(self.sd, "cnet", False, self.device)
         # raft_params.alternate_corr (core/raft.py:137-138): correlation on demand instead of the stored volume
         self._ondemand = bool(getattr(getattr(config, "raft_params", None), "alternate_corr", False))
-        self.engine = ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand)
+        # raft_params.arith (this package's addition, default "split"): how the update block's matrix products are
+        # formed -- "split": every fp32 operand as two fp16 halves on the fp16 matrix cores, fp32 accumulation (the
+        # products carry ~2^-23 relative error, the same grade as an fp32 multiply), "fp32": fp32 MFMA
+        arith = getattr(getattr(config, "raft_params", None), "arith", None) or "split"   # (a Config answers {} for a missing key)
+        if arith not in ("split", "fp32"):
+            raise ValueError(f"raft_params.arith must be 'split' or 'fp32', got {arith!r}")
+        self._arith = ops.ARITH_SPLIT if arith == "split" else ops.ARITH_F32
+        self.engine = ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand, arith=self._arith)
         # C.split_streams (env MFTX_SPLIT_STREAMS overrides): batches of >= 6 pairs run as that many parts on
         # separate HIP streams (see _refine_split); 1 = one stream.  Measured at 7 pairs, 512 x 512
         # (profiles/r2_split_streams.txt): 1 / 2 / 3 / 4 / 7 parts = 63.0 / 64.9 / 59.4 / 60.6 / 49.8 frames/s.
@@ -240,7 +247,7 @@ class RAFTWrapper:
         H0, W0 = geom.shape
         S = min(self._split_streams, P)
         while len(self._engines) < S:
-            self._engines.append(ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand)
+            self._engines.append(ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand, arith=self._arith)
                                  if self._engines else self.engine)
             # part 0 runs on the calling stream, the others on side streams (HIP multiplexes streams onto a handful
             # of hardware queues: every stream saved keeps the copy / encoder streams on queues of their own)

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--w", type=int, default=64)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default=None, help="substring of the layer name")
+    ap.add_argument("--arith", type=int, default=0, help="0 fp32 MFMA, 1 split fp16")
     args = ap.parse_args()
     P, h, w = args.P, args.h, args.w
     M = P * h * w
@@ -54,14 +55,16 @@ def main():
             continue
         x = torch.randn(M, cin, device=dev)
         wt = ops.pack_conv_weight(torch.randn(cout, cin, kh, kw, device=dev) * 0.05)
+        if args.arith:
+            wt = ops.split_weights(wt)
         b = torch.randn(cout, device=dev)
         for _ in range(3):
-            ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu")
+            ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu", arith=args.arith)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.reps):
-            ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu")
+            ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu", arith=args.arith)
         e1.record()
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) / args.reps * 1e-3
