@@ -49,6 +49,15 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 //             normal fp16 numbers whatever the magnitude of x.  Operands must be below 65504 in magnitude.
 enum Arith { AR_F32 = 0, AR_SPLIT = 1 };
 
+// Tuning builds only (-DMFTX_TIMING): per-phase cycle totals of the split K loop, summed over all waves
+// (s_memtime stamps; read back with mftx_debug_timing from tools/conv_phase_timing.py)
+#ifdef MFTX_TIMING
+__device__ unsigned long long mftx_dbg[16];
+#define STAMP(i) asm volatile("s_memtime %0" : "=s"(ts[i]))
+#else
+#define STAMP(i)
+#endif
+
 // hi / lo halves of 8 consecutive k of an activation row, 2.5 instructions per value: v_cvt_pk_f16_f32 for two
 // (round to nearest), the exact residual as one mixed-precision fma each (x - hi, hi read as fp16), and the scaled
 // low half as v_fma_mixlo/mixhi_f16 (r * 2048 rounded to fp16 into one half of the destination).  Written as one
@@ -118,6 +127,19 @@ struct ConvArgs {
     long long s0, s1, s2, s3;                   // floats per query cell, per level
 };
 
+// The same for two values, as the piece that is slotted between two MFMAs of the K loop (5 instructions: they issue
+// in the shadow of one 32-cycle MFMA).  No trailing wait states: the halves are consumed at least two MFMAs later.
+__device__ __forceinline__ void split_pair(float x0, float x1, float k2048, unsigned &h, unsigned &l) {
+    float r0, r1;
+    asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %3, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %2, %6, 0\n\t"
+        "v_fma_mixhi_f16 %1, %3, %6, 0"
+        : "=&v"(h), "=&v"(l), "=&v"(r0), "=&v"(r1)
+        : "v"(x0), "v"(x1), "s"(k2048));
+}
+
 // Tuning builds only (-DMFTX_ABLATE=n): 1 no global loads, 2 + no barriers, 3 + no LDS reads; 4 no W loads, 5 no A loads, 6 A loads for every fifth chunk only.  A
 // compile-time switch on purpose: as run-time branches around the ds_reads these made the compiler
 // lose count of the outstanding LDS operations and wait for ALL of them (lgkmcnt(0)) in front of
@@ -156,8 +178,9 @@ __device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, unsigned vof
 
 // 16 bytes per lane straight into LDS: the wave's 64 lanes land lane-linear at `dst` (wave-uniform);
 // an out-of-range offset stores zeros.
-__device__ __forceinline__ void buf_load_lds(__amdgpu_buffer_rsrc_t r, float *dst, unsigned voff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)dst, 16, voff, 0, 0, 0);
+// soff: wave-uniform byte offset added to the address (not part of the range check, which is on voff alone)
+__device__ __forceinline__ void buf_load_lds(__amdgpu_buffer_rsrc_t r, float *dst, unsigned voff, unsigned soff = 0) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)dst, 16, voff, soff, 0, 0);
 }
 
 // s_barrier with compiler fences on both sides (the intrinsic alone does not order LDS accesses)
@@ -179,7 +202,7 @@ __device__ __forceinline__ void wait_vmcnt() {   // counted wait: leaves N LDS-D
 #endif
 constexpr int min_waves(int wave_tiles) { return wave_tiles == 1 ? MFTX_MINW1 : wave_tiles == 2 ? 3 : 2; }
 // split arithmetic: two accumulator sets and raw + split fragments
-constexpr int min_waves_split(int wave_tiles, int waves) { return waves == 8 ? 2 : wave_tiles == 1 ? 3 : wave_tiles == 2 ? 2 : 1; }
+constexpr int min_waves_split(int wave_tiles, int waves) { return waves == 8 ? 2 : wave_tiles == 1 ? 3 : 2; }
 
 // Epilogue of the correlation-volume GEMM: one wave holds 32 query rows x one super-block (2 x 2 blocks of
 // 8 x 4 target cells, 128 columns) in acc[4].  The tile goes through the wave's private 16 KiB of LDS once:
@@ -439,22 +462,31 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         const int stop = ragged ? cpt : (seg1 ? rag_cc : (seg_cc < rag_cc ? seg_cc : rag_cc));
         left = stop - cc;
     };
-    auto fetch = [&](int buf) {              // global -> LDS (DMA) for the next chunk; then advance
-        if (left == 0) next_run();
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            if (MFTX_ABLATE != 5 && (MFTX_ABLATE != 6 || cc % 5 == 0) && (BM % RPP == 0 || wid * 8 + RPP * i < BM))
-                buf_load_lds(rA, a_dst + buf * BM * LDK + RPP * i * LDK, acur[i]);
-            acur[i] += BK * 4u;              // an OOB offset stays out of range
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
+    // global -> LDS (DMA) for the next chunk, in RA + RB pieces of 1 KiB per wave: begin (offsets of a new run),
+    // the pieces -- issued one by one between the MFMAs of the split-arithmetic loop: eight of them back to back
+    // fill the address unit's queue and hold the wave (and its MFMAs) for most of a microsecond -- and end (advance)
+    auto fetch_begin = [&]() { if (left == 0) next_run(); };
+    auto fetch_piece = [&](int buf, int k) {
+        if (k < RA) {
+            if (MFTX_ABLATE != 5 && (MFTX_ABLATE != 6 || cc % 5 == 0) && (BM % RPP == 0 || wid * 8 + RPP * k < BM))
+                buf_load_lds(rA, a_dst + buf * BM * LDK + RPP * k * LDK, acur[k]);
+            acur[k] += BK * 4u;              // an OOB offset stays out of range
+        } else {
+            const int i = k - RA;
             if (MFTX_ABLATE != 4 && (BN % RPP == 0 || wid * 8 + RPP * i < BN))
                 buf_load_lds(rW, b_dst + buf * BN * LDK + RPP * i * LDK, woff[i]);
             woff[i] += BK * 4u;
         }
+    };
+    auto fetch_end = [&]() {
         --left;
         if (++cc == cpt) { cc = 0; ++tap; }
+    };
+    auto fetch = [&](int buf) {
+        fetch_begin();
+#pragma unroll
+        for (int k = 0; k < RA + RB; ++k) fetch_piece(buf, k);
+        fetch_end();
     };
 
     typedef float acc_t __attribute__((ext_vector_type(NR)));
@@ -492,44 +524,62 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         }
     };
     const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));   // scalar register operand
-    auto mma_split = [&](int slot) {
+    // One 16-wide k group out of raw register set `set`: for every A tile of the wave 3 TN MFMAs, and -- slotted
+    // between them, pair by pair, in the shadow of the matrix pipe -- the split of the NEXT A tile: tile i + 1 of
+    // this group, or tile 0 of the next group (raw set `nset`, when `have_next`).  ah / al hold the split operands
+    // of the tile about to be multiplied (tile 0 on entry); the order is pinned with scheduling barriers.
+    f16x8 ah[AR == AR_SPLIT ? TM : 1], al[AR == AR_SPLIT ? TM : 1];
+    auto group = [&](int set, int nset, bool have_next, int refill = -1) {
         if constexpr (AR == AR_SPLIT) {
-            // the weights arrive split (pack_split_weights: [hi x 8 | lo x 8] per 8 k = the two chunks read)
-            f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+            f16x8 bh[TN], bl[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {           // the weights arrive split: [hi x 8 | lo x 8] per 8 k = the two chunks read
+                bh[j] = __builtin_bit_cast(f16x8, rb[set][j][0]);
+                bl[j] = __builtin_bit_cast(f16x8, rb[set][j][1]);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                const bool in_group = i + 1 < TM;
+                const bool do_split = (in_group || have_next) && !(MFTX_SABL & 1);
+                const f32x4 &u = in_group ? ra[set][i + 1 < TM ? i + 1 : 0][0] : ra[nset][0][0];
+                const f32x4 &v = in_group ? ra[set][i + 1 < TM ? i + 1 : 0][1] : ra[nset][0][1];
+                u32x4 nh = {0, 0, 0, 0}, nl = {0, 0, 0, 0};
+                auto piece = [&](int q) {            // pair q of the split
+                    if (do_split) {
+                        unsigned hh, ll;
+                        split_pair(q < 2 ? u[2 * q] : v[2 * q - 4], q < 2 ? u[2 * q + 1] : v[2 * q - 3], k2048, hh, ll);
+                        nh[q] = hh;
+                        nl[q] = ll;
+                    }
+                };
+                __builtin_amdgcn_sched_barrier(0);
+                // product by product (consecutive MFMAs never wait for each other's accumulator), a pair of the
+                // split behind each of the first four
+#pragma unroll
+                for (int m = 0; m < 3 * TN; ++m) {
+                    const int j = m % TN, prod = m / TN;
+                    if (prod == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    else if (prod == 1) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                    else accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m < 4) { piece(m); __builtin_amdgcn_sched_barrier(0); }
+                    if (refill >= 0 && i * 3 * TN + m < RA + RB) { fetch_piece(refill, i * 3 * TN + m); __builtin_amdgcn_sched_barrier(0); }   // one DMA piece per MFMA
+                }
+#pragma unroll
+                for (int q = 3 * TN; q < 4; ++q) piece(q);       // (TN = 1: fewer MFMAs than pairs)
+                if (i == TM - 1 && refill >= 0) {
+#pragma unroll
+                    for (int k = 3 * TN * TM; k < RA + RB; ++k) fetch_piece(refill, k);     // (fewer MFMAs than pieces)
+                }
                 if (MFTX_SABL & 1) {
-                    ah[i] = __builtin_bit_cast(f16x8, ra[slot][i][0]);
-                    al[i] = __builtin_bit_cast(f16x8, ra[slot][i][1]);
-                } else {
-                    split8(ra[slot][i][0], ra[slot][i][1], k2048, ah[i], al[i]);
+                    nh = __builtin_bit_cast(u32x4, u);
+                    nl = __builtin_bit_cast(u32x4, v);
+                }
+                if (in_group || have_next) {
+                    ah[in_group ? i + 1 : 0] = __builtin_bit_cast(f16x8, nh);
+                    al[in_group ? i + 1 : 0] = __builtin_bit_cast(f16x8, nl);
                 }
             }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bh[j] = __builtin_bit_cast(f16x8, rb[slot][j][0]);
-                bl[j] = __builtin_bit_cast(f16x8, rb[slot][j][1]);
-            }
-            // product by product: consecutive MFMAs never wait for each other's accumulator
-            if (MFTX_SABL & 16) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) { acc[i][j][0] += (float)ah[i][0] * (float)bh[j][0]; accx[i][j][0] += (float)al[i][0] * (float)bl[j][0]; }
-                return;
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
         }
     };
     f32x4 fa[2][TM], fb[2][TN];              // register double buffer of MFMA fragments
@@ -620,28 +670,61 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         if (T >= NS) wait_vmcnt<(NS - 1) * L>(); else wait_vmcnt<0>();
         block_barrier();
         read_raw(0, 0, 0);
+        if (MFTX_SABL & 1) {
+            ah[0] = __builtin_bit_cast(f16x8, ra[0][0][0]);
+            al[0] = __builtin_bit_cast(f16x8, ra[0][0][1]);
+        } else {
+            split8(ra[0][0][0], ra[0][0][1], k2048, ah[0], al[0]);      // the only split that no MFMA hides
+        }
         int slot = 0;
+#ifdef MFTX_TIMING
+        unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        STAMP(6);
+#endif
         for (int c = 0; c < T; ++c) {
             const int nslot = slot + 1 == NS ? 0 : slot + 1;
+            const bool more = c + 1 < T;
+#ifdef MFTX_TIMING
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ts[0]), "+s"(ts[1]), "+s"(ts[2]), "+s"(ts[3]), "+s"(ts[4]), "+s"(ts[5]), "+s"(ts[6]));
+            if (c > 0) {
+                tot[0] += (unsigned)(ts[1] - ts[0]); tot[1] += (unsigned)(ts[2] - ts[1]); tot[2] += (unsigned)(ts[3] - ts[2]);
+                tot[3] += (unsigned)(ts[4] - ts[3]); tot[4] += (unsigned)(ts[5] - ts[4]); tot[5] += (unsigned)(ts[6] - ts[5]);
+                tot[6] += 1;
+            }
+            ts[0] = ts[6];
+#endif
             read_raw(slot, 1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_split(0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (c + 1 < T) {
+            group(0, 1, true);
+            STAMP(1);
+            if (more) {
                 if (!(MFTX_SABL & 4)) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    STAMP(2);
                     if (c + NS - 1 < T) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+                    STAMP(3);
                     block_barrier();
+                    STAMP(4);
                 }
                 read_raw(nslot, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            mma_split(1);
+            // every wave has read the last of chunk c (the barrier above): its slot takes chunk c + NS
+            const bool refill = c + NS < T && !(MFTX_SABL & 2);
+            if (refill) fetch_begin();
+            STAMP(5);
             __builtin_amdgcn_sched_barrier(0);
-            if (c + NS < T && !(MFTX_SABL & 2)) fetch(slot);
-            __builtin_amdgcn_sched_barrier(0);
+            group(1, 0, more, refill ? slot : -1);
+            if (refill) fetch_end();
+            STAMP(6);
             slot = nslot;
         }
+#ifdef MFTX_TIMING
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) atomicAdd(&mftx_dbg[i], (unsigned long long)tot[i]);
+        }
+#endif
     } else {
     // prologue: chunks 0 and 1 in flight, chunk 0 landed, first fragments -> slot 0
     fetch(0);
@@ -816,11 +899,13 @@ template <int EPI>
 static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) {
     if (a.arith == AR_SPLIT) {
         switch (tile) {
-            case 0: return launch_cfg<128, 128, 2, 2, EPI, 32, AR_SPLIT, 4>(a, batch, s, cat);   // one wave per SIMD
+            case 0: return launch_cfg<128, 128, 2, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);   // two workgroups of four 64 x 64 waves per CU
             case 1: return launch_cfg<128, 64, 2, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
             case 4: return launch_cfg<64, 128, 2, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
             case 6: return launch_cfg<128, 128, 4, 2, EPI, 32, AR_SPLIT, 4>(a, batch, s, cat);   // eight waves of 32 x 64
             case 7: return launch_cfg<64, 128, 2, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);
+            case 10: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);  // eight waves of 64 x 64: the A tile is staged once for 256 output channels
+            case 11: return launch_cfg<256, 128, 4, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);  // eight waves of 64 x 64: the W tile is staged once for 256 cells
             case 8: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);
             case 9: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
             default: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 4>(a, batch, s, cat);
@@ -839,15 +924,21 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
 static int pick_tile(const ConvArgs &a, int batch) {
     // debug/tuning override: MFTX_CONV_TILE=0..9
     static const int forced = [] { const char *e = getenv("MFTX_CONV_TILE"); return e ? atoi(e) : -1; }();
-    if (forced >= 0 && forced <= 9) return forced;
+    if (forced >= 0 && forced <= 11) return forced;
     if (a.arith == AR_SPLIT) {
-        // Measured (tools/bench_conv.py --arith 1, M = 7 x 4096): eight waves on 128 x 128 (32 flop per byte staged)
-        // win wherever N fills whole 128-column tiles and there are enough tiles for the chip; 64 x 64
-        // otherwise (N = 64, 192, 576; one or two flow pairs per GPU).
+        // Measured (tools/bench_conv.py --arith 1, M = 7 x 4096).  The staging path (global -> LDS) is what limits
+        // these kernels, so the biggest tile that still fills the chip wins:
+        //   10: 128 x 256, eight 64 x 64 waves (A staged once for 256 output channels)   N % 256 == 0, >= 3/4 tile per CU
+        //    0: 128 x 128, four 64 x 64 waves, two workgroups per CU                     >= 1.5 tiles per CU
+        //    6: 128 x 128, eight 32 x 64 waves, one workgroup per CU                     >= 3/4 tile per CU
+        //    9:  64 x  64, four 32 x 32 waves, ring of three chunks, three workgroups per CU    small N, small M
+        const long long cus = num_cus();
         const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128);
-        if (a.N % 128 != 0 && a.N % 128 <= 64) return 8;
-        if (t128 < num_cus() * 3 / 4) return 8;
-        return 6;
+        if (a.N <= 64) return 9;
+        if (a.N % 256 == 0 && (long long)cdiv(a.M, 128) * (a.N / 256) * 4 >= cus * 3) return 10;
+        if (t128 * 2 >= cus * 3) return 0;
+        if (t128 * 4 >= cus * 3) return 6;
+        return 9;
     }
     // Measured on MI355X (tools/bench_conv.py, M = 7 x 4096 and 4096): the 64x64
     // tile (4 workgroups per CU) wins or ties on every layer -- 7 x 2^k rows tile
@@ -988,6 +1079,14 @@ __global__ void split_weights_kernel(const float *__restrict__ in, uint4 *__rest
     out[2 * i] = h;
     out[2 * i + 1] = l;
 }
+
+#ifdef MFTX_TIMING
+extern "C" int mftx_debug_timing(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mftx_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(mftx_dbg), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 int launch_split_weights(const float *wpk, void *out, long long n, hipStream_t s) {
     if (n <= 0 || n % 8) return fail(MFTX_E_ARG, "split_weights: the packed weight size must be a positive multiple of 8 floats");

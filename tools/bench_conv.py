@@ -33,6 +33,10 @@ LAYERS = [
     ("mask2  1x1 256->576", 256, 576, 1, 1, 1),
     ("ou1    3x3 712->256", 712, 256, 3, 3, 1),
     ("ou2    3x3 256->3", 256, 3, 3, 3, 1),
+    # one K chunk: the fixed cost of a launch + one round of tiles (prologue, pipeline fill, epilogue); not in the total
+    ("tiny   1x1 32->256", 32, 256, 1, 1, 0),
+    ("tiny   1x1 32->128", 32, 128, 1, 1, 0),
+    ("tiny   1x1 128->256", 128, 256, 1, 1, 0),
 ]
 
 

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Per-phase cycle totals of the split-arithmetic K loop (tuning build -DMFTX_TIMING, selected with MFTX_LIB):
+    bash tools/build_ablations.sh T ; MFTX_LIB=mft_amd/csrc/abl/libmftx_T.so python tools/conv_phase_timing.py [tile]
+phases per chunk: group 0 | wait LDS | wait DMA | barrier | LDS reads + refill issue | group 1"""
+import ctypes as C
+import os
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from mft_amd import _lib, ops  # noqa: E402
+
+lib = _lib.load()
+raw = C.CDLL(os.environ["MFTX_LIB"])
+buf = (C.c_ulonglong * 16)()
+P, h, w = 7, 64, 64
+M = P * h * w
+for name, cin, cout, kh, kw in (("gru zr 1x5 256->256", 256, 256, 1, 5), ("gru q 1x5 256->128", 256, 128, 1, 5),
+                                ("fh1 3x3 128->256", 128, 256, 3, 3), ("convc1 1x1 324->256", 324, 256, 1, 1)):
+    x = torch.randn(M, cin, device="cuda")
+    wt = ops.split_weights(ops.pack_conv_weight(torch.randn(cout, cin, kh, kw, device="cuda") * 0.05))
+    b = torch.randn(cout, device="cuda")
+    for _ in range(3):
+        ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu", arith=1)
+    torch.cuda.synchronize()
+    raw.mftx_debug_timing(buf, 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 10
+    for _ in range(reps):
+        ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu", arith=1)
+    e1.record()
+    torch.cuda.synchronize()
+    raw.mftx_debug_timing(buf, 1)
+    n = max(buf[6], 1)
+    names = ("group0", "waitLDS", "waitDMA", "barrier", "reads+refill", "group1")
+    tot = sum(buf[i] for i in range(6))
+    print(f"{name}: {e0.elapsed_time(e1) / reps * 1e3:.1f} us; per wave-chunk {tot / n:.0f} ticks (100 MHz ticks x 24 = cycles at 2.4 GHz?): "
+          + ", ".join(f"{nm} {buf[i] / n:.1f}" for i, nm in enumerate(names)))
