@@ -70,8 +70,11 @@ class RAFTWrapper:
         self.engine = ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand, arith=self._arith)
         # C.split_streams (env MFTX_SPLIT_STREAMS overrides): batches of >= 6 pairs run as that many parts on
         # separate HIP streams (see _refine_split); 1 = one stream.  Measured at 7 pairs, 512 x 512
-        # (profiles/r2_split_streams.txt): 1 / 2 / 3 / 4 / 7 parts = 63.0 / 64.9 / 59.4 / 60.6 / 49.8 frames/s.
-        self._split_streams = int(os.environ.get("MFTX_SPLIT_STREAMS", "") or getattr(config, "split_streams", 0) or 2)
+        # (profiles/r2_split_streams.txt): 1 / 2 / 3 / 4 / 7 parts = 63.0 / 64.9 / 59.4 / 60.6 / 49.8 frames/s with fp32 MFMA
+        # (64 x 64 tiles: a half batch still fills the chip); with the split arithmetic the big tiles want the whole
+        # batch: 1 / 2 parts = 104.9 / 100.6 frames/s.  Default: 1 (split), 2 (fp32).
+        self._split_streams = int(os.environ.get("MFTX_SPLIT_STREAMS", "") or getattr(config, "split_streams", 0) or
+                                  (1 if self._arith == ops.ARITH_SPLIT else 2))
         self._engines, self._side = [], []            # part k: engine (own workspace) and stream (None = caller's)
         self._frames = {}
         # Optional (C.async_encode): encode new frames on a side stream.  The encoders of frame t

@@ -267,6 +267,39 @@ def test_alternate_corr_engine_matches_default(weights_np, flower):
     assert lib.mftx_raft_workspace_bytes_for(alt.engine._h, 7, 135, 240) < lib.mftx_raft_workspace_bytes(7, 135, 240) / 2
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_fp32_mfma_arith_vs_golden_and_default(golden_dir, weights_np, flower, tag):
+    """raft_params.arith = 'fp32' (fp32 MFMA products) against the reference-generated goldens at the same
+    tolerances as the default (split-fp16 products), and the two arithmetics against each other: they differ by
+    fp32 rounding noise only (both are fp32-grade products)."""
+    from mft_amd import ops
+    from mft_amd.config import AttrDict, Config
+    from mft_amd.raft import RAFTWrapper
+    assert flower.engine.arith == ops.ARITH_SPLIT and ops._lib.load().mftx_raft_arith(flower.engine._h) == 1
+    g = np.load(golden_dir / "compute_flow.npz")
+    H, W, iters, fa, fb = (int(v) for v in g[f"{tag}_meta"])
+    c = Config()
+    c.flow_iters = iters
+    c.raft_params = AttrDict(arith="fp32")
+    f32 = RAFTWrapper(c, state_dict=weights_np)
+    assert f32.engine.arith == ops.ARITH_F32 and ops._lib.load().mftx_raft_arith(f32.engine._h) == 0
+    vid = SyntheticVideo(H, W, n_frames=8, seed=5)
+    flow, extra = f32.compute_flow(vid[fa], vid[fb], mode="flow")
+    e = epe(flow.cpu(), T(g[f"{tag}_flow"]))
+    assert e.mean() < 1e-3 and e.max() < 1e-2, float(e.mean())
+    assert (extra["occlusion"].cpu() - T(g[f"{tag}_occl"])).abs().max() < 2e-3
+    flower.C.flow_iters = iters
+    try:
+        flow_s, extra_s = flower.compute_flow(vid[fa], vid[fb], mode="flow")
+    finally:
+        flower.C.flow_iters = 12
+    d = epe(flow_s.cpu(), flow.cpu())
+    assert d.mean() < 1e-4 and d.max() < 2e-3, (float(d.mean()), float(d.max()))
+    with pytest.raises(ValueError):
+        c.raft_params = AttrDict(arith="bf16")
+        RAFTWrapper(c, state_dict=weights_np)
+
+
 def test_result_api(flower):
     from mft_amd.results import FlowOUTrackingResult, FlowOUResult
     assert FlowOUResult is FlowOUTrackingResult

@@ -179,6 +179,62 @@ def test_conv2d_vs_torch(ops_mod, cin, cout, kh, kw, act, scale, P, h, w):
     assert maxerr(got, ref) < 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+# ---------------------------------------------------------------------------
+# split-fp16 arithmetic of the conv GEMM (mftx_conv_desc.arith = MFTX_ARITH_SPLIT)
+# ---------------------------------------------------------------------------
+
+def test_split_weights_format(ops_mod):
+    """mftx_split_weights: every 8 consecutive floats -> [8 fp16 high halves | 8 fp16 low halves x 2048], and
+    hi + lo / 2048 reproduces the fp32 value to half an fp32 ulp -- also for magnitudes far from 1."""
+    g = torch.Generator().manual_seed(11)
+    w = (torch.randn(128, 5 * 64, generator=g) * torch.exp(4 * torch.randn(128, 5 * 64, generator=g))).clamp(-6e4, 6e4).to(DEV)
+    sp = ops_mod.split_weights(w)
+    assert sp.shape == w.shape and sp.dtype == torch.float32
+    halves = sp.view(torch.float16).reshape(128, -1, 2, 8)                 # per 8 k: hi x 8, lo x 8
+    hi, lo = halves[:, :, 0].float(), halves[:, :, 1].float()
+    w8 = w.reshape(128, -1, 8)
+    assert torch.equal(hi, w8.half().float())                               # hi = round-to-nearest fp16
+    assert torch.equal(lo, ((w8 - hi) * 2048).half().float())
+    rec = hi.double() + lo.double() / 2048
+    # half an fp32 ulp; below ~1e-7 the low half is itself a subnormal fp16 (spacing 2^-24 / 2048): absolute floor
+    assert bool(((rec - w8.double()).abs() <= 2.0 ** -23 * w8.double().abs() + 2.0 ** -36).all())
+
+
+@pytest.mark.parametrize("cin,cout,kh,kw,act,scale,P,h,w", [c for c in CONV_CASES if c[1] > 4])
+def test_conv2d_split_arith_vs_fp64(ops_mod, cin, cout, kh, kw, act, scale, P, h, w):
+    """The split arithmetic is an fp32-grade product: against an fp64 convolution its error is no larger than the
+    fp32-MFMA kernel's on the same data (operands spread over several decades), and both meet the fp32 tolerance
+    of test_conv2d_vs_torch."""
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(P, cin, h, w, generator=g) * torch.exp(torch.randn(P, cin, h, w, generator=g))
+    wt = torch.randn(cout, cin, kh, kw, generator=g) * (2.0 / (cin * kh * kw)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    fn = {None: lambda t: t, "relu": torch.relu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}[act]
+    ref = fn(F.conv2d(x.double(), wt.double(), b.double(), padding=(kh // 2, kw // 2))) * scale
+    xp = x.permute(0, 2, 3, 1).reshape(P * h * w, cin).contiguous().to(DEV)
+    wp = ops_mod.pack_conv_weight(wt.to(DEV))
+    err = {}
+    for name, ar, wk in (("fp32", ops_mod.ARITH_F32, wp), ("split", ops_mod.ARITH_SPLIT, ops_mod.split_weights(wp))):
+        out = ops_mod.conv2d(xp, wk, b.to(DEV), P, h, w, cout, kh, kw, act=act, out_scale=scale, arith=ar)
+        got = out.reshape(P, h, w, cout).permute(0, 3, 1, 2).cpu().double()
+        err[name] = (got - ref).abs()
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float(err["split"].max()) < tol and float(err["fp32"].max()) < tol
+    assert float(err["split"].pow(2).mean().sqrt()) <= 1.05 * float(err["fp32"].pow(2).mean().sqrt()) + 1e-12
+
+
+def test_conv2d_split_arith_errors(ops_mod):
+    from mft_amd._lib import MftxError
+    x = torch.zeros(16 * 24, 256, device=DEV)
+    w2 = ops_mod.pack_conv_weight(torch.zeros(2, 256, 3, 3, device=DEV))
+    with pytest.raises(MftxError):                      # N <= 4 runs on the VALU kernel: fp32 weights only
+        ops_mod.conv2d(x, ops_mod.split_weights(w2), None, 1, 16, 24, 2, 3, 3, arith=ops_mod.ARITH_SPLIT)
+    with pytest.raises(MftxError):
+        ops_mod.conv2d(x, ops_mod.pack_conv_weight(torch.zeros(64, 256, 3, 3, device=DEV)), None, 1, 16, 24, 64, 3, 3, arith=7)
+    with pytest.raises(MftxError):
+        ops_mod.split_weights(torch.zeros(3, 5, device=DEV))       # not a multiple of 8 floats
+
+
 def test_conv2d_two_segments(ops_mod):
     g = torch.Generator().manual_seed(5)
     P, h, w = 2, 16, 24
@@ -565,6 +621,13 @@ def test_raft_engine_argument_errors(ops_mod, weights_np):
     assert lib.mftx_raft_refine(None, 1, h, w, 2, f.data_ptr(), f.data_ptr(), n.data_ptr(), n.data_ptr(), None, 0, 0, 0, 0,
                                 out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), None, None, ws.data_ptr(),
                                 ws.numel(), None) == -4
+    # split weights: every GEMM slot must be given; NULL switches back to fp32 MFMA
+    sp, keep = _lib.ptr_array([t.data_ptr() if t is not None and i != 22 else None for i, t in enumerate(eng.split)])
+    assert lib.mftx_raft_set_split_weights(eng._h, sp, 34) == -1 and lib.mftx_raft_arith(eng._h) == 1     # slot 22 (flow head) missing: refused, mode kept
+    assert lib.mftx_raft_set_split_weights(eng._h, sp, 33) == -1
+    assert lib.mftx_raft_set_split_weights(eng._h, None, 0) == 0 and lib.mftx_raft_arith(eng._h) == 0
+    sp, keep = _lib.ptr_array([t.data_ptr() if t is not None else None for t in eng.split])
+    assert lib.mftx_raft_set_split_weights(eng._h, sp, 34) == 0 and lib.mftx_raft_arith(eng._h) == 1
     # the happy path still works after the failures
     flow, occl, sigma = eng.refine(f, f, n, n, h, w, 2)
     assert bool(torch.isfinite(flow).all()) and float(occl.min()) >= 0 and float(sigma.min()) >= 0
@@ -588,3 +651,14 @@ def test_conv_tile_shapes_bitwise(tmp_path):
         outs[tile] = np.load(f)
     for tile in (0, 1, 5):
         assert np.array_equal(outs[tile], outs[2]), tile
+    # the same for the split-arithmetic kernels: 128x128 (four and eight waves), 64x128, 64x64, 128x256, 256x128,
+    # rings of two to four chunks
+    outs = {}
+    for tile in (0, 6, 7, 9, 10, 11):
+        f = tmp_path / f"s{tile}.npy"
+        env = dict(os.environ, MFTX_CONV_TILE=str(tile), MFTX_TILE_WORKER_ARITH="1")
+        res = subprocess.run([sys.executable, str(worker), str(f)], env=env, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs[tile] = np.load(f)
+    for tile in (6, 7, 9, 10, 11):
+        assert np.array_equal(outs[tile], outs[0]), tile

@@ -9,6 +9,9 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from mft_amd import ops  # noqa: E402
 
+import os  # noqa: E402
+
+ARITH = int(os.environ.get("MFTX_TILE_WORKER_ARITH", "0"))        # 1: split-fp16 arithmetic
 g = torch.Generator().manual_seed(5)
 outs = []
 for (cin, cout, kh, kw, P, h, w, act) in [(256, 128, 1, 5, 1, 64, 64, "tanh"), (256, 126, 3, 3, 2, 33, 47, "relu"),
@@ -16,5 +19,7 @@ for (cin, cout, kh, kw, P, h, w, act) in [(256, 128, 1, 5, 1, 64, 64, "tanh"), (
     x = torch.randn(P * h * w, cin, generator=g).cuda()
     wt = ops.pack_conv_weight((torch.randn(cout, cin, kh, kw, generator=g) * 0.05).cuda())
     b = torch.randn(cout, generator=g).cuda()
-    outs.append(ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act=act).cpu().numpy().ravel())
+    if ARITH:
+        wt = ops.split_weights(wt)
+    outs.append(ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act=act, arith=ARITH).cpu().numpy().ravel())
 np.save(sys.argv[1], np.concatenate(outs))
