@@ -62,7 +62,11 @@ def run(args):
     from mft_amd.results import FlowOUTrackingResult
     results, host_results, queries = [], [], None
     drain = vio.ResultDrain()
-    for i, dev_frame in enumerate(vio.FrameRing(frames)):
+    import torch
+    up = [torch.cuda.current_stream()]                   # the streams frames are uploaded on (FrameRing's reuse guard)
+    if getattr(tracker.flower, "_enc_stream", None) is not None:
+        up.append(tracker.flower._enc_stream)
+    for i, dev_frame in enumerate(vio.FrameRing(frames, streams=up)):
         if i == 0:
             meta = tracker.init(dev_frame)
             meta.result = meta.result.cuda()

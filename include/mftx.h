@@ -181,6 +181,10 @@ int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters,
  * out1 = inp [h*w][128]; h = ceil(H0/8), w = ceil(W0/8). */
 typedef struct mftx_encoder mftx_encoder;
 int mftx_encoder_create(const float *const *weights, int n_weights, int instance_norm, mftx_encoder **out);
+/* Arithmetic of the encoder's convolutions (mftx_conv_desc.arith): split = the mftx_split_weights form of the
+ * n conv weights, in the order of mftx_encoder_create's (weight, bias) pairs -> MFTX_ARITH_SPLIT; NULL -> fp32 MFMA.
+ * The pointers are kept, not copied. */
+int mftx_encoder_set_split_weights(mftx_encoder *e, const void *const *split, int n);
 void mftx_encoder_destroy(mftx_encoder *e);
 size_t mftx_encoder_workspace_bytes(int H0, int W0);
 int mftx_encoder_forward(mftx_encoder *e, const uint8_t *img, int H0, int W0, float *out0, float *out1,

@@ -43,6 +43,7 @@ SIGNATURES = {
     "mftx_raft_set_ondemand": (C.c_int, [C.c_void_p, C.c_int]),
     "mftx_raft_workspace_bytes_for": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mftx_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "mftx_encoder_set_split_weights": (C.c_int, [C.c_void_p, _PP, C.c_int]),
     "mftx_raft_set_split_weights": (C.c_int, [C.c_void_p, _PP, C.c_int]),
     "mftx_raft_arith": (C.c_int, [C.c_void_p]),
     "mftx_split_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),

@@ -75,7 +75,8 @@ int launch_split_weights(const float *wpk, void *out, long long n_floats, hipStr
 bool conv_small_applicable(const mftx_conv_desc &d);
 int launch_conv_small(const mftx_conv_desc &d, hipStream_t s, float *accum = nullptr, int ld_accum = 0);
 // all-pairs correlation volume + its 3 pooled levels in one launch (pyramid layout above)
-int launch_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, int w, float *const lvl[4], hipStream_t s);
+int launch_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, int w, float *const lvl[4], hipStream_t s,
+                        float *f2_split = nullptr);
 int launch_corr_lookup(const float *const lvl[4], const float *coords, int P, int h, int w,
                        float *out, int ld_out, hipStream_t s);
 // on-demand correlation (csrc/corr_ondemand.hip): pooled feature pyramid + lookup without a stored volume

@@ -302,7 +302,7 @@ __device__ __forceinline__ void volume_epilogue(const ConvArgs &p, const f32x16 
 // tile choice still does not show in the results.
 template <int BM, int BN, int WM, int WN, int EPI, int MT = 32, int AR = AR_F32, int NS = 2>
 __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
-    static_assert(AR == AR_F32 || (MT == 32 && EPI != EPI_VOLUME), "split arithmetic: 32x32 tiles of the conv layers");
+    static_assert(AR == AR_F32 || MT == 32, "split arithmetic: 32x32 MFMA tiles");
     // NS: LDS ring of K chunks.  fp32 MFMA: two (a chunk is > 1000 matrix cycles per wave, deeper rings were
     // measured: no gain).  Split arithmetic: a chunk is 192 matrix cycles per MFMA tile, well below the L2 latency:
     // three or four chunks are kept in flight.
@@ -1098,7 +1098,8 @@ int launch_split_weights(const float *wpk, void *out, long long n, hipStream_t s
 
 // lvl[0][p][i][.] = <f1[p][i][:], f2[p][j][:]> / sqrt(C) over all target cells j (blocked layout), and the
 // three pooled levels, in one launch (core/corr.py:14-28, 53-69)
-int launch_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, int w, float *const lvl[4], hipStream_t s) {
+// f2_split (optional): scratch of P * h * w * C floats -> the volume GEMM runs in split arithmetic (f2 is split into it first)
+int launch_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, int w, float *const lvl[4], hipStream_t s, float *f2_split) {
     const int N = h * w;
     if ((long long)N * C * 4 > 0x7fffffffLL) return fail(MFTX_E_ARG, "corr_pyramid: feature map exceeds 2 GiB");
     const PyramidLayout L = pyramid_layout(h, w);
@@ -1115,6 +1116,12 @@ int launch_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, i
     a.lvl1 = lvl[1]; a.lvl2 = lvl[2]; a.lvl3 = lvl[3];
     a.s0 = L.stride[0]; a.s1 = L.stride[1]; a.s2 = L.stride[2]; a.s3 = L.stride[3];
     // one wave = 32 queries x one super-block (128 columns): 128 x 128 tiles of four waves stacked along M
+    if (f2_split != nullptr) {
+        if (int e = launch_split_weights(f2, f2_split, (long long)P * N * C, s)) return e;
+        a.w = f2_split;
+        a.arith = AR_SPLIT;
+        return launch_cfg<128, 128, 4, 1, EPI_VOLUME, 32, AR_SPLIT, 2>(a, P, s, PC_CORR_VOLUME, 2.0 * N * N * (double)C * P);
+    }
     return launch_cfg<128, 128, 4, 1, EPI_VOLUME>(a, P, s, PC_CORR_VOLUME, 2.0 * N * N * (double)C * P);
 }
 

@@ -186,6 +186,8 @@ struct mftx_encoder {
     uint32_t magic;
     int instance_norm;          // 1: fnet (instance norm), 0: cnet (batch norm folded into the weights)
     const float *w[EC_COUNT], *b[EC_COUNT];
+    const float *wg[EC_COUNT];  // what the conv GEMMs stream: w, or its split form (arith = MFTX_ARITH_SPLIT)
+    int arith;
 };
 static constexpr uint32_t ENC_MAGIC = 0x454e4358;
 
@@ -199,9 +201,26 @@ extern "C" int mftx_encoder_create(const float *const *weights, int n_weights, i
     if (!e) return fail(MFTX_E_ARG, "encoder_create: out of host memory");
     e->magic = ENC_MAGIC;
     e->instance_norm = instance_norm ? 1 : 0;
-    for (int i = 0; i < EC_COUNT; ++i) { e->w[i] = nullptr; e->b[i] = nullptr; }
-    for (int i = 0; i < n_conv; ++i) { e->w[i] = weights[2 * i]; e->b[i] = weights[2 * i + 1]; }
+    for (int i = 0; i < EC_COUNT; ++i) { e->w[i] = e->wg[i] = nullptr; e->b[i] = nullptr; }
+    for (int i = 0; i < n_conv; ++i) { e->w[i] = e->wg[i] = weights[2 * i]; e->b[i] = weights[2 * i + 1]; }
+    e->arith = MFTX_ARITH_F32;
     *out = e;
+    return 0;
+}
+
+extern "C" int mftx_encoder_set_split_weights(mftx_encoder *e, const void *const *split, int n) {
+    if (!e || e->magic != ENC_MAGIC) return fail(MFTX_E_STATE, "encoder_set_split_weights: bad handle");
+    const int n_conv = e->instance_norm ? EC_COUNT - 1 : EC_COUNT;
+    if (!split) {                                    // back to fp32 MFMA
+        for (int i = 0; i < n_conv; ++i) e->wg[i] = e->w[i];
+        e->arith = MFTX_ARITH_F32;
+        return 0;
+    }
+    if (n != n_conv) return fail(MFTX_E_ARG, "encoder_set_split_weights: expected %d weights, got %d", n_conv, n);
+    for (int i = 0; i < n_conv; ++i)
+        if (!split[i] || !aligned16(split[i])) return fail(MFTX_E_ALIGN, "encoder_set_split_weights: weight %d null or unaligned", i);
+    for (int i = 0; i < n_conv; ++i) e->wg[i] = static_cast<const float *>(split[i]);
+    e->arith = MFTX_ARITH_SPLIT;
     return 0;
 }
 
@@ -227,7 +246,7 @@ struct Enc {
              int w, int k, int stride, int act, const float *residual = nullptr, int w_row0 = 0) {
         mftx_conv_desc d{};
         d.a0 = in; d.lda0 = lda; d.c0 = cin;
-        d.wpk = e->w[slot]; d.bias = e->b[slot];
+        d.wpk = e->wg[slot]; d.bias = e->b[slot]; d.arith = e->arith;
         (void)w_row0;
         d.out = out; d.ldo = ldo; d.P = 1; d.h = h; d.w = w; d.N = cout; d.kh = k; d.kw = k;
         d.act = act; d.out_scale = 1.f;
@@ -305,7 +324,7 @@ extern "C" int mftx_encoder_forward(mftx_encoder *e, const uint8_t *img, int H0,
     {
         mftx_conv_desc d{};
         d.a0 = E.ws.img; d.lda0 = 4; d.c0 = 28;
-        d.wpk = e->w[EC_STEM]; d.bias = e->b[EC_STEM];
+        d.wpk = e->wg[EC_STEM]; d.bias = e->b[EC_STEM]; d.arith = e->arith;
         d.out = E.ws.a; d.ldo = 64; d.P = 1; d.h = h1; d.w = w1; d.N = 64; d.kh = 7; d.kw = 1;
         d.act = e->instance_norm ? 0 : 1; d.out_scale = 1.f;
         d.stride = 2; d.hin = Hp; d.win = Wp + 6; d.pad_y = 3; d.pad_x = -1;

@@ -101,6 +101,7 @@ struct Workspace {
     float *f2l[3];                 // on-demand correlation: the pooled second feature map, levels 1..3
     float *coords1, *corr, *cor1, *corflo, *flo1, *hx, *z, *rh, *fh, *delta, *mask, *ouin, *ouh, *ou, *flow_lr;
     float *pre_zr[2], *pre_q[2];   // inp part of the GRU gate convolutions (+ bias), per pass
+    float *f2s;                    // split form of fmap2 (B operand of the volume GEMM in split arithmetic)
     size_t bytes;
 };
 
@@ -132,6 +133,7 @@ static Workspace carve(void *base, int P, int h, int w, bool ondemand = false) {
     ws.ou = take(M * 4);
     ws.flow_lr = take(M * 2);
     for (int pass = 0; pass < 2; ++pass) { ws.pre_zr[pass] = take(M * 256); ws.pre_q[pass] = take(M * 128); }
+    ws.f2s = take(ondemand ? 0 : M * 256);
     ws.bytes = off;
     return ws;
 }
@@ -270,7 +272,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     // correlation volume + pyramid (core/corr.py:14-28)
     const float *f2lv[4] = {fmap2, ws.f2l[0], ws.f2l[1], ws.f2l[2]};
     if (ondemand) TRY(launch_fmap_pyramid(fmap2, P, 256, h, w, ws.f2l, s));   // core/corr.py:78-82 (only fmap2's pyramid is used)
-    else TRY(launch_corr_pyramid(fmap1, fmap2, P, 256, h, w, ws.lvl, s));
+    else TRY(launch_corr_pyramid(fmap1, fmap2, P, 256, h, w, ws.lvl, s, r->arith == MFTX_ARITH_SPLIT ? ws.f2s : nullptr));
     {
         const long long slots = (long long)M * 64;
         ProfScope prof(PC_GLUE, s, 0);

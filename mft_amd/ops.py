@@ -161,7 +161,7 @@ def pack_encoder_weights(sd: dict, prefix: str, batch_norm: bool, device) -> lis
 class EncoderEngine:
     """Handle on the native encoder runtime (``mftx_encoder_*``): fnet or cnet."""
 
-    def __init__(self, state_dict: dict, prefix: str, instance_norm: bool, device):
+    def __init__(self, state_dict: dict, prefix: str, instance_norm: bool, device, arith=None):
         lib = _lib.load()
         self.device = torch.device(device)
         self.instance_norm = instance_norm
@@ -172,6 +172,13 @@ class EncoderEngine:
               "mftx_encoder_create")
         self._h = handle
         self._ws = None
+        self.arith = ARITH_SPLIT if arith is None else int(arith)
+        if self.arith == ARITH_SPLIT:           # split-fp16 products: the convolutions stream split weights
+            self.split = [split_weights(t) for t in self.weights[0::2]]
+            sarr, self._keep_split = _lib.ptr_array([t.data_ptr() for t in self.split])
+            check(lib.mftx_encoder_set_split_weights(self._h, sarr, len(self.split)), "mftx_encoder_set_split_weights")
+        elif self.arith != ARITH_F32:
+            raise MftxError(f"unknown arithmetic {arith!r}")
 
     def __del__(self):
         try:

@@ -56,8 +56,6 @@ class RAFTWrapper:
         sd = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v)))
               for k, v in strip_module_prefix(state_dict).items()}
         self.sd = {k: v.to(self.device) for k, v in sd.items()}
-        self.fnet_engine = ops.EncoderEngine(self.sd, "fnet", True, self.device)
-        self.cnet_engine = ops.EncoderEngine(self.sd, "cnet", False, self.device)
         # raft_params.alternate_corr (core/raft.py:137-138): correlation on demand instead of the stored volume
         self._ondemand = bool(getattr(getattr(config, "raft_params", None), "alternate_corr", False))
         # raft_params.arith (this package's addition, default "split"): how the update block's matrix products are
@@ -67,6 +65,8 @@ class RAFTWrapper:
         if arith not in ("split", "fp32"):
             raise ValueError(f"raft_params.arith must be 'split' or 'fp32', got {arith!r}")
         self._arith = ops.ARITH_SPLIT if arith == "split" else ops.ARITH_F32
+        self.fnet_engine = ops.EncoderEngine(self.sd, "fnet", True, self.device, arith=self._arith)
+        self.cnet_engine = ops.EncoderEngine(self.sd, "cnet", False, self.device, arith=self._arith)
         self.engine = ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand, arith=self._arith)
         # C.split_streams (env MFTX_SPLIT_STREAMS overrides): batches of >= 6 pairs run as that many parts on
         # separate HIP streams (see _refine_split); 1 = one stream.  Measured at 7 pairs, 512 x 512

@@ -129,13 +129,18 @@ class FrameRing:
     full of GEMM launches and stalled the loop for a frame time, ``tools/io_paths.py``).
 
     ``keep``: how many later frames a yielded frame stays valid for (its buffer is recycled after that); the default
-    covers the tracker's memory ring (32 frames + the frames in flight).
+    covers the tracker's memory ring (32 frames + the frames in flight).  ``streams``: the HIP streams the consumer
+    uploads on (default: the stream current when the next frame is asked for; with ``C.async_encode`` pass the flow
+    plugin's ``ensure_encode_stream()``).  A buffer is only overwritten once the uploads enqueued on those streams
+    while it was the newest frame have completed -- an event recorded when the consumer comes back for the next
+    frame; in steady state it completed dozens of frames ago and the check costs nothing.
     """
 
-    def __init__(self, frames, keep=40):
+    def __init__(self, frames, keep=40, streams=None):
         self.frames = iter(frames)
         self.slots = max(2, int(keep))
-        self._pinned = []
+        self.streams = streams
+        self._pinned, self._events = [], {}
 
     def prepare(self, shape):
         """Pin all the buffers now (pinning is slow -- milliseconds each -- and otherwise happens frame by frame)."""
@@ -151,8 +156,17 @@ class FrameRing:
             buf = self._pinned[n % self.slots]
             if tuple(buf.shape) != frame.shape:
                 raise ValueError("all frames of a video must have the same size")
+            for ev in self._events.pop(n % self.slots, ()):          # uploads of the frame this buffer held before
+                ev.synchronize()
             buf.copy_(torch.from_numpy(frame))
             yield buf
+            if torch.cuda.is_available():                            # the consumer is back: its uploads of `buf` are enqueued
+                evs = []
+                for st in (self.streams or [torch.cuda.current_stream()]):
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    evs.append(ev)
+                self._events[n % self.slots] = evs
 
 
 class ResultDrain:
