@@ -776,6 +776,96 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         volume_epilogue(p, acc[0], smem + wid * 4096, lane, m0 + wm * 32, n0 / BN, bz);
         continue;
     }
+    if constexpr (AR == AR_SPLIT) {
+        // Vectorised epilogue: each 32 x 32 accumulator tile goes through 4 KiB of the wave's own LDS (the ring is
+        // free now) and comes back as four float4 per lane -- row t * 8 + (lane >> 3), columns 4 (lane & 7) .. + 3:
+        // the addend / z / h reads and the stores become 16-byte accesses, a quarter of the instructions of the
+        // C/D layout's 4-byte ones (the epilogue is issue-bound: 64 stores per 64 x 64 wave tile), same 128-byte runs
+        // per row.  Two phases per tile as below: every global read first, then arithmetic and stores.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        block_barrier();                      // every wave is done with the ring: it becomes epilogue staging
+        float *st = smem + wid * 1024;
+        const int c4 = lane & 7, rq = lane >> 3;
+        const bool pre_add = p.addend != nullptr && p.residual_mode == 0;
+        const bool any_add = pre_add || p.residual_mode == 1;
+        // (an output whose rows are not 16-byte aligned -- ldo = 126 -- is stored value by value)
+        const bool vec_out = EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q || ((p.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nb = n0 + wn * TN * 32 + j * 32 + c4 * 4;          // first of this lane's four columns
+            const bool full = nb + 3 < p.N;
+            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias != nullptr) {
+                if (full) bias4 = *reinterpret_cast<const f32x4 *>(p.bias + nb);
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bias4[e] = nb + e < p.N ? p.bias[nb + e] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                {
+                    float *w = st + (4 * (lane >> 5)) * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2)) * 32] = acc[i][j][r];
+                }
+                const int mb = m0 + wm * TM * 32 + i * 32 + rq;
+                f32x4 v[4], add[4], a0[4], a1[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    v[t] = *reinterpret_cast<const f32x4 *>(st + (t * 8 + rq) * 32 + c4 * 4);
+                    const long long m = mb + t * 8;
+                    add[t] = a0[t] = a1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (m >= p.M || nb >= p.N) continue;
+                    if (full) {
+                        if (any_add) add[t] = *reinterpret_cast<const f32x4 *>(p.addend + m * p.ld_addend + nb);
+                        if constexpr (EPI == EPI_GRU_ZR) {
+                            if (nb >= 128) a1[t] = *reinterpret_cast<const f32x4 *>(p.hx + m * p.ld_hx + (nb - 128));
+                        } else if constexpr (EPI == EPI_GRU_Q) {
+                            a0[t] = *reinterpret_cast<const f32x4 *>(p.z + m * 128 + nb);
+                            a1[t] = *reinterpret_cast<const f32x4 *>(p.hx + m * p.ld_hx + nb);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (nb + e < p.N && any_add) add[t][e] = p.addend[m * p.ld_addend + nb + e];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const long long m = mb + t * 8;
+                    if (m >= p.M || nb >= p.N) continue;
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float sv = v[t][e] + bias4[e];
+                        if (pre_add) sv += add[t][e];
+                        if constexpr (EPI == EPI_RELU) {
+                            o[e] = fmaxf(sv, 0.f) * p.out_scale;
+                        } else if constexpr (EPI == EPI_GRU_ZR) {   // [z | r] gates; r is folded into r*h
+                            const float g = fast_sigmoid(sv);
+                            o[e] = nb < 128 ? g : g * a1[t][e];
+                        } else if constexpr (EPI == EPI_GRU_Q) {    // candidate q, h <- (1-z) h + z q
+                            o[e] = (1.f - a0[t][e]) * a1[t][e] + a0[t][e] * fast_tanh(sv);
+                        } else {
+                            float g = act_fn(sv, p.act) * p.out_scale;
+                            if (p.residual_mode == 1) g = fmaxf(g + add[t][e], 0.f);
+                            o[e] = g;
+                        }
+                    }
+                    float *dst;
+                    if constexpr (EPI == EPI_GRU_ZR) dst = nb < 128 ? p.z + m * 128 + nb : p.rh + m * 128 + (nb - 128);
+                    else if constexpr (EPI == EPI_GRU_Q) dst = p.hx + m * p.ld_hx + nb;
+                    else dst = out + m * p.ldo + nb;
+                    if (full && vec_out) *reinterpret_cast<f32x4 *>(dst) = o;
+                    else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (nb + e < p.N) dst[e] = o[e];
+                }
+            }
+        }
+        continue;
+    }
     const int col_l = lane & (MT - 1);
     const int row_h = MT == 32 ? 4 * (lane >> 5) : 4 * (lane >> 4);
     auto row_of = [](int r) { return MT == 32 ? (r & 3) + 8 * (r >> 2) : r; };
@@ -984,6 +1074,8 @@ static int validate(const mftx_conv_desc &d) {
         return fail(MFTX_E_ALIGN, "conv2d: operands must be 16-byte aligned");
     if (d.act < 0 || d.act > 3) return fail(MFTX_E_ARG, "conv2d: bad activation");
     if (d.arith != AR_F32 && d.arith != AR_SPLIT) return fail(MFTX_E_ARG, "conv2d: bad arithmetic");
+    if (d.arith == AR_SPLIT && ((d.bias && !aligned16(d.bias)) || (d.addend && (d.ld_addend % 4 || !aligned16(d.addend)))))
+        return fail(MFTX_E_ALIGN, "conv2d: split arithmetic reads 16-byte pieces: bias and addend must be 16-byte aligned, the addend's row stride a multiple of 4");
     const long long M = (long long)d.P * d.h * d.w;
     const long long Min = (long long)d.P * (d.hin ? d.hin : d.h) * (d.win ? d.win : d.w);
     const long long lim = 0x7fffffffLL;      // buffer offsets are 32-bit, bit 31 marks "out of range"

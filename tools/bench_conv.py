@@ -40,6 +40,15 @@ LAYERS = [
 ]
 
 
+# encoder layers (core/extractor.py), stride-1 ones: (name, cin, cout, k, grid)
+ENC_LAYERS = [
+    ("enc l1 3x3 64->64 @256", 64, 64, 3, 256),
+    ("enc l2 3x3 96->96 @128", 96, 96, 3, 128),
+    ("enc l3 3x3 128->128 @64", 128, 128, 3, 64),
+    ("enc head 1x1 128->256 @64", 128, 256, 1, 64),
+]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--P", type=int, default=7)
@@ -48,13 +57,21 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default=None, help="substring of the layer name")
     ap.add_argument("--arith", type=int, default=0, help="0 fp32 MFMA, 1 split fp16")
+    ap.add_argument("--enc", action="store_true", help="the encoder's layer shapes (one 512 x 512 frame) instead")
     args = ap.parse_args()
     P, h, w = args.P, args.h, args.w
     M = P * h * w
     dev = "cuda"
     tot_t = tot_f = 0.0
     print(f"M = {M} cells (P={P}, {h}x{w})")
-    for name, cin, cout, kh, kw, calls in LAYERS:
+    layers = LAYERS
+    if args.enc:
+        layers = [(n, ci, co, k, k, 1, g) for n, ci, co, k, g in ENC_LAYERS]
+    for layer in layers:
+        name, cin, cout, kh, kw, calls = layer[:6]
+        if args.enc:
+            P, h, w = 1, layer[6], layer[6]
+            M = h * w
         if args.only and args.only not in name:
             continue
         x = torch.randn(M, cin, device=dev)
@@ -76,8 +93,9 @@ def main():
         tot_t += t * calls
         tot_f += fl * calls
         print(f"{name:24s} {t * 1e6:9.1f} us  {fl / t / 1e12:7.1f} TFLOP/s  ({fl / 1e9:6.2f} GFLOP)")
-    print(f"weighted per pair-batch: {tot_t * 1e3:.2f} ms, {tot_f / tot_t / 1e12:.1f} TFLOP/s "
-          f"({tot_f / tot_t / 157.3e12 * 100:.1f}% of 157.3)")
+    if tot_t > 0:
+        print(f"weighted per pair-batch: {tot_t * 1e3:.2f} ms, {tot_f / tot_t / 1e12:.1f} TFLOP/s "
+              f"({tot_f / tot_t / 157.3e12 * 100:.1f}% of 157.3)")
 
 
 if __name__ == "__main__":

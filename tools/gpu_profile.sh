@@ -13,9 +13,12 @@ BENCH="python bench.py --steps 20 --warmup 5"
 QUIET="--no-cpu-baseline --no-profile --no-parity --no-host-io --sync-encode"
 
 $BENCH > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+$BENCH --arith fp32 --no-cpu-baseline --no-host-io --no-alt-arith > $OUT/bench_fp32_arith.json 2> $OUT/bench_fp32.err; echo "bench fp32 rc=$?"
+for a in 0 1; do echo "== arithmetic $a (0 fp32 MFMA, 1 split fp16): error against an fp64 convolution"; timeout 200 python tools/conv_arith_error.py $a 2>&1 | grep -v amdgpu.ids; done > $OUT/conv_arith_error.txt
+(timeout 100 tools/micro/mfma_shadow; timeout 100 tools/micro/lds_fill) > $OUT/micro_mfma_shadow_lds_fill.txt 2>&1
 for t in bench_lookup bench_small bench_corr; do timeout 120 python tools/$t.py 2>&1 | grep -v amdgpu.ids; done > $OUT/micro.txt
 timeout 300 python tools/bench_pairs.py > $OUT/bench_pairs.txt 2>/dev/null
-MFTX_SPLIT_STREAMS=1 timeout 300 python tools/bench_conv.py --P 7 > $OUT/bench_conv_P7.txt 2>/dev/null
+(echo "== split fp16 arithmetic"; timeout 300 python tools/bench_conv.py --P 7 --arith 1; echo "== fp32 MFMA"; timeout 300 python tools/bench_conv.py --P 7 --arith 0; echo "== encoder layers, split"; timeout 100 python tools/bench_conv.py --enc --arith 1) 2>/dev/null | grep -v amdgpu.ids > $OUT/bench_conv_P7.txt
 
 MFTX_SPLIT_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof/trace -o bench -- $BENCH $QUIET > /dev/null 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
