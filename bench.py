@@ -250,13 +250,18 @@ def respawn_under_torchrun(n):
     return subprocess.run(cmd, env=env, stdout=REAL_STDOUT if REAL_STDOUT is not None else None).returncode
 
 
+HOST_MS = []          # host time of every track() call (enqueue only: nothing waits for the GPU)
+
+
 def run_frames(tracker, frames, first, count, window):
     """Track frames[first : first + count]; with `window` > 1 in look-ahead windows (multi-GPU).
     -> pairs per frame."""
     pairs = []
     if window <= 1:
         for i in range(first, first + count):
+            t0 = time.perf_counter()
             tracker.track(frames[i])
+            HOST_MS.append(1e3 * (time.perf_counter() - t0))
             pairs.append(len(tracker.last_pairs))
         return pairs
     i = first
@@ -339,8 +344,10 @@ def main():
 
     first = 1 + preroll + args.warmup
     fence()
+    del HOST_MS[:]
     t0 = time.perf_counter()
     timed_pairs = run_frames(tracker, frames, first, args.steps, window)
+    host_ms = list(HOST_MS)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -379,6 +386,7 @@ def main():
                        f"feature + FlowOU all-gather over RCCL, replicated chain/select",
                        "frames_resident_in_hbm": True, "preroll_frames": preroll,
                        "first_timed_frame": first},
+            "host_enqueue_ms_per_step": (float(np.mean(host_ms)) if host_ms else None),
             "pairs_per_frame": {"warmup": warm_pairs, "timed_min": min(timed_pairs), "timed_max": max(timed_pairs),
                                 "timed_mean": float(np.mean(timed_pairs)), "profile_pass_min": min(prof_pairs, default=None)},
             "ramp": {"frames": preroll, "fps": (preroll / t_ramp) if preroll else None,

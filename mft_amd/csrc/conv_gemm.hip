@@ -996,6 +996,7 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
             case 7: return launch_cfg<64, 128, 2, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);
             case 10: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);  // eight waves of 64 x 64: the A tile is staged once for 256 output channels
             case 11: return launch_cfg<256, 128, 4, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);  // eight waves of 64 x 64: the W tile is staged once for 256 cells
+            case 12: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);  // as 10, ring of three chunks (144 KiB)
             case 8: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);
             case 9: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
             default: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 4>(a, batch, s, cat);
@@ -1014,7 +1015,7 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
 static int pick_tile(const ConvArgs &a, int batch) {
     // debug/tuning override: MFTX_CONV_TILE=0..9
     static const int forced = [] { const char *e = getenv("MFTX_CONV_TILE"); return e ? atoi(e) : -1; }();
-    if (forced >= 0 && forced <= 11) return forced;
+    if (forced >= 0 && forced <= 12) return forced;
     if (a.arith == AR_SPLIT) {
         // Measured (tools/bench_conv.py --arith 1, M = 7 x 4096).  The staging path (global -> LDS) is what limits
         // these kernels, so the biggest tile that still fills the chip wins:

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 BENCH="python bench.py --steps 20 --warmup 5"
 # per-kernel passes: one batch, one stream, encoders on the main stream -> every kernel runs alone, like bench.py's own
 # HIP-event pass (the timed region of the default run overlaps two half-batches and the next frame's encoders)
-QUIET="--no-cpu-baseline --no-profile --no-parity --no-host-io --sync-encode"
+QUIET="--no-cpu-baseline --no-profile --no-parity --no-host-io --sync-encode --no-alt-arith"
 
 $BENCH > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 $BENCH --arith fp32 --no-cpu-baseline --no-host-io --no-alt-arith > $OUT/bench_fp32_arith.json 2> $OUT/bench_fp32.err; echo "bench fp32 rc=$?"
