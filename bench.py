@@ -133,7 +133,7 @@ def profile_pass(tracker, frames, first, steps, arith="split"):
         if i in FLOP_CATS:
             d.update(unit="TFLOP/s", achieved=work[i] / t / 1e12, peak=FP32_MFMA_PEAK_TFLOPS,
                      bound="valu" if i in VALU_CATS else "mfma", work_per_launch=work[i] / cnt[i])
-            if name == "conv_gemm" and arith == "split":
+            if name in ("conv_gemm", "corr_volume_gemm") and arith == "split":
                 # the update block's GEMMs run every fp32 product as three fp16 MFMA products: the matrix work actually
                 # executed is 3 x the algorithmic flops, priced against the fp16 MFMA peak; the algorithmic rate is kept
                 # next to it (it may exceed the fp32 MFMA peak, which this path does not use)
@@ -159,7 +159,7 @@ def profiled_traffic():
         if line.startswith("#") or "conv_gemm" not in line:
             continue
         name, launches, _fetch, fetch_x2, write = line.rsplit(",", 4)     # the kernel name contains commas
-        if "volume" in name or "<128, 128," in name or re.search(r"<\d+, \d+, \d+, \d+, 4(, \d+)?>", name):
+        if "volume" in name or re.search(r"<\d+, \d+, \d+, \d+, 4[,>]", name):
             continue                                 # the correlation volume GEMM is its own category
         tot += float(launches) * (float(fetch_x2) + float(write)) * 1e6
         n += float(launches)

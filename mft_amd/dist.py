@@ -61,10 +61,13 @@ class _NullCtx:
 
 
 class WindowSharder:
-    #: most pairs per engine call.  Per-pair time of a call (512 x 512, 12 iterations, two half-batches on two
-    #: streams): 2.08 ms at 7 pairs, 2.03 at 8, 1.99 at 14, 1.97 at 16 (the 64-row tiles of 8 k pairs divide the 256 CUs
-    #: evenly for every layer) -- a share is cut into equal batches of at most this many pairs
+    #: most pairs per engine call; a share is cut into equal batches of at most this many pairs.  fp32 MFMA (64 x 64
+    #: tiles, two half-batches on two streams): 2.08 ms per pair at 7 pairs, 2.03 at 8, 1.99 at 14, 1.97 at 16 -> 16.
+    #: Split arithmetic: the N = 256 layers run as 128 x 256 tiles, 32 per pair -- 7 or 8 pairs are one round on the 256
+    #: CUs, 10 or 11 pairs a full round and a third of one (forced-sharded bench: 88 frames/s with batches of 10 + 11,
+    #: against 105 unsharded) -> 8: shares of 21 units run as 7 + 7 + 7.
     MAX_BATCH = 16
+    MAX_BATCH_SPLIT = 8
 
     def __init__(self, group=None):
         if not dist.is_initialized():
@@ -171,7 +174,8 @@ class WindowSharder:
         # receive buffer -- no staging copies on either side
         send = torch.empty(max(slots, 1), H, W, 4, dtype=torch.float32, device=dev)
         mine = units[off: off + cnt]
-        n_batches = -(-cnt // self.MAX_BATCH) if cnt else 0
+        max_batch = self.MAX_BATCH_SPLIT if getattr(tracker.flower, "_arith", 0) == 1 else self.MAX_BATCH
+        n_batches = -(-cnt // max_batch) if cnt else 0
         bounds = [(cnt * i) // n_batches for i in range(n_batches + 1)] if cnt else [0]
         for b0, b1 in zip(bounds[:-1], bounds[1:]):
             batch = mine[b0: b1]
