@@ -1021,14 +1021,14 @@ static int pick_tile(const ConvArgs &a, int batch) {
         // these kernels, so the biggest tile that still fills the chip wins:
         //   10: 128 x 256, eight 64 x 64 waves (A staged once for 256 output channels)   N % 256 == 0, >= 3/4 tile per CU
         //    0: 128 x 128, four 64 x 64 waves, two workgroups per CU                     >= 1.5 tiles per CU
-        //    6: 128 x 128, eight 32 x 64 waves, one workgroup per CU                     >= 3/4 tile per CU
+        //    6: 128 x 128, eight 32 x 64 waves, one workgroup per CU                     3/4 .. 1 tile per CU
         //    9:  64 x  64, four 32 x 32 waves, ring of three chunks, three workgroups per CU    small N, small M
         const long long cus = num_cus();
         const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128);
         if (a.N <= 64) return 9;
         if (a.N % 256 == 0 && (long long)cdiv(a.M, 128) * (a.N / 256) * 4 >= cus * 3) return 10;
         if (t128 * 2 >= cus * 3) return 0;
-        if (t128 * 4 >= cus * 3) return 6;
+        if (t128 * 4 >= cus * 3 && t128 <= cus) return 6;     // one round only: five pairs, N = 256 (320 tiles) would take two
         return 9;
     }
     // Measured on MI355X (tools/bench_conv.py, M = 7 x 4096 and 4096): the 64x64

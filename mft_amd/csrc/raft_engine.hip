@@ -148,6 +148,9 @@ struct mftx_raft {
     int arith;                     // MFTX_ARITH_*: arithmetic of the update block's matrix products
     const float *w[W_COUNT];
     const float *wg[W_COUNT];      // what the GEMM layers stream: w, or the split form of it (arith = MFTX_ARITH_SPLIT)
+    // the motion encoder's flow branch (convf1 -> convf2) runs on a stream of its own, beside lookup -> convc1 -> convc2
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join;
 };
 // weights that go through the conv GEMM (the others feed VALU kernels and stay fp32)
 static constexpr int GEMM_SLOTS[] = {W_CONVC1, W_CONVC2, W_CONVF2, W_CONV, W_ZR1_DYN, W_ZR1_INP, W_Q1_DYN, W_Q1_INP,
@@ -166,13 +169,30 @@ extern "C" int mftx_raft_create(const float *const *weights, int n_weights, mftx
     r->magic = RAFT_MAGIC;
     r->ondemand = 0;
     r->arith = MFTX_ARITH_F32;
+    r->side = nullptr; r->ev_fork = nullptr; r->ev_join = nullptr;
     for (int i = 0; i < W_COUNT; ++i) r->w[i] = r->wg[i] = weights[i];
     *out = r;
     return 0;
 }
 
 extern "C" void mftx_raft_destroy(mftx_raft *r) {
-    if (r && r->magic == RAFT_MAGIC) { r->magic = 0; delete r; }
+    if (r && r->magic == RAFT_MAGIC) {
+        r->magic = 0;
+        if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
+        if (r->ev_join) (void)hipEventDestroy(r->ev_join);
+        if (r->side) (void)hipStreamDestroy(r->side);
+        delete r;
+    }
+}
+
+// the side stream and its two events, on first use (on the device that is current in the calling thread)
+static int ensure_side_stream(mftx_raft *r) {
+    if (r->side) return 0;
+    hipError_t e = hipStreamCreateWithFlags(&r->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_join, hipEventDisableTiming);
+    if (e != hipSuccess) return fail((int)e, "raft_refine: side stream: %s", hipGetErrorString(e));
+    return 0;
 }
 
 extern "C" size_t mftx_raft_workspace_bytes(int P, int h, int w) {
@@ -292,34 +312,55 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     const int strips = cdiv(w, F1_CELLS);
     for (int it = 0; it < iters; ++it) {
         const bool last = (it == iters - 1);
-        // correlation lookup and the first layer of the flow branch: both need only coords1 -> one launch
-        // (separately when every kernel is being timed, or with MFTX_RAFT_NOFUSE)
-        {
-            const ConvF1Args f1{ws.coords1, W[W_CONVF1], W[B_CONVF1], ws.flo1, ws.hx, h, w, strips, P * h * strips};
-            const int f1_blocks = cdiv(f1.n_strips, 2);
-            static const bool nofuse = getenv("MFTX_RAFT_NOFUSE") != nullptr;
-            if (prof_enabled() || nofuse || ondemand) {
-                if (ondemand) TRY(launch_corr_ondemand(fmap1, f2lv, ws.coords1, P, h, w, ws.corr, 324, s));
-                else TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, 324, s));
+        // The motion encoder has two independent branches (core/update.py:152-158): correlation lookup -> convc1 -> convc2
+        // and convf1 -> convf2 on the flow.  Both need only coords1.  Split arithmetic, small batches (up to four
+        // 512 x 512 pairs: the kernels leave CUs idle): the flow branch runs on the handle's SIDE STREAM beside the
+        // correlation branch and joins in front of `conv` -- 3.67 -> 3.45 ms at one pair, 5.94 -> 5.59 at four
+        // (tools/bench_pairs.py); at seven pairs every kernel fills the chip and the two stream hand-overs per iteration
+        // cost more than the overlap gives (106.7 vs 111.5 frames/s in order on one stream, 108.8 with lookup + convf1
+        // as one launch): in order on one stream.  fp32 MFMA keeps round 1's grouping (lookup + convf1 in one launch,
+        // convc2 + convf2 in one launch).  The per-kernel timing pass and MFTX_RAFT_NOFUSE run everything in order.
+        const ConvF1Args f1{ws.coords1, W[W_CONVF1], W[B_CONVF1], ws.flo1, ws.hx, h, w, strips, P * h * strips};
+        const int f1_blocks = cdiv(f1.n_strips, 2);
+        static const bool nofuse = getenv("MFTX_RAFT_NOFUSE") != nullptr;
+        static const bool nopair = getenv("MFTX_RAFT_NOPAIR") != nullptr;
+        const mftx_conv_desc c2 = gemm(conv_desc(ws.cor1, 256, 256, nullptr, 0, 0, G[W_CONVC2], W[B_CONVC2], ws.corflo, 256, P, h, w, 192, 3, 3, 1));
+        const mftx_conv_desc f2 = gemm(conv_desc(ws.flo1, 128, 128, nullptr, 0, 0, G[W_CONVF2], W[B_CONVF2], ws.corflo + 192, 256, P, h, w, 64, 3, 3, 1));
+        static const int fork_env = [] { const char *e = getenv("MFTX_RAFT_FORK"); return e ? atoi(e) : -1; }();   // tuning: 0 never, 1 always
+        const bool serial = prof_enabled() || nofuse || (AR == MFTX_ARITH_SPLIT && (fork_env == 0 || (fork_env < 0 && M > 20000)));
+        const bool forked = !serial && AR == MFTX_ARITH_SPLIT;
+        if (forked) {
+            TRY(ensure_side_stream(r));
+            if (hipEventRecord(r->ev_fork, s) != hipSuccess || hipStreamWaitEvent(r->side, r->ev_fork, 0) != hipSuccess)
+                return fail(MFTX_E_STATE, "raft_refine: fork onto the side stream failed");
+            hipLaunchKernelGGL(convf1_kernel, dim3(f1_blocks), dim3(256), 0, r->side, f1);
+            TRY(check_launch("convf1"));
+            TRY(launch_conv(f2, r->side));
+            if (hipEventRecord(r->ev_join, r->side) != hipSuccess) return fail(MFTX_E_STATE, "raft_refine: join event failed");
+        }
+        if (serial || forked || ondemand) {
+            if (ondemand) TRY(launch_corr_ondemand(fmap1, f2lv, ws.coords1, P, h, w, ws.corr, 324, s));
+            else TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, 324, s));
+            if (!forked) {
                 ProfScope prof(PC_CONVF1, s, 2.0 * M * 128 * 98);
                 hipLaunchKernelGGL(convf1_kernel, dim3(f1_blocks), dim3(256), 0, s, f1);
-            } else {
-                const LookupArgs la = make_lookup_args(lv, ws.coords1, P, h, w, ws.corr, 324);
-                const int lookup_blocks = cdiv(cdiv(la.cells, 2), LK_WAVES);
-                hipLaunchKernelGGL(lookup_convf1_kernel, dim3(lookup_blocks + f1_blocks), dim3(256), 0, s, la, f1,
-                                   lookup_blocks, f1_blocks);
             }
-            TRY(check_launch("lookup + convf1"));
+        } else {
+            const LookupArgs la = make_lookup_args(lv, ws.coords1, P, h, w, ws.corr, 324);
+            const int lookup_blocks = cdiv(cdiv(la.cells, 2), LK_WAVES);
+            hipLaunchKernelGGL(lookup_convf1_kernel, dim3(lookup_blocks + f1_blocks), dim3(256), 0, s, la, f1,
+                               lookup_blocks, f1_blocks);
         }
+        TRY(check_launch("lookup + convf1"));
         // motion encoder (core/update.py:152-160)
         TRY(launch_conv(gemm(conv_desc(ws.corr, 324, 324, nullptr, 0, 0, G[W_CONVC1], W[B_CONVC1], ws.cor1, 256, P, h, w, 256, 1, 1, 1)), s));
-        // second layers of the two branches, independent of each other: one launch (core/update.py:153,155)
-        {
-            static const bool nopair = getenv("MFTX_RAFT_NOPAIR") != nullptr;
-            const mftx_conv_desc c2 = gemm(conv_desc(ws.cor1, 256, 256, nullptr, 0, 0, G[W_CONVC2], W[B_CONVC2], ws.corflo, 256, P, h, w, 192, 3, 3, 1));
-            const mftx_conv_desc f2 = gemm(conv_desc(ws.flo1, 128, 128, nullptr, 0, 0, G[W_CONVF2], W[B_CONVF2], ws.corflo + 192, 256, P, h, w, 64, 3, 3, 1));
-            if (nopair || AR != MFTX_ARITH_F32) { TRY(launch_conv(c2, s)); TRY(launch_conv(f2, s)); }
-            else TRY(launch_conv_pair(c2, f2, s));
+        if (forked) {
+            TRY(launch_conv(c2, s));
+            if (hipStreamWaitEvent(s, r->ev_join, 0) != hipSuccess) return fail(MFTX_E_STATE, "raft_refine: join failed");
+        } else if (nopair || AR != MFTX_ARITH_F32) {
+            TRY(launch_conv(c2, s)); TRY(launch_conv(f2, s));
+        } else {
+            TRY(launch_conv_pair(c2, f2, s));      // second layers of the two branches in one launch
         }
         TRY(launch_conv(gemm(conv_desc(ws.corflo, 256, 256, nullptr, 0, 0, G[W_CONV], W[B_CONV], ws.hx + 256, 384, P, h, w, 126, 3, 3, 1)), s));
         // SepConvGRU (core/update.py:108-123): horizontal 1x5 then vertical 5x1
