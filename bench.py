@@ -264,13 +264,17 @@ def run_frames(tracker, frames, first, count, window):
             HOST_MS.append(1e3 * (time.perf_counter() - t0))
             pairs.append(len(tracker.last_pairs))
         return pairs
-    i = first
+    i, got = first, 0
     while i < first + count:
         n = min(window, first + count - i)
         nxt = frames[i + n: min(i + 2 * n, first + count)]          # the following window: its encoders start early
-        tracker.track_window(frames[i: i + n], next_imgs=nxt)
+        # pipelined: the call hands back the PREVIOUS window's results; this window's result exchange and selections
+        # overlap the next window's flow batches
+        got += len(tracker.track_window(frames[i: i + n], next_imgs=nxt, defer=True))
         pairs += [len(tracker._plan(k)) for k in range(i, i + n)]
         i += n
+    got += len(tracker.flush_window())
+    assert got == count, (got, count)
     return pairs
 
 
@@ -297,6 +301,11 @@ def main():
     ap.add_argument("--arith", choices=("split", "fp32"), default="split",
                     help="raft_params.arith: split-fp16 products on the fp16 matrix cores (default) or fp32 MFMA")
     ap.add_argument("--no-alt-arith", action="store_true", help="skip the short pass in the other arithmetic")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="with --force-sharded on ONE GPU: behave like rank 0 of this many ranks (compute only that rank's "
+                         "share of every window; the other ranks' slots of the all-gathers are filled with copies of the "
+                         "own data).  Results are meaningless; the time per window is what one rank of that world would "
+                         "spend, without the wire time of the collectives: the projected multi-GPU rate")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the multi-GPU code path (windows, RCCL all-gathers) even with one rank (testing)")
     args = ap.parse_args()
@@ -329,6 +338,20 @@ def main():
         f"pre-roll {preroll} + warm-up {args.warmup} + {args.steps} timed frames")
     tracker, conf = build_tracker(args, sharded=("force" if args.force_sharded and world == 1 else sharded))
     tracker.init(frames[0])
+    if args.emulate_world > 1:
+        if not (args.force_sharded and world == 1):
+            raise SystemExit("--emulate-world needs --force-sharded on one GPU")
+        G = args.emulate_world
+        sh = tracker.sharder
+        sh.world_size, sh.rank = G, 0
+        window = args.window if args.window > 0 else 3 * G
+
+        def fake_all_gather(recv, send, group=None, async_op=False):      # every rank's slot := this rank's data
+            recv.view(G, *send.shape).copy_(send.unsqueeze(0).expand(G, *send.shape))
+            return None
+        import mft_amd.dist as mdist
+        mdist.dist = type("FakeDist", (), {"all_gather_into_tensor": staticmethod(fake_all_gather),
+                                           "is_initialized": staticmethod(lambda: True)})
     torch.cuda.synchronize()
     t_ramp = time.perf_counter()
     ramp_pairs = run_frames(tracker, frames, 1, preroll, window)
@@ -386,6 +409,7 @@ def main():
                        f"feature + FlowOU all-gather over RCCL, replicated chain/select",
                        "frames_resident_in_hbm": True, "preroll_frames": preroll,
                        "first_timed_frame": first},
+            "emulated_world": (args.emulate_world or None),
             "host_enqueue_ms_per_step": (float(np.mean(host_ms)) if host_ms else None),
             "pairs_per_frame": {"warmup": warm_pairs, "timed_min": min(timed_pairs), "timed_max": max(timed_pairs),
                                 "timed_mean": float(np.mean(timed_pairs)), "profile_pass_min": min(prof_pairs, default=None)},

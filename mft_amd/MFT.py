@@ -136,15 +136,22 @@ class MFT():
         lefts = [self.memory[left_id]['result'].planes() for _, left_id, _ in plan]
         return self._finish_frame(frame_i, input_img, plan, lefts, rights)
 
-    def track_window(self, imgs, next_imgs=None):
+    def track_window(self, imgs, next_imgs=None, defer=False):
         """Track the next ``len(imgs)`` frames and return their metas in order.  Same results as calling
         ``track`` on each; with ``C.delta_sharding`` and several ranks the (frame, delta) flow
         computations of the whole window are sharded over the GPUs (``mft_amd/dist.py``).  ``next_imgs``
-        (optional): the frames of the window after this one, so that their encoding can start early."""
+        (optional): the frames of the window after this one, so that their encoding can start early.
+        ``defer`` (multi-GPU only; ignored otherwise): pipelined mode -- returns the metas of the window deferred by
+        the previous call ([] the first time) while this window's result exchange overlaps the next window's flow
+        batches; ``flush_window()`` returns the last one."""
         imgs = list(imgs)
         if self._sharded() and imgs:
-            return self.sharder.track_window(self, imgs, next_imgs=list(next_imgs) if next_imgs else None)
+            return self.sharder.track_window(self, imgs, next_imgs=list(next_imgs) if next_imgs else None, defer=defer)
         return [self.track(img) for img in imgs]
+
+    def flush_window(self):
+        """Metas of the window a ``track_window(..., defer=True)`` call left pending ([] if none)."""
+        return self.sharder.flush(self) if self._sharded() else []
 
     def _finish_frame(self, frame_i, input_img, plan, lefts, rights):
         """Chain every candidate onto its stored (template -> left) result, pick the best per pixel

@@ -77,6 +77,7 @@ class WindowSharder:
         self.world_size = dist.get_world_size(group)
         self.stats = {"windows": 0, "units": 0, "my_units": 0, "encoded": 0}
         self._prefetch = None          # feature exchange of the next window, started early
+        self._pending = None           # a window whose batches and all-gather are under way (track_window(defer=True))
 
     @classmethod
     def from_environment(cls):
@@ -135,15 +136,38 @@ class WindowSharder:
             tracker.flower.adopt_packed(fid, h["recv"][frame_owner(j, G), j // G], h["imgs"][j])
 
     # ------------------------------------------------------------------ the window
-    def track_window(self, tracker, imgs, next_imgs=None):
+    def track_window(self, tracker, imgs, next_imgs=None, defer=False):
         """Track ``imgs`` (the next L frames); returns their metas in order.  Identical results and
         tracker state on every rank.  ``next_imgs``: the frames of the FOLLOWING window, if known -- their
-        encoding and feature exchange are started on a side stream now and overlap this window's RAFT batches."""
+        encoding and feature exchange are started on a side stream now and overlap this window's RAFT batches.
+
+        ``defer``: pipelined mode -- this window's RAFT batches are enqueued and its FlowOU all-gather is started
+        (asynchronously), but its chain + select is left pending; what is returned are the metas of the window
+        deferred by the PREVIOUS call ([] the first time), ``flush`` hands back the last one.  The all-gather and the
+        replicated selections of window w then overlap the RAFT batches of window w + 1 instead of standing between
+        two windows' batches.  Same results, one window later."""
+        cur = self._start_window(tracker, imgs, next_imgs, async_gather=defer)
+        if not defer:
+            assert self._pending is None, "flush() the deferred window before switching to undeferred calls"
+            return self._finish_window(tracker, cur)
+        prev, self._pending = self._pending, cur
+        return self._finish_window(tracker, prev) if prev is not None else []
+
+    def flush(self, tracker):
+        """Metas of the window a ``defer`` call left pending ([] if there is none)."""
+        prev, self._pending = self._pending, None
+        return self._finish_window(tracker, prev) if prev is not None else []
+
+    def _start_window(self, tracker, imgs, next_imgs, async_gather):
         G, r = self.world_size, self.rank
         L = len(imgs)
         d = tracker.time_direction
-        frame_ids = [tracker.current_frame_i + d * (j + 1) for j in range(L)]
+        pend = self._pending
+        last_id = pend["frame_ids"][-1] if pend is not None else tracker.current_frame_i
+        frame_ids = [last_id + d * (j + 1) for j in range(L)]
         window_img = dict(zip(frame_ids, imgs))
+        if pend is not None:                       # frames of the deferred window are not in tracker.memory yet
+            window_img.update(zip(pend["frame_ids"], pend["imgs"]))
 
         def img_of(fid):
             return window_img[fid] if fid in window_img else tracker.memory[fid]['img']
@@ -154,7 +178,8 @@ class WindowSharder:
         off, cnt = shares[r]
         slots = max(c for _, c in shares)
 
-        tracker._window_ids = set(frame_ids)
+        keep = set(frame_ids) | (set(pend["frame_ids"]) if pend is not None else set())
+        tracker._window_ids = set(keep)
         pre = self._prefetch
         self._prefetch = None
         if pre is not None and pre["ids"] == frame_ids:
@@ -184,31 +209,42 @@ class WindowSharder:
                 left_id = plans[j][k][1]
                 pairs.append((left_id, img_of(left_id), frame_ids[j], imgs[j]))
             res = tracker._flows_for_pairs(pairs, packed_out=send[b0: b0 + len(batch)], planar=False)
-            for s, out in enumerate(res):
+            for s_, out in enumerate(res):
                 if len(out) < 4:                      # a plugin without packed output: interleave here
-                    send[b0 + s].copy_(torch.cat([out[0], out[1], out[2]], 0).permute(1, 2, 0))
-        recv = self._all_gather(send)                 # [G, slots, H, W, 4]
+                    send[b0 + s_].copy_(torch.cat([out[0], out[1], out[2]], 0).permute(1, 2, 0))
+        recv = torch.empty((G,) + tuple(send.shape), dtype=send.dtype, device=send.device)     # [G, slots, H, W, 4]
+        work = dist.all_gather_into_tensor(recv.view(G * send.shape[0], *send.shape[1:]), send, group=self.group,
+                                           async_op=async_gather)
         self.stats["windows"] += 1
         self.stats["units"] += len(units)
         self.stats["my_units"] += cnt
+        return dict(frame_ids=frame_ids, imgs=list(imgs), plans=plans, shares=shares, send=send, recv=recv,
+                    work=work if async_gather else None)
 
+    def _finish_window(self, tracker, w):
+        """Replicated chain + select of a started window, frame by frame -> its metas."""
+        if w["work"] is not None:
+            w["work"].wait()                          # the caller's stream waits for the collective (no host wait)
+        frame_ids, imgs, plans, recv = w["frame_ids"], w["imgs"], w["plans"], w["recv"]
         owner_slot = {}
-        for rr, (o, c) in enumerate(shares):
-            for s in range(c):
-                owner_slot[o + s] = (rr, s)
-
-        # ---- replicated chain + select, frame by frame
+        for rr, (o, c) in enumerate(w["shares"]):
+            for s_ in range(c):
+                owner_slot[o + s_] = (rr, s_)
+        later = set(self._pending["frame_ids"]) if self._pending is not None else set()
+        if self._prefetch is not None:
+            later |= set(self._prefetch["ids"])
         metas, u = [], 0
+        L = len(frame_ids)
         for j, fid in enumerate(frame_ids):
             plan = plans[j]
             lefts, rights = [], []
             for k in range(len(plan)):
-                rr, s = owner_slot[u]
+                rr, s_ = owner_slot[u]
                 u += 1
-                rights.append(recv[rr, s])            # packed [H, W, 4]
+                rights.append(recv[rr, s_])            # packed [H, W, 4]
                 lefts.append(tracker.memory[plan[k][1]]['result'].planes())
-            if j == L - 1:                             # (a prefetched next window's features stay until it is tracked)
-                tracker._window_ids = set(self._prefetch["ids"]) if self._prefetch is not None else set()
+            # features stay for: the rest of this window, a window already started behind it, a prefetched one
+            tracker._window_ids = set(frame_ids[j + 1:]) | later
             metas.append(tracker._finish_frame(fid, imgs[j], plan, lefts, rights))
         return metas
 

@@ -49,22 +49,37 @@ class ExchangingFlower:
         return out
 
 
-def run(sharded, window, flower, prefetch=False):
+def run(sharded, window, flower, prefetch=False, defer=False):
     tr = make_tracker(flower, delta_sharding=sharded)
     tr.init(gi.id_image(0))
-    out, i = {}, 1
+    out, i, done = {}, 1, 1            # done: index of the next frame whose meta has not come back yet
+
+    def record(metas):
+        nonlocal done
+        for m in metas:
+            res = m.result
+            out[f"flow{done}"] = res.flow.numpy()
+            out[f"occl{done}"] = res.occlusion.numpy()
+            out[f"sigma{done}"] = res.sigma.numpy()
+            done += 1
+
     while i < N_FRAMES:
         imgs = [gi.id_image(k) for k in range(i, min(i + window, N_FRAMES))]
         nxt = [gi.id_image(k) for k in range(i + window, min(i + 2 * window, N_FRAMES))] if prefetch else None
-        metas = tr.track_window(imgs, next_imgs=nxt) if window > 1 else [tr.track(imgs[0])]
-        for k, m in enumerate(metas):
-            res = m.result
-            out[f"flow{i + k}"] = res.flow.numpy()
-            out[f"occl{i + k}"] = res.occlusion.numpy()
-            out[f"sigma{i + k}"] = res.sigma.numpy()
-        out[f"chosen{i + len(imgs) - 1}"] = tr.last_chosen.numpy()
-        out[f"keys{i + len(imgs) - 1}"] = np.array(sorted(tr.memory.keys()))
+        if window > 1:
+            metas = tr.track_window(imgs, next_imgs=nxt, defer=defer)       # defer: the PREVIOUS window's metas
+            assert len(metas) == (len(imgs) if not defer else (0 if i == 1 else window))
+        else:
+            metas = [tr.track(imgs[0])]
+        record(metas)
         i += len(imgs)
+        if not defer:
+            out[f"chosen{i - 1}"] = tr.last_chosen.numpy()
+            out[f"keys{i - 1}"] = np.array(sorted(tr.memory.keys()))
+    if defer:
+        record(tr.flush_window())
+        assert tr.flush_window() == []
+    assert done == N_FRAMES
     return out, tr
 
 
@@ -75,10 +90,11 @@ if __name__ == "__main__":
     rank = dist.get_rank()
     wx = max(5, dist.get_world_size())       # the feature exchange needs at least one frame per rank in a window
     for mode, window, mk in (("L1", 1, StubFlower), ("L8", 8, StubFlower), ("L5x", wx, ExchangingFlower),
-                             ("L5p", wx, ExchangingFlower)):
+                             ("L5p", wx, ExchangingFlower), ("L5d", wx, ExchangingFlower)):
         fl = mk()
-        res, tr = run(True, window, fl, prefetch=(mode == "L5p"))      # L5p: next window's features exchanged early
-        if mode in ("L5x", "L5p"):
+        # L5p: next window's features exchanged early; L5d: that, and every window's results one call late (pipelined)
+        res, tr = run(True, window, fl, prefetch=(mode in ("L5p", "L5d")), defer=(mode == "L5d"))
+        if mode in ("L5x", "L5p", "L5d"):
             st = tr.sharder.stats
             res.update(_encoded=np.array(fl.encoded), _local=np.array(fl.local), _frames=np.array(N_FRAMES - 1), _my_units=np.array(st["my_units"]),
                        _windows=np.array(st["windows"]))

@@ -20,7 +20,7 @@ from mft_amd.weights import make_weights  # noqa: E402
 N_FRAMES = 14
 
 
-def run(flower, sharding, window, prefetch=False):
+def run(flower, sharding, window, prefetch=False, defer=False):
     c = Config()
     c.deltas = [np.inf, 1, 2, 4, 8]
     c.occlusion_threshold = 0.02
@@ -30,16 +30,24 @@ def run(flower, sharding, window, prefetch=False):
     tr = MFT(c)
     vid = SyntheticVideo(128, 160, n_frames=N_FRAMES, seed=4)
     tr.init(vid[0])
-    out, i = {}, 1
+    out, i, done = {}, 1, 1
+
+    def record(metas):
+        nonlocal done
+        for m in metas:
+            res = m.result
+            out[f"flow{done}"], out[f"occl{done}"], out[f"sigma{done}"] = \
+                res.flow.numpy(), res.occlusion.numpy(), res.sigma.numpy()
+            done += 1
+
     while i < N_FRAMES:
         imgs = [vid[k] for k in range(i, min(i + window, N_FRAMES))]
         nxt = [vid[k] for k in range(i + window, min(i + 2 * window, N_FRAMES))] if prefetch else None
-        metas = tr.track_window(imgs, next_imgs=nxt) if window > 1 else [tr.track(imgs[0])]
-        for k, m in enumerate(metas):
-            res = m.result
-            out[f"flow{i + k}"], out[f"occl{i + k}"], out[f"sigma{i + k}"] = \
-                res.flow.numpy(), res.occlusion.numpy(), res.sigma.numpy()
+        record(tr.track_window(imgs, next_imgs=nxt, defer=defer) if window > 1 else [tr.track(imgs[0])])
         i += len(imgs)
+    if defer:
+        record(tr.flush_window())
+    assert done == N_FRAMES
     out["final_chosen"] = tr.last_chosen.cpu().numpy()
     out["final_keys"] = np.array(sorted(tr.memory.keys()))
     return out, tr
@@ -55,8 +63,9 @@ if __name__ == "__main__":
     flower = RAFTWrapper(fc, state_dict=make_weights(7))
     rank, world = dist.get_rank(), dist.get_world_size()
     sharding = "force" if world == 1 else True
-    for mode, window in (("L1", 1), ("L6", 6), ("L6p", 6)):
-        res, tr = run(flower, sharding, window, prefetch=(mode == "L6p"))   # L6p: next window's encoders + exchange on a side stream
+    for mode, window in (("L1", 1), ("L6", 6), ("L6p", 6), ("L6d", 6)):
+        # L6p: next window's encoders + exchange on a side stream; L6d: that, pipelined (results one window late)
+        res, tr = run(flower, sharding, window, prefetch=(mode in ("L6p", "L6d")), defer=(mode == "L6d"))
         res["_encoded"] = np.array(tr.sharder.stats["encoded"])
         np.savez(outdir / f"rank{rank}_{mode}.npz", **res)
     if rank == 0:

@@ -25,14 +25,14 @@ def test_window_sharding_rccl_bitwise(tmp_path):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=550)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     single = np.load(tmp_path / "single.npz")
-    for mode in ("L1", "L6", "L6p"):
+    for mode in ("L1", "L6", "L6p", "L6d"):
         enc = 0
         for r in range(n):
             got = np.load(tmp_path / f"rank{r}_{mode}.npz")
             enc += int(got["_encoded"])
             for k in single.files:
                 assert np.array_equal(got[k], single[k]), (mode, r, k)
-        if mode in ("L6", "L6p") and n <= 6:
+        if mode in ("L6", "L6p", "L6d") and n <= 6:
             # every exchanged frame is encoded exactly once across the ranks (the ragged last window of one
             # frame is shorter than the world size when n > 1: every rank encodes it itself)
             assert enc == (13 if n == 1 else 12), enc

@@ -292,9 +292,10 @@ def test_shard_plan():
 @pytest.mark.parametrize("world", [2, 4])
 def test_window_sharding_gloo(tmp_path, world):
     """World size 2 and 4 over gloo: the per-frame mode (L = 1; at world 4 some ranks own no unit of a
-    frame), look-ahead windows (L = 8, ragged last window) and the feature-exchanging path (L = 5) all
-    reproduce the single-rank tracker bit for bit, on every rank; with exchanged features no rank
-    encodes a frame another rank owns."""
+    frame), look-ahead windows (L = 8, ragged last window), the feature-exchanging path (L = 5, also with the
+    next window's exchange started early) and the pipelined mode (results one window late: the all-gather
+    and the selections of a window overlap the next window's batches) all reproduce the single-rank
+    tracker bit for bit, on every rank; with exchanged features no rank encodes a frame another rank owns."""
     script = REPO / "tests" / "dist_worker.py"
     port = str(29609 + world)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
@@ -305,12 +306,12 @@ def test_window_sharding_gloo(tmp_path, world):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     single = np.load(out / "single.npz")
-    for mode in ("L1", "L8", "L5x", "L5p"):
+    for mode in ("L1", "L8", "L5x", "L5p", "L5d"):
         rk = [np.load(out / f"rank{r}_{mode}.npz") for r in range(world)]
         for k in single.files:
             for r in range(world):                                      # replicas stay identical, and equal to the unsharded run
                 assert np.array_equal(rk[r][k], single[k]), (mode, r, k)
-    for mode in ("L5x", "L5p"):
+    for mode in ("L5x", "L5p", "L5d"):
         st = [np.load(out / f"rank{r}_{mode}.npz") for r in range(world)]
         # every window frame was encoded exactly once across the ranks (also when the next window's exchange is
         # started early, L5p), none outside the exchange
