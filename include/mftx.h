@@ -124,6 +124,11 @@ typedef struct mftx_conv_desc {
      * <= ~2^-23 relative: the same grade as fp32) -- wpk must then be the output of
      * mftx_split_weights, and all operands below 65504 in magnitude. */
     int arith;
+    /* MFTX_ARITH_SPLIT only.  a_split: the A operand(s) are already stored in split form -- every 8 consecutive channels
+     * of a row as 32 bytes [hi x 8 | lo x 8] of fp16 (same size and row stride as fp32; c0, c1, lda0, lda1 multiples of 8,
+     * rows 32-byte aligned) -- as written by a producer with out_split = 1: the kernel then spends no instruction on
+     * splitting.  out_split: write the output in that form (ldo a multiple of 8). */
+    int a_split, out_split;
 } mftx_conv_desc;
 #define MFTX_ARITH_F32 0
 #define MFTX_ARITH_SPLIT 1

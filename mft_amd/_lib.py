@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
                 ("act", C.c_int), ("out_scale", C.c_float),
                 ("addend", C.c_void_p), ("ld_addend", C.c_int),
                 ("stride", C.c_int), ("hin", C.c_int), ("win", C.c_int), ("pad_y", C.c_int), ("pad_x", C.c_int),
-                ("residual_mode", C.c_int), ("arith", C.c_int)]
+                ("residual_mode", C.c_int), ("arith", C.c_int), ("a_split", C.c_int), ("out_split", C.c_int)]
 
 
 _PP = C.POINTER(C.c_void_p)

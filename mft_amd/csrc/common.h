@@ -60,6 +60,10 @@ inline PyramidLayout pyramid_layout(int h, int w) {
 }
 
 // ---- kernel launchers shared between the per-op exports and the RAFT engine
+// SPLIT storage of an fp32 tensor row (the A operands of the split-arithmetic GEMMs, written that way by their
+// producers): every 8 consecutive channels are 32 bytes [hi x 8 | lo x 8] of fp16, hi = fp16(x), lo = fp16((x - hi) * 2048)
+// -- same size, same row stride, channel c at byte split_row_offset(c) (its low half 16 bytes further).
+__host__ __device__ inline int split_row_offset(int c) { return (c >> 3) * 32 + (c & 7) * 2; }
 int launch_conv(const mftx_conv_desc &d, hipStream_t s);
 int launch_conv_pair(const mftx_conv_desc &a, const mftx_conv_desc &b, hipStream_t s);   // two independent ReLU convs, one launch
 // conv whose epilogue is a GRU gate (see conv_gemm.hip)
@@ -69,6 +73,10 @@ struct GruEpilogue {
     int ld_hx;
     float *z;          // [M][128]
     float *rh;         // [M][128]
+    // split arithmetic with split-form activations (mftx_conv_desc.out_split): hx and rh are written in split form, and
+    // the gate algebra reads / writes this fp32 copy of h instead ([M][ld_hf]); null: h lives in hx as fp32
+    float *hf = nullptr;
+    int ld_hf = 0;
 };
 int launch_conv_gru(const mftx_conv_desc &d, const GruEpilogue &g, hipStream_t s);
 int launch_split_weights(const float *wpk, void *out, long long n_floats, hipStream_t s);

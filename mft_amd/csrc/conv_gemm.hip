@@ -47,7 +47,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 //             v_mfma_f32_32x32x16_f16 (2.5 PF peak, fp32 accumulation; each fp16 product is exact in fp32).
 //             The cross terms have their own accumulator, scaled once in the epilogue: the lo halves stay
 //             normal fp16 numbers whatever the magnitude of x.  Operands must be below 65504 in magnitude.
-enum Arith { AR_F32 = 0, AR_SPLIT = 1 };
+//   AR_PRESPLIT: the same products, with the A operand ALREADY stored in split form by its producer (every 8 channels as
+//             [hi x 8 | lo x 8], the layout of the split weights): no VALU work in the K loop at all.  Internal to
+//             the refinement engine (mftx_conv_desc.arith = MFTX_ARITH_SPLIT + a_split).
+enum Arith { AR_F32 = 0, AR_SPLIT = 1, AR_PRESPLIT = 2 };
 
 // Tuning builds only (-DMFTX_TIMING): per-phase cycle totals of the split K loop, summed over all waves
 // (s_memtime stamps; read back with mftx_debug_timing from tools/conv_phase_timing.py)
@@ -116,11 +119,14 @@ struct ConvArgs {
     int w_rows;               // valid rows of the W operand
     int act;
     int arith;                // Arith
+    int a_pre;                // split arithmetic: both A segments are stored in split form (-> AR_PRESPLIT kernels)
     float out_scale;
     int batch;                                  // correlation volume: one GEMM per pair
     long long a_bstride, w_bstride, o_bstride;  // per batch element
     unsigned a0_bytes, a1_bytes, w_bytes;       // buffer extents (per batch element)
     float *hx; int ld_hx; float *z; float *rh;  // GRU epilogues
+    float *hf; int ld_hf;                       // split arithmetic: the fp32 copy of h the gate algebra reads and writes (hx itself may be in split form)
+    int out_split;                              // outputs that feed GEMMs (out, rh, hx) are written in split form
     // EPI_VOLUME only: feature grid and the pooled levels (pyramid layout of common.h; out = level 0)
     int vh, vw, sbw, wb0;
     float *lvl1, *lvl2, *lvl3;
@@ -138,6 +144,29 @@ __device__ __forceinline__ void split_pair(float x0, float x1, float k2048, unsi
         "v_fma_mixhi_f16 %1, %3, %6, 0"
         : "=&v"(h), "=&v"(l), "=&v"(r0), "=&v"(r1)
         : "v"(x0), "v"(x1), "s"(k2048));
+}
+
+// Four consecutive channels nb .. nb + 3 (nb % 4 == 0) of a SPLIT-format row: their fp16 high halves are 8 bytes at
+// group (nb >> 3), half ((nb >> 2) & 1); the low halves 16 bytes further (common.h: split_row_offset)
+__device__ __forceinline__ void store_split4(float *row, int nb, const f32x4 &o, int valid = 4) {
+    unsigned h0, h1, l0, l1;
+    const float k2048 = 2048.f;
+    split_pair(o[0], o[1], k2048, h0, l0);
+    split_pair(o[2], o[3], k2048, h1, l1);
+    char *dst = reinterpret_cast<char *>(row) + split_row_offset(nb);
+    if (valid >= 4) {
+        *reinterpret_cast<uint2 *>(dst) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(dst + 16) = make_uint2(l0, l1);
+    } else {                                         // N tail: the other channels of the group belong to someone else
+        const unsigned short hs[4] = {(unsigned short)h0, (unsigned short)(h0 >> 16), (unsigned short)h1, (unsigned short)(h1 >> 16)};
+        const unsigned short ls[4] = {(unsigned short)l0, (unsigned short)(l0 >> 16), (unsigned short)l1, (unsigned short)(l1 >> 16)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < valid) {
+                reinterpret_cast<unsigned short *>(dst)[e] = hs[e];
+                reinterpret_cast<unsigned short *>(dst + 16)[e] = ls[e];
+            }
+    }
 }
 
 // Tuning builds only (-DMFTX_ABLATE=n): 1 no global loads, 2 + no barriers, 3 + no LDS reads; 4 no W loads, 5 no A loads, 6 A loads for every fifth chunk only.  A
@@ -306,7 +335,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
     // NS: LDS ring of K chunks.  fp32 MFMA: two (a chunk is > 1000 matrix cycles per wave, deeper rings were
     // measured: no gain).  Split arithmetic: a chunk is 192 matrix cycles per MFMA tile, well below the L2 latency:
     // three or four chunks are kept in flight.
-    static_assert(AR == AR_SPLIT || NS == 2, "ring depth");
+    static_assert(AR != AR_F32 || NS == 2, "ring depth");
+    constexpr bool SPLIT = AR != AR_F32;          // split arithmetic, A split in registers (AR_SPLIT) or by its producer (AR_PRESPLIT)
+    constexpr bool PRE = AR == AR_PRESPLIT;
     constexpr int TM = BM / WM / MT, TN = BN / WN / MT;
     constexpr int NR = MT == 32 ? 16 : 4;       // accumulator registers per MFMA tile
     constexpr int RPP = 8 * WM * WN;            // rows staged per pass: 8 per wave (one 1 KiB LDS-DMA)
@@ -454,7 +485,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         const bool ragged = cc >= rag_cc;
         const unsigned lda = (unsigned)(seg1 ? p.lda1 : p.lda0);
         const unsigned cb = (unsigned)(cc * BK - (seg1 ? p.c0 : 0)) * 4u;
-        const bool lane_ok = !ragged || cc * BK + col4 < ctot;     // ragged chunk: zero-fill beyond the last channel
+        // ragged chunk: zero-fill beyond the last channel (pre-split A: a 16-byte piece holds one half of 8 channels)
+        const bool lane_ok = !ragged || cc * BK + (PRE ? (col4 & ~7) : col4) < ctot;
         rA = seg1 ? rA1 : rA0;
 #pragma unroll
         for (int i = 0; i < RA; ++i)
@@ -498,8 +530,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) acc[i][j][r] = 0.f;
 
-    acc_t accx[AR == AR_SPLIT ? TM : 1][AR == AR_SPLIT ? TN : 1];      // cross terms (x 2048)
-    if constexpr (AR == AR_SPLIT) {
+    acc_t accx[SPLIT ? TM : 1][SPLIT ? TN : 1];      // cross terms (x 2048)
+    if constexpr (SPLIT) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -508,9 +540,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                 for (int r = 0; r < NR; ++r) accx[i][j][r] = 0.f;
     }
     // ---- split arithmetic: raw fp32 fragments double buffered in registers, split right before their MFMAs
-    f32x4 ra[2][AR == AR_SPLIT ? TM : 1][2], rb[2][AR == AR_SPLIT ? TN : 1][2];
+    f32x4 ra[2][SPLIT ? TM : 1][2], rb[2][SPLIT ? TN : 1][2];
     auto read_raw = [&](int buf, int g, int slot) {
-        if constexpr (AR == AR_SPLIT && !(MFTX_SABL & 8)) {
+        if constexpr (SPLIT && !(MFTX_SABL & 8)) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -528,9 +560,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
     // between them, pair by pair, in the shadow of the matrix pipe -- the split of the NEXT A tile: tile i + 1 of
     // this group, or tile 0 of the next group (raw set `nset`, when `have_next`).  ah / al hold the split operands
     // of the tile about to be multiplied (tile 0 on entry); the order is pinned with scheduling barriers.
-    f16x8 ah[AR == AR_SPLIT ? TM : 1], al[AR == AR_SPLIT ? TM : 1];
+    f16x8 ah[SPLIT ? TM : 1], al[SPLIT ? TM : 1];
     auto group = [&](int set, int nset, bool have_next, int refill = -1) {
-        if constexpr (AR == AR_SPLIT) {
+        if constexpr (SPLIT) {
             f16x8 bh[TN], bl[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {           // the weights arrive split: [hi x 8 | lo x 8] per 8 k = the two chunks read
@@ -540,7 +572,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const bool in_group = i + 1 < TM;
-                const bool do_split = (in_group || have_next) && !(MFTX_SABL & 1);
+                const bool do_split = (in_group || have_next) && !(MFTX_SABL & 1) && !PRE;
                 const f32x4 &u = in_group ? ra[set][i + 1 < TM ? i + 1 : 0][0] : ra[nset][0][0];
                 const f32x4 &v = in_group ? ra[set][i + 1 < TM ? i + 1 : 0][1] : ra[nset][0][1];
                 u32x4 nh = {0, 0, 0, 0}, nl = {0, 0, 0, 0};
@@ -571,7 +603,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
 #pragma unroll
                     for (int k = 3 * TN * TM; k < RA + RB; ++k) fetch_piece(refill, k);     // (fewer MFMAs than pieces)
                 }
-                if (MFTX_SABL & 1) {
+                if ((MFTX_SABL & 1) || PRE) {            // the two chunks read ARE the halves
                     nh = __builtin_bit_cast(u32x4, u);
                     nl = __builtin_bit_cast(u32x4, v);
                 }
@@ -655,7 +687,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    if constexpr (AR == AR_SPLIT) {
+    if constexpr (SPLIT) {
         // Ring of NS chunks, slot of chunk c = c % NS (run-time index: the K loop is not unrolled over the slots).
         // Per chunk: two 16-wide k groups; the raw fragments of the next group are read from LDS before the
         // current group is split and multiplied; ONE barrier per chunk, taken before the last group's MFMAs --
@@ -670,7 +702,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         if (T >= NS) wait_vmcnt<(NS - 1) * L>(); else wait_vmcnt<0>();
         block_barrier();
         read_raw(0, 0, 0);
-        if (MFTX_SABL & 1) {
+        if ((MFTX_SABL & 1) || PRE) {
             ah[0] = __builtin_bit_cast(f16x8, ra[0][0][0]);
             al[0] = __builtin_bit_cast(f16x8, ra[0][0][1]);
         } else {
@@ -754,7 +786,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         step(0, false, false);
     }
     }
-    if constexpr (AR == AR_SPLIT) {          // fold the cross terms in
+    if constexpr (SPLIT) {          // fold the cross terms in
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -776,7 +808,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         volume_epilogue(p, acc[0], smem + wid * 4096, lane, m0 + wm * 32, n0 / BN, bz);
         continue;
     }
-    if constexpr (AR == AR_SPLIT) {
+    if constexpr (SPLIT) {
         // Vectorised epilogue: each 32 x 32 accumulator tile goes through 4 KiB of the wave's own LDS (the ring is
         // free now) and comes back as four float4 per lane -- row t * 8 + (lane >> 3), columns 4 (lane & 7) .. + 3:
         // the addend / z / h reads and the stores become 16-byte accesses, a quarter of the instructions of the
@@ -819,10 +851,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                     if (full) {
                         if (any_add) add[t] = *reinterpret_cast<const f32x4 *>(p.addend + m * p.ld_addend + nb);
                         if constexpr (EPI == EPI_GRU_ZR) {
-                            if (nb >= 128) a1[t] = *reinterpret_cast<const f32x4 *>(p.hx + m * p.ld_hx + (nb - 128));
+                            if (nb >= 128) a1[t] = *reinterpret_cast<const f32x4 *>(p.hf + m * p.ld_hf + (nb - 128));
                         } else if constexpr (EPI == EPI_GRU_Q) {
                             a0[t] = *reinterpret_cast<const f32x4 *>(p.z + m * 128 + nb);
-                            a1[t] = *reinterpret_cast<const f32x4 *>(p.hx + m * p.ld_hx + nb);
+                            a1[t] = *reinterpret_cast<const f32x4 *>(p.hf + m * p.ld_hf + nb);
                         }
                     } else {
 #pragma unroll
@@ -852,10 +884,22 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                             o[e] = g;
                         }
                     }
-                    float *dst;
-                    if constexpr (EPI == EPI_GRU_ZR) dst = nb < 128 ? p.z + m * 128 + nb : p.rh + m * 128 + (nb - 128);
-                    else if constexpr (EPI == EPI_GRU_Q) dst = p.hx + m * p.ld_hx + nb;
-                    else dst = out + m * p.ldo + nb;
+                    if constexpr (EPI == EPI_GRU_ZR) {
+                        if (nb < 128) *reinterpret_cast<f32x4 *>(p.z + m * 128 + nb) = o;          // z: fp32, read by the q epilogue only
+                        else if (p.out_split) store_split4(p.rh + m * 128, nb - 128, o);           // r h: an A operand of the q GEMM
+                        else *reinterpret_cast<f32x4 *>(p.rh + m * 128 + (nb - 128)) = o;
+                        continue;
+                    }
+                    if constexpr (EPI == EPI_GRU_Q) {
+                        *reinterpret_cast<f32x4 *>(p.hf + m * p.ld_hf + nb) = o;
+                        if (p.out_split) store_split4(p.hx + m * p.ld_hx, nb, o);
+                        continue;
+                    }
+                    if (p.out_split) {
+                        store_split4(out + m * p.ldo, nb, o, full ? 4 : p.N - nb);
+                        continue;
+                    }
+                    float *dst = out + m * p.ldo + nb;
                     if (full && vec_out) *reinterpret_cast<f32x4 *>(dst) = o;
                     else
 #pragma unroll
@@ -923,7 +967,7 @@ __device__ __forceinline__ int n_virtual_tiles(const ConvArgs &p, int BM, int BN
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, int MT = 32, int AR = AR_F32, int NS = 2>
-__global__ __launch_bounds__(64 * WM * WN, AR == AR_SPLIT ? min_waves_split((BM / WM / MT) * (BN / WN / MT), WM * WN) : min_waves((BM / WM / MT) * (BN / WN / MT)))
+__global__ __launch_bounds__(64 * WM * WN, AR != AR_F32 ? min_waves_split((BM / WM / MT) * (BN / WN / MT), WM * WN) : min_waves((BM / WM / MT) * (BN / WN / MT)))
 void conv_gemm_kernel(ConvArgs p) {
     conv_gemm_body<BM, BN, WM, WN, EPI, MT, AR, NS>(p, blockIdx.x);
 }
@@ -987,6 +1031,14 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat, 
 // the ring is fixed at two chunks, which lets the K loop be unrolled over the slots.
 template <int EPI>
 static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) {
+    if (a.arith == AR_SPLIT && a.a_pre) {              // A already in split form: the production tiles only
+        switch (tile) {
+            case 0: return launch_cfg<128, 128, 2, 2, EPI, 32, AR_PRESPLIT, 2>(a, batch, s, cat);
+            case 6: return launch_cfg<128, 128, 4, 2, EPI, 32, AR_PRESPLIT, 4>(a, batch, s, cat);
+            case 10: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_PRESPLIT, 2>(a, batch, s, cat);
+            default: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
+        }
+    }
     if (a.arith == AR_SPLIT) {
         switch (tile) {
             case 0: return launch_cfg<128, 128, 2, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);   // two workgroups of four 64 x 64 waves per CU
@@ -1075,6 +1127,11 @@ static int validate(const mftx_conv_desc &d) {
         return fail(MFTX_E_ALIGN, "conv2d: operands must be 16-byte aligned");
     if (d.act < 0 || d.act > 3) return fail(MFTX_E_ARG, "conv2d: bad activation");
     if (d.arith != AR_F32 && d.arith != AR_SPLIT) return fail(MFTX_E_ARG, "conv2d: bad arithmetic");
+    if ((d.a_split || d.out_split) && d.arith != AR_SPLIT) return fail(MFTX_E_ARG, "conv2d: split-form operands belong to the split arithmetic");
+    if (d.a_split && (d.c0 % 8 || d.c1 % 8 || d.lda0 % 8 || (d.c1 > 0 && d.lda1 % 8) || (reinterpret_cast<uintptr_t>(d.a0) & 31) || (d.c1 > 0 && (reinterpret_cast<uintptr_t>(d.a1) & 31))))
+        return fail(MFTX_E_ALIGN, "conv2d: a split-form A operand has channel counts and row strides in multiples of 8 and 32-byte aligned rows");
+    if (d.out_split && (d.ldo % 8 || (reinterpret_cast<uintptr_t>(d.out) & 31)))
+        return fail(MFTX_E_ALIGN, "conv2d: a split-form output has a row stride in multiples of 8 and 32-byte aligned rows");
     if (d.arith == AR_SPLIT && ((d.bias && !aligned16(d.bias)) || (d.addend && (d.ld_addend % 4 || !aligned16(d.addend)))))
         return fail(MFTX_E_ALIGN, "conv2d: split arithmetic reads 16-byte pieces: bias and addend must be 16-byte aligned, the addend's row stride a multiple of 4");
     const long long M = (long long)d.P * d.h * d.w;
@@ -1096,6 +1153,8 @@ static ConvArgs to_args(const mftx_conv_desc &d) {
     a.w_rows = round_up(d.N, 128);
     a.act = d.act; a.out_scale = d.out_scale;
     a.arith = d.arith;
+    a.a_pre = d.a_split; a.out_split = d.out_split;
+    a.hf = nullptr; a.ld_hf = 0;
     a.addend = d.addend; a.ld_addend = d.ld_addend; a.residual_mode = d.residual_mode;
     a.stride = d.stride ? d.stride : 1;
     a.hin = d.hin ? d.hin : d.h; a.win = d.win ? d.win : d.w;
@@ -1150,6 +1209,7 @@ int launch_conv_gru(const mftx_conv_desc &d, const GruEpilogue &g, hipStream_t s
     if (int e = validate(d)) return e;
     ConvArgs a = to_args(d);
     a.hx = g.hx; a.ld_hx = g.ld_hx; a.z = g.z; a.rh = g.rh;
+    a.hf = g.hf ? g.hf : g.hx; a.ld_hf = g.hf ? g.ld_hf : g.ld_hx;
     if ((g.mode == 1 && d.N != 256) || (g.mode == 2 && d.N != 128)) return fail(MFTX_E_ARG, "gru epilogue: bad N");
     return dispatch(a, g.mode == 1 ? EPI_GRU_ZR : EPI_GRU_Q, 1, s, PC_CONV_GEMM);
 }

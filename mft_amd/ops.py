@@ -61,6 +61,19 @@ def split_weights(wpk: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def split_activations(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [M, C] (C % 8 == 0) -> the split form the engine stores GEMM inputs in: every 8 channels of a row as
+    [hi x 8 | lo x 8] fp16 (same shape and dtype as a container).  The same kernel as ``split_weights``."""
+    return split_weights(x)
+
+
+def unsplit_activations(x: torch.Tensor) -> torch.Tensor:
+    """Inverse of ``split_activations`` (exact: hi + lo / 2048 is representable in fp32)."""
+    m, c = x.shape
+    h = x.contiguous().view(torch.float16).reshape(m, c // 8, 2, 8).float()
+    return (h[:, :, 0] + h[:, :, 1] * (1.0 / 2048.0)).reshape(m, c)
+
+
 def pack_raft_weights(sd: dict, device) -> list:
     """The 30 tensors ``mftx_raft_create`` expects, in WeightSlot order
     (csrc/raft_engine.hip).  z|r gates and the two OU heads are fused into single
@@ -303,11 +316,13 @@ def corr_lookup_ondemand(f1: torch.Tensor, f2_levels, coords: torch.Tensor, h: i
 
 
 def conv2d(x: torch.Tensor, wpk: torch.Tensor, bias, P, h, w, N, kh, kw, act=None, out_scale=1.0, x2=None,
-           addend=None, stride=0, hin=0, win=0, pad_y=0, pad_x=0, residual_mode=0, arith=ARITH_F32):
+           addend=None, stride=0, hin=0, win=0, pad_y=0, pad_x=0, residual_mode=0, arith=ARITH_F32, a_split=False,
+           out_split=False, out=None):
     """x: pixel-major [P*h*w, C0] (optionally concatenated with x2 [P*h*w, C1]) ->
     [P*h*w, N].  arith = ARITH_SPLIT: wpk is the output of ``split_weights``."""
     lib = _lib.load()
-    out = torch.empty(P * h * w, N, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(P * h * w, N, dtype=torch.float32, device=x.device)
     d = ConvDesc()
     d.a0, d.lda0, d.c0 = _chk(x, "x"), x.shape[1], x.shape[1]
     if x2 is not None:
@@ -316,12 +331,13 @@ def conv2d(x: torch.Tensor, wpk: torch.Tensor, bias, P, h, w, N, kh, kw, act=Non
         d.a1, d.lda1, d.c1 = None, 0, 0
     d.wpk = _chk(wpk, "wpk")
     d.bias = _chk(bias, "bias") if bias is not None else None
-    d.out, d.ldo = out.data_ptr(), N
+    d.out, d.ldo = _chk(out, "out"), out.shape[1]
     d.P, d.h, d.w, d.N, d.kh, d.kw = P, h, w, N, kh, kw
     d.act, d.out_scale = ACT[act], out_scale
     d.addend, d.ld_addend = (_chk(addend, "addend"), addend.shape[1]) if addend is not None else (None, 0)
     d.stride, d.hin, d.win, d.pad_y, d.pad_x, d.residual_mode = stride, hin, win, pad_y, pad_x, residual_mode
     d.arith = arith
+    d.a_split, d.out_split = int(bool(a_split)), int(bool(out_split))      # operands in split form (see split_activations)
     check(lib.mftx_conv2d(C.byref(d), _stream()), "mftx_conv2d")
     return out
 

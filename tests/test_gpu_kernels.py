@@ -223,6 +223,39 @@ def test_conv2d_split_arith_vs_fp64(ops_mod, cin, cout, kh, kw, act, scale, P, h
     assert float(err["split"].pow(2).mean().sqrt()) <= 1.05 * float(err["fp32"].pow(2).mean().sqrt()) + 1e-12
 
 
+@pytest.mark.parametrize("cin,cout,kh,kw,P,h,w,x2c", [(256, 192, 3, 3, 2, 16, 24, 0), (128, 128, 1, 5, 7, 32, 32, 128),
+                                                    (328, 256, 1, 1, 1, 17, 23, 0), (256, 126, 3, 3, 3, 33, 47, 0),
+                                                    (712, 256, 3, 3, 1, 16, 24, 0)])
+def test_conv2d_split_form_operands(ops_mod, cin, cout, kh, kw, P, h, w, x2c):
+    """Split-form operands (the engine's storage of GEMM inputs): a pre-split A gives the same bits as A split in
+    registers, and a split-form output is the fp32 output's split, bit for bit -- the N = 126 tail leaves the rest
+    of its 8-channel group alone."""
+    g = torch.Generator().manual_seed(cin + cout)
+    M = P * h * w
+    x = (torch.randn(M, cin, generator=g) * torch.exp(torch.randn(M, cin, generator=g))).to(DEV)
+    x2 = torch.randn(M, x2c, generator=g).to(DEV) if x2c else None
+    wt = ops_mod.split_weights(ops_mod.pack_conv_weight((torch.randn(cout, cin + x2c, kh, kw, generator=g) * 0.05).to(DEV)))
+    b = torch.randn(cout, generator=g).to(DEV)
+    ref = ops_mod.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu", arith=ops_mod.ARITH_SPLIT, x2=x2)
+    xs = ops_mod.split_activations(x)
+    assert torch.equal(ops_mod.unsplit_activations(xs), ops_mod.unsplit_activations(ops_mod.split_activations(ops_mod.unsplit_activations(xs))))
+    got = ops_mod.conv2d(xs, wt, b, P, h, w, cout, kh, kw, act="relu", arith=ops_mod.ARITH_SPLIT, a_split=True,
+                         x2=ops_mod.split_activations(x2) if x2c else None)
+    assert torch.equal(got, ref)
+    if cout % 8 == 0:
+        outs = ops_mod.conv2d(xs, wt, b, P, h, w, cout, kh, kw, act="relu", arith=ops_mod.ARITH_SPLIT, a_split=True,
+                              x2=ops_mod.split_activations(x2) if x2c else None, out_split=True)
+        assert torch.equal(outs, ops_mod.split_activations(ref))
+    else:                                   # N = 126 into a 128-wide split buffer: channels 126, 127 are not touched
+        buf = ops_mod.split_activations(torch.full((M, 128), 7.0, device=DEV))
+        ops_mod.conv2d(xs, wt, b, P, h, w, cout, kh, kw, act="relu", arith=ops_mod.ARITH_SPLIT, a_split=True,
+                       out_split=True, out=buf)
+        dec = ops_mod.unsplit_activations(buf)
+        assert torch.equal(dec[:, :cout], ops_mod.unsplit_activations(ops_mod.split_activations(
+            torch.cat([ref, torch.zeros(M, 2, device=DEV)], 1)))[:, :cout])
+        assert bool((dec[:, cout:] == 7.0).all())
+
+
 def test_conv2d_split_arith_errors(ops_mod):
     from mft_amd._lib import MftxError
     x = torch.zeros(16 * 24, 256, device=DEV)
