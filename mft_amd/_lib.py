@@ -51,6 +51,7 @@ SIGNATURES = {
     "mftx_raft_destroy": (None, [C.c_void_p]),
     "mftx_raft_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "mftx_raft_workspace_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.c_int]),
+    "mftx_raft_workspace_layout_for": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.c_int]),
     "mftx_raft_refine": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_int, C.c_int, C.c_int, C.c_int,

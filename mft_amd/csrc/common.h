@@ -64,6 +64,43 @@ inline PyramidLayout pyramid_layout(int h, int w) {
 // producers): every 8 consecutive channels are 32 bytes [hi x 8 | lo x 8] of fp16, hi = fp16(x), lo = fp16((x - hi) * 2048)
 // -- same size, same row stride, channel c at byte split_row_offset(c) (its low half 16 bytes further).
 __host__ __device__ inline int split_row_offset(int c) { return (c >> 3) * 32 + (c & 7) * 2; }
+#ifdef __HIPCC__
+// (hi, lo) halves of a value, bit for bit what the GEMM's register split produces (round to nearest twice)
+__device__ __forceinline__ unsigned split_halves(float v) {
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)((v - (float)h) * 2048.f);
+    return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+// Channel c of a split-form row, one value per lane, the lanes of a pair (lane ^ 1) holding channels c and c ^ 1 with
+// the parity of c = the parity of the lane: the even lane stores the pair's high halves, the odd lane the low halves --
+// one 4-byte store per lane, like the fp32 form.  EVERY lane of the wave must call this (the exchange is a shuffle);
+// `store` says whether this lane's pair is written.
+__device__ __forceinline__ void store_split_pairwise(float *row, int c, float v, bool store) {
+    const unsigned mine = split_halves(v);
+    const unsigned other = (unsigned)__shfl_xor((int)mine, 1);
+    const bool odd = (c & 1) != 0;
+    const unsigned word = odd ? ((other >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (other << 16));
+    char *dst = reinterpret_cast<char *>(row) + split_row_offset(c & ~1) + (odd ? 16 : 0);
+    if (store) *reinterpret_cast<unsigned *>(dst) = word;
+}
+// four consecutive channels c .. c + 3 (c % 4 == 0) of a split-form row <-> four floats
+__device__ __forceinline__ float4 load_split4(const float *row, int c) {
+    const char *src = reinterpret_cast<const char *>(row) + split_row_offset(c);
+    const uint2 h = *reinterpret_cast<const uint2 *>(src), l = *reinterpret_cast<const uint2 *>(src + 16);
+    auto dec = [](unsigned hh, unsigned ll, int hi) {
+        const _Float16 a = __builtin_bit_cast(_Float16, (unsigned short)(hi ? hh >> 16 : hh));
+        const _Float16 b = __builtin_bit_cast(_Float16, (unsigned short)(hi ? ll >> 16 : ll));
+        return (float)a + (float)b * (1.f / 2048.f);
+    };
+    return make_float4(dec(h.x, l.x, 0), dec(h.x, l.x, 1), dec(h.y, l.y, 0), dec(h.y, l.y, 1));
+}
+__device__ __forceinline__ void store_split4v(float *row, int c, float4 v) {
+    const unsigned a = split_halves(v.x), b = split_halves(v.y), cc = split_halves(v.z), d = split_halves(v.w);
+    char *dst = reinterpret_cast<char *>(row) + split_row_offset(c);
+    *reinterpret_cast<uint2 *>(dst) = make_uint2((a & 0xffffu) | (b << 16), (cc & 0xffffu) | (d << 16));
+    *reinterpret_cast<uint2 *>(dst + 16) = make_uint2((a >> 16) | (b & 0xffff0000u), (cc >> 16) | (d & 0xffff0000u));
+}
+#endif
 int launch_conv(const mftx_conv_desc &d, hipStream_t s);
 int launch_conv_pair(const mftx_conv_desc &a, const mftx_conv_desc &b, hipStream_t s);   // two independent ReLU convs, one launch
 // conv whose epilogue is a GRU gate (see conv_gemm.hip)
@@ -86,11 +123,11 @@ int launch_conv_small(const mftx_conv_desc &d, hipStream_t s, float *accum = nul
 int launch_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, int w, float *const lvl[4], hipStream_t s,
                         float *f2_split = nullptr);
 int launch_corr_lookup(const float *const lvl[4], const float *coords, int P, int h, int w,
-                       float *out, int ld_out, hipStream_t s);
+                       float *out, int ld_out, hipStream_t s, int out_split = 0);
 // on-demand correlation (csrc/corr_ondemand.hip): pooled feature pyramid + lookup without a stored volume
 int launch_fmap_pyramid(const float *f2, int P, int C, int h, int w, float *const lvl[3], hipStream_t s);
 int launch_corr_ondemand(const float *f1, const float *const f2lvl[4], const float *coords, int P, int h, int w,
-                         float *out, int ld_out, hipStream_t s);
+                         float *out, int ld_out, hipStream_t s, int out_split = 0);
 int launch_convex_upsample(const float *flow_lr, const float *ou, int ld_ou, const float *mask,
                            int P, int h, int w, int pl, int pr, int pt, int pb,
                            float *flow, float *occl, float *sigma, float *packed, hipStream_t s);

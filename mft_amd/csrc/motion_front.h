@@ -26,6 +26,7 @@ struct LookupArgs {
     unsigned hbwb[2];       // blocks per query of levels 0, 1
     long long stride[4];    // floats per query cell
     int ablate;     // tuning only (MFTX_LOOKUP_ABLATE): 1 no tap loads, 2 no stores, 3 neither
+    int out_split;  // write the 324 features in split form (common.h; ld_out >= 328: channels 324..327 are written as zeros)
 };
 
 inline LookupArgs make_lookup_args(const float *const lvl[4], const float *coords, int P, int h, int w, float *out,
@@ -34,7 +35,7 @@ inline LookupArgs make_lookup_args(const float *const lvl[4], const float *coord
     const PyramidLayout L = pyramid_layout(h, w);
     for (int l = 0; l < 4; ++l) { a.lvl[l] = lvl[l]; a.hl[l] = L.h[l]; a.wl[l] = L.w[l]; a.stride[l] = L.stride[l]; }
     for (int l = 0; l < 2; ++l) { a.wb[l] = L.wb[l]; a.hbwb[l] = (unsigned)(L.hb[l] * L.wb[l]); }
-    a.coords = coords; a.out = out; a.ld_out = ld_out;
+    a.coords = coords; a.out = out; a.ld_out = ld_out; a.out_split = 0;
     a.cells = P * h * w; a.n_per_img = h * w;
     static const int ablate = [] { const char *e = getenv("MFTX_LOOKUP_ABLATE"); return e ? atoi(e) : 0; }();
     a.ablate = ablate;
@@ -160,13 +161,17 @@ __device__ __forceinline__ void lookup_block_body(const LookupArgs &p, int block
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const int o = lane + 64 * j;
-                if ((j < 5 || o < 324) && (!(p.ablate & 2) || (j == 0 && lane == 0))) {
+                const bool live = (j < 5 || o < 324) && (!(p.ablate & 2) || (j == 0 && lane == 0));
+                float val = 0.f;
+                if (live) {
                     const int l = o_lvl[j];
                     const float4 wq = *reinterpret_cast<const float4 *>(tp + 4 * LK_LVL + l * 4);
                     const float *t4 = tp + o_ab[j] + (l == 0 ? xo[u][0] : l == 1 ? xo[u][1] : 0);
                     const float v00 = t4[0], v01 = t4[1], v10 = t4[LK_ROW], v11 = t4[LK_ROW + 1];
-                    dst[o] = v00 * wq.x + v01 * wq.y + v10 * wq.z + v11 * wq.w;
+                    val = v00 * wq.x + v01 * wq.y + v10 * wq.z + v11 * wq.w;
                 }
+                if (p.out_split) store_split_pairwise(dst, o, val, j < 5 || o < 328);     // (wave-uniform branch; 324..327: zeros)
+                else if (live) dst[o] = val;
             }
         }
     }
@@ -187,6 +192,7 @@ struct ConvF1Args {
     const float *coords1, *w98 /* [98][128] */, *bias;
     float *flo1, *hx;
     int h, w, strips_per_row, n_strips;
+    int out_split;      // flo1 and the flow tail of hx are written in split form (common.h)
 };
 // one strip of 16 cells by 128 threads (`tid` 0..127); `patch` is that half-block's LDS slab.  Every
 // thread of the block must call this the same number of times (it synchronises the block).
@@ -253,8 +259,12 @@ __device__ __forceinline__ void convf1_strip(const ConvF1Args &q, int strip_id, 
 #pragma unroll
     for (int t = 0; t < F1_CELLS; ++t) {
         const int x = x0 + t;
-        if (x < w && live) {
-            const long long cell = img_base + (long long)y * w + x;
+        const bool st = x < w && live;                       // (uniform per block)
+        const long long cell = st ? img_base + (long long)y * w + x : 0;
+        if (q.out_split) {                                   // every lane takes part in the pair exchange
+            store_split_pairwise(flo1 + cell * 128, co, fmaxf(acc[t], 0.f), st);
+            store_split_pairwise(hx + cell * 384, 382 + (co & 1), patch[3][2 * (t + 3) + (co & 1)], st && co < 2);
+        } else if (st) {
             flo1[cell * 128 + co] = fmaxf(acc[t], 0.f);
             if (co < 2) hx[cell * 384 + 382 + co] = patch[3][2 * (t + 3) + co];
         }

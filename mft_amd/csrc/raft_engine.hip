@@ -16,15 +16,22 @@ namespace mftx {
 
 // hx[m] = [net | inp | (motion: filled later)], coords1 = pixel grid
 // (core/raft.py:146-151; coords_grid core/utils/utils.py:115-118)
+// hf (split arithmetic with split-form activations): hx is written in split form (common.h) and h additionally as
+// fp32 into hf [M][128], the copy the GRU's gate algebra reads
 __global__ void init_state_kernel(const float *__restrict__ net, const float *__restrict__ inp,
-                                  const float *__restrict__ flow_init, float *hx, float *coords1, int M, int h,
+                                  const float *__restrict__ flow_init, float *hx, float *hf, float *coords1, int M, int h,
                                   int w) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over M*64 float4 slots
     if (i >= (long long)M * 64) return;
     const int m = (int)(i >> 6), q = (int)(i & 63);
     const float4 v = (q < 32) ? reinterpret_cast<const float4 *>(net)[(long long)m * 32 + q]
                               : reinterpret_cast<const float4 *>(inp)[(long long)m * 32 + (q - 32)];
-    reinterpret_cast<float4 *>(hx + (long long)m * 384)[q] = v;
+    if (hf != nullptr) {
+        store_split4v(hx + (long long)m * 384, 4 * q, v);
+        if (q < 32) reinterpret_cast<float4 *>(hf + (long long)m * 128)[q] = v;
+    } else {
+        reinterpret_cast<float4 *>(hx + (long long)m * 384)[q] = v;
+    }
     if (q == 0) {
         const int rem = m % (h * w);
         float cx = (float)(rem % w), cy = (float)(rem / w);
@@ -64,15 +71,31 @@ __global__ __launch_bounds__(256) void lookup_convf1_kernel(LookupArgs lp, ConvF
 // OU input [net128 | inp128 | corr324 | flow2 | delta2 | motion128] = 712
 // (core/update.py:197), flow = coords1 - grid AFTER the last update
 // (core/raft.py:199-206); also emits flow_lr for the upsampler.
-__global__ void ou_gather_kernel(const float *__restrict__ hx, const float *__restrict__ corr,
+// split != 0: hx and corr ([M][ld_corr]) are in split form and so is ouin -- four channels are one half group
+// (common.h: load_split4 / store_split4v; decode + encode reproduces the halves exactly)
+__global__ void ou_gather_kernel(const float *__restrict__ hx, const float *__restrict__ corr, int ld_corr,
                                  const float *__restrict__ coords1, const float *__restrict__ delta,
-                                 float *__restrict__ ouin, float *__restrict__ flow_lr, int M, int h, int w) {
+                                 float *__restrict__ ouin, float *__restrict__ flow_lr, int M, int h, int w, int split) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over M*178 float4 slots
     if (i >= (long long)M * 178) return;
     const int m = (int)(i / 178), q = (int)(i - (long long)m * 178);
     float4 v;
+    if (split) {
+        if (q < 64) v = load_split4(hx + (long long)m * 384, 4 * q);
+        else if (q < 145) v = load_split4(corr + (long long)m * ld_corr, 4 * (q - 64));
+        else if (q == 145) {
+            const int rem = m % (h * w);
+            const float fx = coords1[2 * (long long)m] - (float)(rem % w);
+            const float fy = coords1[2 * (long long)m + 1] - (float)(rem / w);
+            v = make_float4(fx, fy, delta[2 * (long long)m], delta[2 * (long long)m + 1]);
+            flow_lr[2 * (long long)m] = fx;
+            flow_lr[2 * (long long)m + 1] = fy;
+        } else v = load_split4(hx + (long long)m * 384 + 256, 4 * (q - 146));
+        store_split4v(ouin + (long long)m * 712, 4 * q, v);
+        return;
+    }
     if (q < 64) v = reinterpret_cast<const float4 *>(hx + (long long)m * 384)[q];                 // net, inp
-    else if (q < 145) v = reinterpret_cast<const float4 *>(corr + (long long)m * 324)[q - 64];    // corr
+    else if (q < 145) v = reinterpret_cast<const float4 *>(corr + (long long)m * ld_corr)[q - 64];    // corr
     else if (q == 145) {
         const int rem = m % (h * w);
         const float fx = coords1[2 * (long long)m] - (float)(rem % w);
@@ -102,10 +125,12 @@ struct Workspace {
     float *coords1, *corr, *cor1, *corflo, *flo1, *hx, *z, *rh, *fh, *delta, *mask, *ouin, *ouh, *ou, *flow_lr;
     float *pre_zr[2], *pre_q[2];   // inp part of the GRU gate convolutions (+ bias), per pass
     float *f2s;                    // split form of fmap2 (B operand of the volume GEMM in split arithmetic)
+    float *hf;                     // split arithmetic: fp32 copy of h [M][128] (hx itself is in split form)
+    int ld_corr;                   // 324, or 328 when corr is stored in split form (whole 8-channel groups)
     size_t bytes;
 };
 
-static Workspace carve(void *base, int P, int h, int w, bool ondemand = false) {
+static Workspace carve(void *base, int P, int h, int w, bool ondemand = false, bool split = false) {
     Workspace ws{};
     const size_t N = (size_t)h * w, M = (size_t)P * N;
     size_t off = 0;
@@ -118,7 +143,8 @@ static Workspace carve(void *base, int P, int h, int w, bool ondemand = false) {
     for (int l = 0; l < 4; ++l) ws.lvl[l] = take(ondemand ? 0 : M * (size_t)L.stride[l]);
     for (int l = 1; l < 4; ++l) ws.f2l[l - 1] = take(ondemand ? (size_t)P * (h >> l) * (w >> l) * 256 : 0);
     ws.coords1 = take(M * 2);
-    ws.corr = take(M * 324);
+    ws.ld_corr = split ? 328 : 324;
+    ws.corr = take(M * ws.ld_corr);
     ws.cor1 = take(M * 256);
     ws.corflo = take(M * 256);
     ws.flo1 = take(M * 128);
@@ -133,7 +159,8 @@ static Workspace carve(void *base, int P, int h, int w, bool ondemand = false) {
     ws.ou = take(M * 4);
     ws.flow_lr = take(M * 2);
     for (int pass = 0; pass < 2; ++pass) { ws.pre_zr[pass] = take(M * 256); ws.pre_q[pass] = take(M * 128); }
-    ws.f2s = take(ondemand ? 0 : M * 256);
+    ws.f2s = take(ondemand || !split ? 0 : M * 256);
+    ws.hf = take(split ? M * 128 : 0);
     ws.bytes = off;
     return ws;
 }
@@ -229,20 +256,27 @@ extern "C" int mftx_raft_arith(const mftx_raft *r) {
 
 extern "C" size_t mftx_raft_workspace_bytes_for(const mftx_raft *r, int P, int h, int w) {
     if (!r || r->magic != RAFT_MAGIC || P <= 0 || h <= 0 || w <= 0) return 0;
-    return carve(nullptr, P, h, w, r->ondemand != 0).bytes;
+    return carve(nullptr, P, h, w, r->ondemand != 0, r->arith == MFTX_ARITH_SPLIT).bytes;
 }
 
 // Byte offsets of the workspace regions, in the order lvl0..3, coords1, corr,
 // cor1, corflo, flo1, hx, z, rh, fh, delta, mask, ouin, ouh, ou, flow_lr -- lets
 // the parity tests inspect the intermediates of the last iteration.
-extern "C" int mftx_raft_workspace_layout(int P, int h, int w, size_t *offsets, int n) {
+static int workspace_layout(const mftx_raft *r, int P, int h, int w, size_t *offsets, int n) {
     if (P <= 0 || h <= 0 || w <= 0 || !offsets || n != 19) return fail(MFTX_E_ARG, "workspace_layout: need 19 slots");
     char *base = reinterpret_cast<char *>(uintptr_t(1) << 40);
-    Workspace ws = carve(base, P, h, w);
+    Workspace ws = carve(base, P, h, w, r && r->ondemand != 0, r && r->arith == MFTX_ARITH_SPLIT);
     float *ptrs[19] = {ws.lvl[0], ws.lvl[1], ws.lvl[2], ws.lvl[3], ws.coords1, ws.corr, ws.cor1, ws.corflo, ws.flo1,
                        ws.hx, ws.z, ws.rh, ws.fh, ws.delta, ws.mask, ws.ouin, ws.ouh, ws.ou, ws.flow_lr};
     for (int i = 0; i < 19; ++i) offsets[i] = (size_t)(reinterpret_cast<char *>(ptrs[i]) - base);
     return 0;
+}
+extern "C" int mftx_raft_workspace_layout(int P, int h, int w, size_t *offsets, int n) {
+    return workspace_layout(nullptr, P, h, w, offsets, n);
+}
+extern "C" int mftx_raft_workspace_layout_for(const mftx_raft *r, int P, int h, int w, size_t *offsets, int n) {
+    if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "workspace_layout_for: bad handle");
+    return workspace_layout(r, P, h, w, offsets, n);
 }
 
 #define TRY(expr) do { int _e = (expr); if (_e) return _e; } while (0)
@@ -279,7 +313,11 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         pad_top + pad_bottom >= 8)
         return fail(MFTX_E_ARG, "raft_refine: bad padding");
     const bool ondemand = r->ondemand != 0;
-    Workspace ws = carve(workspace, P, h, w, ondemand);
+    // split arithmetic: every tensor that feeds a GEMM of the update block / OU heads lives in the workspace in SPLIT
+    // form (common.h), written that way by its producer -- the GEMMs' K loops then spend nothing on splitting
+    static const bool no_presplit = getenv("MFTX_RAFT_NOPRESPLIT") != nullptr;     // tuning: fp32 activations, split in the GEMMs' registers
+    const bool SP = r->arith == MFTX_ARITH_SPLIT && !no_presplit;
+    Workspace ws = carve(workspace, P, h, w, ondemand, r->arith == MFTX_ARITH_SPLIT);
     if (ws.bytes > workspace_bytes)
         return fail(MFTX_E_WORKSPACE, "raft_refine: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
     hipStream_t s = (hipStream_t)stream;
@@ -287,7 +325,8 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     const float *const *W = r->w;
     const float *const *G = r->wg;          // GEMM layers: fp32 or split weights, by the handle's arithmetic
     const int AR = r->arith;
-    auto gemm = [AR](mftx_conv_desc d) { d.arith = AR; return d; };
+    // gemm(desc, a, o): arithmetic of the handle; a: the A operand(s) are in split form, o: the output is written in it
+    auto gemm = [AR, SP](mftx_conv_desc d, bool a = true, bool o = false) { d.arith = AR; d.a_split = SP && a; d.out_split = SP && o; return d; };
 
     // correlation volume + pyramid (core/corr.py:14-28)
     const float *f2lv[4] = {fmap2, ws.f2l[0], ws.f2l[1], ws.f2l[2]};
@@ -297,7 +336,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         const long long slots = (long long)M * 64;
         ProfScope prof(PC_GLUE, s, 0);
         hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, net, inp,
-                           flow_init, ws.hx, ws.coords1, M, h, w);
+                           flow_init, ws.hx, SP ? ws.hf : nullptr, ws.coords1, M, h, w);
         TRY(check_launch("init_state"));
     }
     // The gate convolutions are linear in their input [h | inp | motion] and `inp` does not change
@@ -305,8 +344,8 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     // once here and enters the per-iteration GEMMs as an epilogue addend.  Same terms, summed once.
     for (int pass = 0; pass < 2; ++pass) {
         const int kh = pass ? 5 : 1, kw = pass ? 1 : 5;
-        TRY(launch_conv(gemm(conv_desc(ws.hx + 128, 384, 128, nullptr, 0, 0, G[pass ? W_ZR2_INP : W_ZR1_INP], W[pass ? B_ZR2 : B_ZR1], ws.pre_zr[pass], 256, P, h, w, 256, kh, kw, 0)), s));
-        TRY(launch_conv(gemm(conv_desc(ws.hx + 128, 384, 128, nullptr, 0, 0, G[pass ? W_Q2_INP : W_Q1_INP], W[pass ? B_Q2 : B_Q1], ws.pre_q[pass], 128, P, h, w, 128, kh, kw, 0)), s));
+        TRY(launch_conv(gemm(conv_desc(ws.hx + 128, 384, 128, nullptr, 0, 0, G[pass ? W_ZR2_INP : W_ZR1_INP], W[pass ? B_ZR2 : B_ZR1], ws.pre_zr[pass], 256, P, h, w, 256, kh, kw, 0), true, false), s));
+        TRY(launch_conv(gemm(conv_desc(ws.hx + 128, 384, 128, nullptr, 0, 0, G[pass ? W_Q2_INP : W_Q1_INP], W[pass ? B_Q2 : B_Q1], ws.pre_q[pass], 128, P, h, w, 128, kh, kw, 0), true, false), s));
     }
     const float *lv[4] = {ws.lvl[0], ws.lvl[1], ws.lvl[2], ws.lvl[3]};
     const int strips = cdiv(w, F1_CELLS);
@@ -320,12 +359,12 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         // cost more than the overlap gives (106.7 vs 111.5 frames/s in order on one stream, 108.8 with lookup + convf1
         // as one launch): in order on one stream.  fp32 MFMA keeps round 1's grouping (lookup + convf1 in one launch,
         // convc2 + convf2 in one launch).  The per-kernel timing pass and MFTX_RAFT_NOFUSE run everything in order.
-        const ConvF1Args f1{ws.coords1, W[W_CONVF1], W[B_CONVF1], ws.flo1, ws.hx, h, w, strips, P * h * strips};
+        const ConvF1Args f1{ws.coords1, W[W_CONVF1], W[B_CONVF1], ws.flo1, ws.hx, h, w, strips, P * h * strips, SP ? 1 : 0};
         const int f1_blocks = cdiv(f1.n_strips, 2);
         static const bool nofuse = getenv("MFTX_RAFT_NOFUSE") != nullptr;
         static const bool nopair = getenv("MFTX_RAFT_NOPAIR") != nullptr;
-        const mftx_conv_desc c2 = gemm(conv_desc(ws.cor1, 256, 256, nullptr, 0, 0, G[W_CONVC2], W[B_CONVC2], ws.corflo, 256, P, h, w, 192, 3, 3, 1));
-        const mftx_conv_desc f2 = gemm(conv_desc(ws.flo1, 128, 128, nullptr, 0, 0, G[W_CONVF2], W[B_CONVF2], ws.corflo + 192, 256, P, h, w, 64, 3, 3, 1));
+        const mftx_conv_desc c2 = gemm(conv_desc(ws.cor1, 256, 256, nullptr, 0, 0, G[W_CONVC2], W[B_CONVC2], ws.corflo, 256, P, h, w, 192, 3, 3, 1), true, true);
+        const mftx_conv_desc f2 = gemm(conv_desc(ws.flo1, 128, 128, nullptr, 0, 0, G[W_CONVF2], W[B_CONVF2], ws.corflo + 192, 256, P, h, w, 64, 3, 3, 1), true, true);
         static const int fork_env = [] { const char *e = getenv("MFTX_RAFT_FORK"); return e ? atoi(e) : -1; }();   // tuning: 0 never, 1 always
         const bool serial = prof_enabled() || nofuse || (AR == MFTX_ARITH_SPLIT && (fork_env == 0 || (fork_env < 0 && M > 20000)));
         const bool forked = !serial && AR == MFTX_ARITH_SPLIT;
@@ -339,21 +378,21 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
             if (hipEventRecord(r->ev_join, r->side) != hipSuccess) return fail(MFTX_E_STATE, "raft_refine: join event failed");
         }
         if (serial || forked || ondemand) {
-            if (ondemand) TRY(launch_corr_ondemand(fmap1, f2lv, ws.coords1, P, h, w, ws.corr, 324, s));
-            else TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, 324, s));
+            if (ondemand) TRY(launch_corr_ondemand(fmap1, f2lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr, s, SP ? 1 : 0));
+            else TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr, s, SP ? 1 : 0));
             if (!forked) {
                 ProfScope prof(PC_CONVF1, s, 2.0 * M * 128 * 98);
                 hipLaunchKernelGGL(convf1_kernel, dim3(f1_blocks), dim3(256), 0, s, f1);
             }
         } else {
-            const LookupArgs la = make_lookup_args(lv, ws.coords1, P, h, w, ws.corr, 324);
+            const LookupArgs la = make_lookup_args(lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr);
             const int lookup_blocks = cdiv(cdiv(la.cells, 2), LK_WAVES);
             hipLaunchKernelGGL(lookup_convf1_kernel, dim3(lookup_blocks + f1_blocks), dim3(256), 0, s, la, f1,
                                lookup_blocks, f1_blocks);
         }
         TRY(check_launch("lookup + convf1"));
         // motion encoder (core/update.py:152-160)
-        TRY(launch_conv(gemm(conv_desc(ws.corr, 324, 324, nullptr, 0, 0, G[W_CONVC1], W[B_CONVC1], ws.cor1, 256, P, h, w, 256, 1, 1, 1)), s));
+        TRY(launch_conv(gemm(conv_desc(ws.corr, ws.ld_corr, ws.ld_corr, nullptr, 0, 0, G[W_CONVC1], W[B_CONVC1], ws.cor1, 256, P, h, w, 256, 1, 1, 1), true, true), s));
         if (forked) {
             TRY(launch_conv(c2, s));
             if (hipStreamWaitEvent(s, r->ev_join, 0) != hipSuccess) return fail(MFTX_E_STATE, "raft_refine: join failed");
@@ -362,17 +401,17 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         } else {
             TRY(launch_conv_pair(c2, f2, s));      // second layers of the two branches in one launch
         }
-        TRY(launch_conv(gemm(conv_desc(ws.corflo, 256, 256, nullptr, 0, 0, G[W_CONV], W[B_CONV], ws.hx + 256, 384, P, h, w, 126, 3, 3, 1)), s));
+        TRY(launch_conv(gemm(conv_desc(ws.corflo, 256, 256, nullptr, 0, 0, G[W_CONV], W[B_CONV], ws.hx + 256, 384, P, h, w, 126, 3, 3, 1), true, true), s));
         // SepConvGRU (core/update.py:108-123): horizontal 1x5 then vertical 5x1
         for (int pass = 0; pass < 2; ++pass) {
             const int kh = pass ? 5 : 1, kw = pass ? 1 : 5;
-            GruEpilogue g1{1, ws.hx, 384, ws.z, ws.rh};
-            TRY(launch_conv_gru(gemm(conv_desc(ws.hx, 384, 128, ws.hx + 256, 384, 128, G[pass ? W_ZR2_DYN : W_ZR1_DYN], nullptr, ws.z, 128, P, h, w, 256, kh, kw, 2, 1.f, ws.pre_zr[pass], 256)), g1, s));
-            GruEpilogue g2{2, ws.hx, 384, ws.z, ws.rh};
-            TRY(launch_conv_gru(gemm(conv_desc(ws.rh, 128, 128, ws.hx + 256, 384, 128, G[pass ? W_Q2_DYN : W_Q1_DYN], nullptr, ws.hx, 384, P, h, w, 128, kh, kw, 3, 1.f, ws.pre_q[pass], 128)), g2, s));
+            GruEpilogue g1{1, ws.hx, 384, ws.z, ws.rh, SP ? ws.hf : nullptr, 128};
+            TRY(launch_conv_gru(gemm(conv_desc(ws.hx, 384, 128, ws.hx + 256, 384, 128, G[pass ? W_ZR2_DYN : W_ZR1_DYN], nullptr, ws.z, 128, P, h, w, 256, kh, kw, 2, 1.f, ws.pre_zr[pass], 256), true, true), g1, s));
+            GruEpilogue g2{2, ws.hx, 384, ws.z, ws.rh, SP ? ws.hf : nullptr, 128};
+            TRY(launch_conv_gru(gemm(conv_desc(ws.rh, 128, 128, ws.hx + 256, 384, 128, G[pass ? W_Q2_DYN : W_Q1_DYN], nullptr, ws.hx, 384, P, h, w, 128, kh, kw, 3, 1.f, ws.pre_q[pass], 128), true, true), g2, s));
         }
         // flow head (core/update.py:6-14) and coordinate update (core/raft.py:184)
-        TRY(launch_conv(gemm(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, G[W_FH1], W[B_FH1], ws.fh, 256, P, h, w, 256, 3, 3, 1)), s));
+        TRY(launch_conv(gemm(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, G[W_FH1], W[B_FH1], ws.fh, 256, P, h, w, 256, 3, 3, 1), true, false), s));
         // last layer of the flow head, fused with coords1 += delta_flow (core/raft.py:184)
         {
             const mftx_conv_desc fh2 = conv_desc(ws.fh, 256, 256, nullptr, 0, 0, W[W_FH2], W[B_FH2], ws.delta, 2, P, h, w, 2, 3, 3, 0);
@@ -382,18 +421,18 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         if (!last) continue;
         // The upsampling mask is consumed only after the last iteration in test
         // mode (core/raft.py:190-196,234-239), so it is computed once.
-        TRY(launch_conv(gemm(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, G[W_MASK0], W[B_MASK0], ws.fh, 256, P, h, w, 256, 3, 3, 1)), s));
-        TRY(launch_conv(gemm(conv_desc(ws.fh, 256, 256, nullptr, 0, 0, G[W_MASK2], W[B_MASK2], ws.mask, 576, P, h, w, 576, 1, 1, 0, 0.25f)), s));
+        TRY(launch_conv(gemm(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, G[W_MASK0], W[B_MASK0], ws.fh, 256, P, h, w, 256, 3, 3, 1), true, false), s));
+        TRY(launch_conv(gemm(conv_desc(ws.fh, 256, 256, nullptr, 0, 0, G[W_MASK2], W[B_MASK2], ws.mask, 576, P, h, w, 576, 1, 1, 0, 0.25f), false, false), s));
         // occlusion + uncertainty heads (core/update.py:196-214)
         float *flow_lr = flow_lr_out ? flow_lr_out : ws.flow_lr;
         {
             const long long slots = (long long)M * 178;
             ProfScope prof(PC_GLUE, s, 0);
             hipLaunchKernelGGL(ou_gather_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, ws.hx,
-                               ws.corr, ws.coords1, ws.delta, ws.ouin, flow_lr, M, h, w);
+                               ws.corr, ws.ld_corr, ws.coords1, ws.delta, ws.ouin, flow_lr, M, h, w, SP ? 1 : 0);
             TRY(check_launch("ou_gather"));
         }
-        TRY(launch_conv(gemm(conv_desc(ws.ouin, 712, 712, nullptr, 0, 0, G[W_OU1], W[B_OU1], ws.ouh, 256, P, h, w, 256, 3, 3, 1)), s));
+        TRY(launch_conv(gemm(conv_desc(ws.ouin, 712, 712, nullptr, 0, 0, G[W_OU1], W[B_OU1], ws.ouh, 256, P, h, w, 256, 3, 3, 1), true, false), s));
         TRY(launch_conv(conv_desc(ws.ouh, 256, 256, nullptr, 0, 0, W[W_OU2], W[B_OU2], ws.ou, 4, P, h, w, 3, 3, 3, 0), s));
         TRY(launch_convex_upsample(flow_lr, ws.ou, 4, ws.mask, P, h, w, pad_left, pad_right, pad_top, pad_bottom,
                                    flow, occl, sigma, packed, s));

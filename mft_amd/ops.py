@@ -525,13 +525,21 @@ class RaftEngine:
     REGIONS = ("lvl0", "lvl1", "lvl2", "lvl3", "coords1", "corr", "cor1", "corflo", "flo1", "hx", "z", "rh", "fh",
                "delta", "mask", "ouin", "ouh", "ou", "flow_lr")
 
+    #: regions stored in split form when the engine runs the split arithmetic (they feed GEMMs), and their row strides
+    SPLIT_REGIONS = {"corr": 328, "cor1": 256, "corflo": 256, "flo1": 128, "hx": 384, "rh": 128, "ouin": 712}
+
     def region(self, name, P, h, w, cols):
-        """View of a workspace region as [P*h*w, cols] fp32 (parity tests)."""
+        """A workspace region as [P*h*w, cols] fp32 (parity tests): a view, or -- for the regions the split arithmetic
+        keeps in split form -- the decoded values."""
         offs = (C.c_size_t * 19)()
-        check(_lib.load().mftx_raft_workspace_layout(P, h, w, offs, 19), "mftx_raft_workspace_layout")
+        check(_lib.load().mftx_raft_workspace_layout_for(self._h, P, h, w, offs, 19), "mftx_raft_workspace_layout_for")
         off = offs[self.REGIONS.index(name)]
-        n = P * h * w * cols
-        return self._ws[off: off + 4 * n].view(torch.float32).reshape(P * h * w, cols)
+        M = P * h * w
+        if self.arith == ARITH_SPLIT and name in self.SPLIT_REGIONS:
+            ld = self.SPLIT_REGIONS[name]
+            raw = self._ws[off: off + 4 * M * ld].view(torch.float32).reshape(M, ld)
+            return unsplit_activations(raw)[:, :cols]
+        return self._ws[off: off + 4 * M * cols].view(torch.float32).reshape(M, cols)
 
     def refine(self, fmap1, fmap2, net, inp, h, w, iters, pads=(0, 0, 0, 0), want_flow_lr=False, flow_init=None,
                packed=None, planar=True):

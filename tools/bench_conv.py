@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default=None, help="substring of the layer name")
     ap.add_argument("--arith", type=int, default=0, help="0 fp32 MFMA, 1 split fp16")
+    ap.add_argument("--a-split", action="store_true", help="A operand pre-split (split arithmetic)")
+    ap.add_argument("--out-split", action="store_true", help="output written in split form")
     ap.add_argument("--enc", action="store_true", help="the encoder's layer shapes (one 512 x 512 frame) instead")
     args = ap.parse_args()
     P, h, w = args.P, args.h, args.w
@@ -74,18 +76,23 @@ def main():
             M = h * w
         if args.only and args.only not in name:
             continue
-        x = torch.randn(M, cin, device=dev)
-        wt = ops.pack_conv_weight(torch.randn(cout, cin, kh, kw, device=dev) * 0.05)
+        cin_s = -(-cin // 8) * 8 if args.a_split else cin       # split form: whole 8-channel groups (324 -> 328)
+        x = torch.randn(M, cin_s, device=dev)
+        if args.a_split:
+            x = ops.split_activations(x)
+        wt = ops.pack_conv_weight(torch.randn(cout, cin_s, kh, kw, device=dev) * 0.05)
         if args.arith:
             wt = ops.split_weights(wt)
         b = torch.randn(cout, device=dev)
+        osplit = args.out_split and cout > 4
+        obuf = torch.empty(M, -(-cout // 8) * 8, device=dev) if osplit else None
         for _ in range(3):
-            ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu", arith=args.arith)
+            ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu", arith=args.arith, a_split=args.a_split, out_split=osplit, out=obuf)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.reps):
-            ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu", arith=args.arith)
+            ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu", arith=args.arith, a_split=args.a_split, out_split=osplit, out=obuf)
         e1.record()
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) / args.reps * 1e-3
