@@ -467,42 +467,41 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
             woff[i] = (n < p.w_rows && srow + RPP * i < BN) ? (unsigned)n * ktot_b + col4 * 4u : OOB;
         }
     }
-    unsigned acell[RA];                      // this tap's source cell of each row, or OOB (conv halo / M tail)
-    unsigned acur[RA];                       // byte offsets of the NEXT chunk to fetch, +128 B per chunk inside a run
+    // Byte offsets of the NEXT chunk to fetch, per row and channel segment (a0 / a1 of a concatenated input): computed
+    // once per filter tap for both segments, +128 B per chunk after that -- a segment change inside a tap costs nothing
+    // (it used to recompute every row's offset, ~100 instructions in front of the chunk's DMA: with a ring of two chunks
+    // that delay showed in full on the two-segment GRU gate GEMMs, 75 vs 64 us).
+    unsigned acur0[RA], acur1[RA];
     __amdgpu_buffer_rsrc_t rA = rA0;
-    int tap = 0, cc = 0, left = 0;           // next chunk to fetch; chunks left in its run
-    auto next_run = [&]() {                  // (tap, cc) starts a run: offsets from scratch
-        if (cc == 0) {
-            const int dy = tap / p.kw, dx = tap - dy * p.kw;
+    int cc = 0, dy = 0, dx = 0;              // next chunk to fetch: channel chunk, filter tap (dy, dx)
+    // ragged last chunk (channel count not a multiple of 32): this lane's piece lies beyond the last channel -> zeros
+    // (pre-split A: a 16-byte piece holds one half of 8 channels)
+    const bool rag_dead = (cpt - 1) * BK + (PRE ? (col4 & ~7) : col4) >= ctot;
+    auto new_tap = [&]() {
 #pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                const int yy = ay[i] + dy, xx = ax[i] + dx;
-                const bool ok = (yy >= 0) & (yy < p.hin) & (xx >= 0) & (xx < p.win);
-                acell[i] = ok ? (unsigned)(am[i] + yy * p.win + xx) : OOB;
-            }
+        for (int i = 0; i < RA; ++i) {
+            const int yy = ay[i] + dy, xx = ax[i] + dx;
+            const bool ok = (yy >= 0) & (yy < p.hin) & (xx >= 0) & (xx < p.win);
+            const unsigned cell = (unsigned)(am[i] + yy * p.win + xx);
+            acur0[i] = ok ? (cell * (unsigned)p.lda0 + col4) * 4u : OOB;      // conv halo / M tail: out of range -> zeros
+            acur1[i] = ok ? (cell * (unsigned)p.lda1 + col4) * 4u : OOB;
         }
-        const bool seg1 = cc >= seg_cc;      // wave-uniform
-        const bool ragged = cc >= rag_cc;
-        const unsigned lda = (unsigned)(seg1 ? p.lda1 : p.lda0);
-        const unsigned cb = (unsigned)(cc * BK - (seg1 ? p.c0 : 0)) * 4u;
-        // ragged chunk: zero-fill beyond the last channel (pre-split A: a 16-byte piece holds one half of 8 channels)
-        const bool lane_ok = !ragged || cc * BK + (PRE ? (col4 & ~7) : col4) < ctot;
-        rA = seg1 ? rA1 : rA0;
-#pragma unroll
-        for (int i = 0; i < RA; ++i)
-            acur[i] = (acell[i] != OOB && lane_ok) ? (acell[i] * lda + col4) * 4u + cb : OOB;
-        const int stop = ragged ? cpt : (seg1 ? rag_cc : (seg_cc < rag_cc ? seg_cc : rag_cc));
-        left = stop - cc;
     };
-    // global -> LDS (DMA) for the next chunk, in RA + RB pieces of 1 KiB per wave: begin (offsets of a new run),
+    // global -> LDS (DMA) for the next chunk, in RA + RB pieces of 1 KiB per wave: begin (a new tap's offsets),
     // the pieces -- issued one by one between the MFMAs of the split-arithmetic loop: eight of them back to back
     // fill the address unit's queue and hold the wave (and its MFMAs) for most of a microsecond -- and end (advance)
-    auto fetch_begin = [&]() { if (left == 0) next_run(); };
+    auto fetch_begin = [&]() {
+        if (cc == 0) new_tap();
+        rA = cc >= seg_cc ? rA1 : rA0;       // (wave-uniform)
+    };
     auto fetch_piece = [&](int buf, int k) {
         if (k < RA) {
+            const bool seg1 = cc >= seg_cc;
+            unsigned off = seg1 ? acur1[k] : acur0[k];
+            if (cc >= rag_cc && rag_dead) off = OOB;
             if (MFTX_ABLATE != 5 && (MFTX_ABLATE != 6 || cc % 5 == 0) && (BM % RPP == 0 || wid * 8 + RPP * k < BM))
-                buf_load_lds(rA, a_dst + buf * BM * LDK + RPP * k * LDK, acur[k]);
-            acur[k] += BK * 4u;              // an OOB offset stays out of range
+                buf_load_lds(rA, a_dst + buf * BM * LDK + RPP * k * LDK, off);
+            if (seg1) acur1[k] += BK * 4u; else acur0[k] += BK * 4u;     // an OOB offset stays out of range
         } else {
             const int i = k - RA;
             if (MFTX_ABLATE != 4 && (BN % RPP == 0 || wid * 8 + RPP * i < BN))
@@ -511,8 +510,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         }
     };
     auto fetch_end = [&]() {
-        --left;
-        if (++cc == cpt) { cc = 0; ++tap; }
+        if (++cc == cpt) {
+            cc = 0;
+            if (++dx == p.kw) { dx = 0; ++dy; }
+        }
     };
     auto fetch = [&](int buf) {
         fetch_begin();
@@ -822,9 +823,44 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         const bool any_add = pre_add || p.residual_mode == 1;
         // (an output whose rows are not 16-byte aligned -- ldo = 126 -- is stored value by value)
         const bool vec_out = EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q || ((p.ldo & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0);
+        // software pipeline over the wave's TM x TN tiles: the global reads (addend, z, h) of tile k + 1 are issued
+        // before tile k is staged, combined and stored -- per tile they are a full memory round trip, and a z|r
+        // launch moves 73 MB through its epilogue (addend + h in, z + r h out) against 29 MB for a plain layer
+        struct TileLoads { f32x4 add[4], a0[4], a1[4]; };
+        TileLoads ld[2];
+        auto tile_nb = [&](int j) { return n0 + wn * TN * 32 + j * 32 + c4 * 4; };          // first of this lane's four columns
+        auto tile_mb = [&](int i) { return m0 + wm * TM * 32 + i * 32 + rq; };
+        auto issue_loads = [&](int k, TileLoads &L) {
+            const int j = k / TM, i = k % TM;
+            const int nb = tile_nb(j), mb = tile_mb(i);
+            const bool full = nb + 3 < p.N;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nb = n0 + wn * TN * 32 + j * 32 + c4 * 4;          // first of this lane's four columns
+            for (int t = 0; t < 4; ++t) {
+                const long long m = mb + t * 8;
+                L.add[t] = L.a0[t] = L.a1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m >= p.M || nb >= p.N) continue;
+                if (full) {
+                    if (any_add) L.add[t] = *reinterpret_cast<const f32x4 *>(p.addend + m * p.ld_addend + nb);
+                    if constexpr (EPI == EPI_GRU_ZR) {
+                        if (nb >= 128) L.a1[t] = *reinterpret_cast<const f32x4 *>(p.hf + m * p.ld_hf + (nb - 128));
+                    } else if constexpr (EPI == EPI_GRU_Q) {
+                        L.a0[t] = *reinterpret_cast<const f32x4 *>(p.z + m * 128 + nb);
+                        L.a1[t] = *reinterpret_cast<const f32x4 *>(p.hf + m * p.ld_hf + nb);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (nb + e < p.N && any_add) L.add[t][e] = p.addend[m * p.ld_addend + nb + e];
+                }
+            }
+        };
+        issue_loads(0, ld[0]);
+#pragma unroll
+        for (int k = 0; k < TM * TN; ++k) {
+            const int j = k / TM, i = k % TM;
+            if (k + 1 < TM * TN) issue_loads(k + 1, ld[(k + 1) & 1]);
+            const TileLoads &L = ld[k & 1];
+            const int nb = tile_nb(j);
             const bool full = nb + 3 < p.N;
             f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
             if (p.bias != nullptr) {
@@ -833,79 +869,58 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) bias4[e] = nb + e < p.N ? p.bias[nb + e] : 0.f;
             }
+            {
+                float *w = st + (4 * (lane >> 5)) * 32 + (lane & 31);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                {
-                    float *w = st + (4 * (lane >> 5)) * 32 + (lane & 31);
+                for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2)) * 32] = acc[i][j][r];
+            }
+            const int mb = tile_mb(i);
+            f32x4 v[4];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2)) * 32] = acc[i][j][r];
-                }
-                const int mb = m0 + wm * TM * 32 + i * 32 + rq;
-                f32x4 v[4], add[4], a0[4], a1[4];
+            for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const f32x4 *>(st + (t * 8 + rq) * 32 + c4 * 4);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    v[t] = *reinterpret_cast<const f32x4 *>(st + (t * 8 + rq) * 32 + c4 * 4);
-                    const long long m = mb + t * 8;
-                    add[t] = a0[t] = a1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (m >= p.M || nb >= p.N) continue;
-                    if (full) {
-                        if (any_add) add[t] = *reinterpret_cast<const f32x4 *>(p.addend + m * p.ld_addend + nb);
-                        if constexpr (EPI == EPI_GRU_ZR) {
-                            if (nb >= 128) a1[t] = *reinterpret_cast<const f32x4 *>(p.hf + m * p.ld_hf + (nb - 128));
-                        } else if constexpr (EPI == EPI_GRU_Q) {
-                            a0[t] = *reinterpret_cast<const f32x4 *>(p.z + m * 128 + nb);
-                            a1[t] = *reinterpret_cast<const f32x4 *>(p.hf + m * p.ld_hf + nb);
-                        }
+            for (int t = 0; t < 4; ++t) {
+                const long long m = mb + t * 8;
+                if (m >= p.M || nb >= p.N) continue;
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float sv = v[t][e] + bias4[e];
+                    if (pre_add) sv += L.add[t][e];
+                    if constexpr (EPI == EPI_RELU) {
+                        o[e] = fmaxf(sv, 0.f) * p.out_scale;
+                    } else if constexpr (EPI == EPI_GRU_ZR) {   // [z | r] gates; r is folded into r*h
+                        const float g = fast_sigmoid(sv);
+                        o[e] = nb < 128 ? g : g * L.a1[t][e];
+                    } else if constexpr (EPI == EPI_GRU_Q) {    // candidate q, h <- (1-z) h + z q
+                        o[e] = (1.f - L.a0[t][e]) * L.a1[t][e] + L.a0[t][e] * fast_tanh(sv);
                     } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (nb + e < p.N && any_add) add[t][e] = p.addend[m * p.ld_addend + nb + e];
+                        float g = act_fn(sv, p.act) * p.out_scale;
+                        if (p.residual_mode == 1) g = fmaxf(g + L.add[t][e], 0.f);
+                        o[e] = g;
                     }
                 }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const long long m = mb + t * 8;
-                    if (m >= p.M || nb >= p.N) continue;
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float sv = v[t][e] + bias4[e];
-                        if (pre_add) sv += add[t][e];
-                        if constexpr (EPI == EPI_RELU) {
-                            o[e] = fmaxf(sv, 0.f) * p.out_scale;
-                        } else if constexpr (EPI == EPI_GRU_ZR) {   // [z | r] gates; r is folded into r*h
-                            const float g = fast_sigmoid(sv);
-                            o[e] = nb < 128 ? g : g * a1[t][e];
-                        } else if constexpr (EPI == EPI_GRU_Q) {    // candidate q, h <- (1-z) h + z q
-                            o[e] = (1.f - a0[t][e]) * a1[t][e] + a0[t][e] * fast_tanh(sv);
-                        } else {
-                            float g = act_fn(sv, p.act) * p.out_scale;
-                            if (p.residual_mode == 1) g = fmaxf(g + add[t][e], 0.f);
-                            o[e] = g;
-                        }
-                    }
-                    if constexpr (EPI == EPI_GRU_ZR) {
-                        if (nb < 128) *reinterpret_cast<f32x4 *>(p.z + m * 128 + nb) = o;          // z: fp32, read by the q epilogue only
-                        else if (p.out_split) store_split4(p.rh + m * 128, nb - 128, o);           // r h: an A operand of the q GEMM
-                        else *reinterpret_cast<f32x4 *>(p.rh + m * 128 + (nb - 128)) = o;
-                        continue;
-                    }
-                    if constexpr (EPI == EPI_GRU_Q) {
-                        *reinterpret_cast<f32x4 *>(p.hf + m * p.ld_hf + nb) = o;
-                        if (p.out_split) store_split4(p.hx + m * p.ld_hx, nb, o);
-                        continue;
-                    }
-                    if (p.out_split) {
-                        store_split4(out + m * p.ldo, nb, o, full ? 4 : p.N - nb);
-                        continue;
-                    }
-                    float *dst = out + m * p.ldo + nb;
-                    if (full && vec_out) *reinterpret_cast<f32x4 *>(dst) = o;
-                    else
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (nb + e < p.N) dst[e] = o[e];
+                if constexpr (EPI == EPI_GRU_ZR) {
+                    if (nb < 128) *reinterpret_cast<f32x4 *>(p.z + m * 128 + nb) = o;          // z: fp32, read by the q epilogue only
+                    else if (p.out_split) store_split4(p.rh + m * 128, nb - 128, o);           // r h: an A operand of the q GEMM
+                    else *reinterpret_cast<f32x4 *>(p.rh + m * 128 + (nb - 128)) = o;
+                    continue;
                 }
+                if constexpr (EPI == EPI_GRU_Q) {
+                    *reinterpret_cast<f32x4 *>(p.hf + m * p.ld_hf + nb) = o;
+                    if (p.out_split) store_split4(p.hx + m * p.ld_hx, nb, o);
+                    continue;
+                }
+                if (p.out_split) {
+                    store_split4(out + m * p.ldo, nb, o, full ? 4 : p.N - nb);
+                    continue;
+                }
+                float *dst = out + m * p.ldo + nb;
+                if (full && vec_out) *reinterpret_cast<f32x4 *>(dst) = o;
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (nb + e < p.N) dst[e] = o[e];
             }
         }
         continue;
@@ -1036,6 +1051,7 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
             case 0: return launch_cfg<128, 128, 2, 2, EPI, 32, AR_PRESPLIT, 2>(a, batch, s, cat);
             case 6: return launch_cfg<128, 128, 4, 2, EPI, 32, AR_PRESPLIT, 4>(a, batch, s, cat);
             case 10: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_PRESPLIT, 2>(a, batch, s, cat);
+            case 12: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
             default: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
         }
     }
