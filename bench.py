@@ -264,10 +264,14 @@ def run_frames(tracker, frames, first, count, window):
             HOST_MS.append(1e3 * (time.perf_counter() - t0))
             pairs.append(len(tracker.last_pairs))
         return pairs
+    # equal windows of at most `window` frames (20 frames, window 8: 7 + 7 + 6, not 8 + 8 + 4: every rank keeps a
+    # full batch in every window)
+    n_win = -(-count // window)
+    sizes = [count // n_win + (1 if k < count % n_win else 0) for k in range(n_win)]
     i, got = first, 0
-    while i < first + count:
-        n = min(window, first + count - i)
-        nxt = frames[i + n: min(i + 2 * n, first + count)]          # the following window: its encoders start early
+    for k, n in enumerate(sizes):
+        nn = sizes[k + 1] if k + 1 < n_win else 0
+        nxt = frames[i + n: i + n + nn]                              # the following window: its encoders start early
         # pipelined: the call hands back the PREVIOUS window's results; this window's result exchange and selections
         # overlap the next window's flow batches
         got += len(tracker.track_window(frames[i: i + n], next_imgs=nxt, defer=True))

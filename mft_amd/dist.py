@@ -99,8 +99,8 @@ class WindowSharder:
         for ``_finish_feature_exchange`` (None: nothing to exchange)."""
         flower = tracker.flower
         G, L = self.world_size, len(frame_ids)
-        if not hasattr(flower, "encode_packed") or L < G:
-            return None              # a reference-style plugin, or fewer frames than ranks: everyone encodes what it needs
+        if not hasattr(flower, "encode_packed") or 2 * L < G:
+            return None              # a reference-style plugin, or far fewer frames than ranks (the online mode, L = 1): everyone encodes what it needs
         stream = None
         if side and hasattr(flower, "ensure_encode_stream"):
             stream = flower.ensure_encode_stream()   # all encoder work of the plugin is serialised on this stream
@@ -115,6 +115,8 @@ class WindowSharder:
                     send = torch.empty((slots,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
                 send[s_] = packed
                 self.stats["encoded"] += 1
+            if send is None:         # a window shorter than the world: this rank owns none of its frames, its slot is not read
+                send = torch.empty((slots, flower.packed_numel(imgs[0])), dtype=torch.float32, device=tracker.device)
             recv = torch.empty((G,) + tuple(send.shape), dtype=send.dtype, device=send.device)
             # (NCCL orders the collective behind the work already on the CURRENT stream -- the side stream here)
             work = dist.all_gather_into_tensor(recv.view(G * send.shape[0], *send.shape[1:]), send, group=self.group,

@@ -161,6 +161,11 @@ class RAFTWrapper:
             buf.record_stream(main)
         return buf, (h, w)
 
+    def packed_numel(self, img_bgr):
+        """Floats in the buffer ``encode_packed`` produces for a frame of this size."""
+        h, w, _ = self._geometry(*img_bgr.shape[:2])
+        return h * w * 512
+
     def adopt_packed(self, frame_id, buf, img_bgr):
         """Install features produced by ``encode_packed`` (here or on another rank) for ``frame_id``."""
         H0, W0 = img_bgr.shape[:2]

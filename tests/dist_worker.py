@@ -27,6 +27,9 @@ class ExchangingFlower:
         self.encoded += 1
         return torch.full((6,), float(gi.decode_id(img))), (1, 1)
 
+    def packed_numel(self, img):
+        return 6
+
     def adopt_packed(self, frame_id, buf, img):
         assert int(buf[0]) == gi.decode_id(img) == frame_id
         self.features[frame_id] = buf
