@@ -162,9 +162,9 @@ size_t mftx_raft_workspace_bytes_for(const mftx_raft *r, int P, int h, int w);
  * cor1, corflo, flo1, hx, z, rh, fh, delta, mask, ouin, ouh, ou, flow_lr: after
  * mftx_raft_refine they hold the intermediates of the last iteration (tests). */
 int mftx_raft_workspace_layout(int P, int h, int w, size_t *offsets, int n);
-/* The same for a handle's current mode.  With MFTX_ARITH_SPLIT the regions that feed GEMMs -- corr (row stride 328),
- * cor1, corflo, flo1, hx, rh, ouin -- hold their values in SPLIT form (mftx_conv_desc.a_split: every 8 channels as
- * [hi x 8 | lo x 8] fp16, value = hi + lo / 2048); the others (z, fh, delta, mask, ouh, ou, coords1, flow_lr) are fp32. */
+/* The same for a handle's current mode.  With MFTX_ARITH_SPLIT the regions that feed GEMMs -- cor1, corflo, flo1, hx,
+ * rh, ouin -- hold their values in SPLIT form (mftx_conv_desc.a_split: every 8 channels as
+ * [hi x 8 | lo x 8] fp16, value = hi + lo / 2048); the others (corr, z, fh, delta, mask, ouh, ou, coords1, flow_lr) are fp32. */
 int mftx_raft_workspace_layout_for(const mftx_raft *r, int P, int h, int w, size_t *offsets, int n);
 /* fmap1/fmap2: [P][h*w][256]; net, inp: [P][h*w][128] (tanh / relu already
  * applied).  flow_init (optional, may be NULL): [P*h*w][2] initial flow at 1/8

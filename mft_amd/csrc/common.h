@@ -123,11 +123,11 @@ int launch_conv_small(const mftx_conv_desc &d, hipStream_t s, float *accum = nul
 int launch_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, int w, float *const lvl[4], hipStream_t s,
                         float *f2_split = nullptr);
 int launch_corr_lookup(const float *const lvl[4], const float *coords, int P, int h, int w,
-                       float *out, int ld_out, hipStream_t s, int out_split = 0);
+                       float *out, int ld_out, hipStream_t s);
 // on-demand correlation (csrc/corr_ondemand.hip): pooled feature pyramid + lookup without a stored volume
 int launch_fmap_pyramid(const float *f2, int P, int C, int h, int w, float *const lvl[3], hipStream_t s);
 int launch_corr_ondemand(const float *f1, const float *const f2lvl[4], const float *coords, int P, int h, int w,
-                         float *out, int ld_out, hipStream_t s, int out_split = 0);
+                         float *out, int ld_out, hipStream_t s);
 int launch_convex_upsample(const float *flow_lr, const float *ou, int ld_ou, const float *mask,
                            int P, int h, int w, int pl, int pr, int pt, int pb,
                            float *flow, float *occl, float *sigma, float *packed, hipStream_t s);

@@ -47,7 +47,6 @@ struct OnDemandArgs {
     int ld_out, cells, n_per_img;
     int hl[4], wl[4];
     float scale;
-    int out_split;              // as LookupArgs::out_split
 };
 
 __global__ __launch_bounds__(64 * LK_WAVES) void corr_ondemand_kernel(OnDemandArgs p) {
@@ -141,15 +140,11 @@ __global__ __launch_bounds__(64 * LK_WAVES) void corr_ondemand_kernel(OnDemandAr
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int o = lane + 64 * j;
-            const bool live = j < 5 || o < 324;
-            float val = 0.f;
-            if (live) {
+            if (j < 5 || o < 324) {
                 const float4 wq = *reinterpret_cast<const float4 *>(tp + 4 * LK_LVL + o_lvl[j] * 4);
                 const float *t4 = tp + o_ab[j];
-                val = t4[0] * wq.x + t4[1] * wq.y + t4[LK_ROW] * wq.z + t4[LK_ROW + 1] * wq.w;
+                dst[o] = t4[0] * wq.x + t4[1] * wq.y + t4[LK_ROW] * wq.z + t4[LK_ROW + 1] * wq.w;
             }
-            if (p.out_split) store_split_pairwise(dst, o, val, j < 5 || o < 328);
-            else if (live) dst[o] = val;
         }
     }
 }
@@ -168,9 +163,9 @@ int launch_fmap_pyramid(const float *f2, int P, int C, int h, int w, float *cons
 }
 
 int launch_corr_ondemand(const float *f1, const float *const f2lvl[4], const float *coords, int P, int h, int w,
-                         float *out, int ld_out, hipStream_t s, int out_split) {
+                         float *out, int ld_out, hipStream_t s) {
     OnDemandArgs a;
-    a.f1 = f1; a.coords = coords; a.out = out; a.ld_out = ld_out; a.out_split = out_split;
+    a.f1 = f1; a.coords = coords; a.out = out; a.ld_out = ld_out;
     a.cells = P * h * w; a.n_per_img = h * w;
     for (int l = 0; l < 4; ++l) { a.f2[l] = f2lvl[l]; a.hl[l] = h >> l; a.wl[l] = w >> l; }
     if ((long long)h * w * 1024 > 0x7fffffffLL) return fail(MFTX_E_ARG, "corr_lookup_ondemand: feature map exceeds 2 GiB");

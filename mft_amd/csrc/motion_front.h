@@ -26,7 +26,6 @@ struct LookupArgs {
     unsigned hbwb[2];       // blocks per query of levels 0, 1
     long long stride[4];    // floats per query cell
     int ablate;     // tuning only (MFTX_LOOKUP_ABLATE): 1 no tap loads, 2 no stores, 3 neither
-    int out_split;  // write the 324 features in split form (common.h; ld_out >= 328: channels 324..327 are written as zeros)
 };
 
 inline LookupArgs make_lookup_args(const float *const lvl[4], const float *coords, int P, int h, int w, float *out,
@@ -35,7 +34,7 @@ inline LookupArgs make_lookup_args(const float *const lvl[4], const float *coord
     const PyramidLayout L = pyramid_layout(h, w);
     for (int l = 0; l < 4; ++l) { a.lvl[l] = lvl[l]; a.hl[l] = L.h[l]; a.wl[l] = L.w[l]; a.stride[l] = L.stride[l]; }
     for (int l = 0; l < 2; ++l) { a.wb[l] = L.wb[l]; a.hbwb[l] = (unsigned)(L.hb[l] * L.wb[l]); }
-    a.coords = coords; a.out = out; a.ld_out = ld_out; a.out_split = 0;
+    a.coords = coords; a.out = out; a.ld_out = ld_out;
     a.cells = P * h * w; a.n_per_img = h * w;
     static const int ablate = [] { const char *e = getenv("MFTX_LOOKUP_ABLATE"); return e ? atoi(e) : 0; }();
     a.ablate = ablate;
@@ -161,17 +160,13 @@ __device__ __forceinline__ void lookup_block_body(const LookupArgs &p, int block
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const int o = lane + 64 * j;
-                const bool live = (j < 5 || o < 324) && (!(p.ablate & 2) || (j == 0 && lane == 0));
-                float val = 0.f;
-                if (live) {
+                if ((j < 5 || o < 324) && (!(p.ablate & 2) || (j == 0 && lane == 0))) {
                     const int l = o_lvl[j];
                     const float4 wq = *reinterpret_cast<const float4 *>(tp + 4 * LK_LVL + l * 4);
                     const float *t4 = tp + o_ab[j] + (l == 0 ? xo[u][0] : l == 1 ? xo[u][1] : 0);
                     const float v00 = t4[0], v01 = t4[1], v10 = t4[LK_ROW], v11 = t4[LK_ROW + 1];
-                    val = v00 * wq.x + v01 * wq.y + v10 * wq.z + v11 * wq.w;
+                    dst[o] = v00 * wq.x + v01 * wq.y + v10 * wq.z + v11 * wq.w;
                 }
-                if (p.out_split) store_split_pairwise(dst, o, val, j < 5 || o < 328);     // (wave-uniform branch; 324..327: zeros)
-                else if (live) dst[o] = val;
             }
         }
     }

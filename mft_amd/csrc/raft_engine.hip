@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void lookup_convf1_kernel(LookupArgs lp, ConvF
 // OU input [net128 | inp128 | corr324 | flow2 | delta2 | motion128] = 712
 // (core/update.py:197), flow = coords1 - grid AFTER the last update
 // (core/raft.py:199-206); also emits flow_lr for the upsampler.
-// split != 0: hx and corr ([M][ld_corr]) are in split form and so is ouin -- four channels are one half group
-// (common.h: load_split4 / store_split4v; decode + encode reproduces the halves exactly)
+// split != 0: hx is in split form and so is ouin -- four channels are one half group (common.h: load_split4 /
+// store_split4v; decode + encode reproduces the halves exactly); corr is fp32 in either mode
 __global__ void ou_gather_kernel(const float *__restrict__ hx, const float *__restrict__ corr, int ld_corr,
                                  const float *__restrict__ coords1, const float *__restrict__ delta,
                                  float *__restrict__ ouin, float *__restrict__ flow_lr, int M, int h, int w, int split) {
@@ -82,7 +82,7 @@ __global__ void ou_gather_kernel(const float *__restrict__ hx, const float *__re
     float4 v;
     if (split) {
         if (q < 64) v = load_split4(hx + (long long)m * 384, 4 * q);
-        else if (q < 145) v = load_split4(corr + (long long)m * ld_corr, 4 * (q - 64));
+        else if (q < 145) v = reinterpret_cast<const float4 *>(corr + (long long)m * ld_corr)[q - 64];
         else if (q == 145) {
             const int rem = m % (h * w);
             const float fx = coords1[2 * (long long)m] - (float)(rem % w);
@@ -126,7 +126,7 @@ struct Workspace {
     float *pre_zr[2], *pre_q[2];   // inp part of the GRU gate convolutions (+ bias), per pass
     float *f2s;                    // split form of fmap2 (B operand of the volume GEMM in split arithmetic)
     float *hf;                     // split arithmetic: fp32 copy of h [M][128] (hx itself is in split form)
-    int ld_corr;                   // 324, or 328 when corr is stored in split form (whole 8-channel groups)
+    int ld_corr;                   // 324: the lookup's features stay fp32 (the lookup is HBM-bound; convc1 splits them in registers)
     size_t bytes;
 };
 
@@ -143,7 +143,7 @@ static Workspace carve(void *base, int P, int h, int w, bool ondemand = false, b
     for (int l = 0; l < 4; ++l) ws.lvl[l] = take(ondemand ? 0 : M * (size_t)L.stride[l]);
     for (int l = 1; l < 4; ++l) ws.f2l[l - 1] = take(ondemand ? (size_t)P * (h >> l) * (w >> l) * 256 : 0);
     ws.coords1 = take(M * 2);
-    ws.ld_corr = split ? 328 : 324;
+    ws.ld_corr = 324;
     ws.corr = take(M * ws.ld_corr);
     ws.cor1 = take(M * 256);
     ws.corflo = take(M * 256);
@@ -378,8 +378,10 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
             if (hipEventRecord(r->ev_join, r->side) != hipSuccess) return fail(MFTX_E_STATE, "raft_refine: join event failed");
         }
         if (serial || forked || ondemand) {
-            if (ondemand) TRY(launch_corr_ondemand(fmap1, f2lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr, s, SP ? 1 : 0));
-            else TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr, s, SP ? 1 : 0));
+            // (the 324 features stay fp32: written in split form the lookup takes 31 instead of 27 us, more than convc1
+            // gains from a pre-split A -- and its HBM roofline is the one with a north-star target)
+            if (ondemand) TRY(launch_corr_ondemand(fmap1, f2lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr, s));
+            else TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr, s));
             if (!forked) {
                 ProfScope prof(PC_CONVF1, s, 2.0 * M * 128 * 98);
                 hipLaunchKernelGGL(convf1_kernel, dim3(f1_blocks), dim3(256), 0, s, f1);
@@ -392,7 +394,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         }
         TRY(check_launch("lookup + convf1"));
         // motion encoder (core/update.py:152-160)
-        TRY(launch_conv(gemm(conv_desc(ws.corr, ws.ld_corr, ws.ld_corr, nullptr, 0, 0, G[W_CONVC1], W[B_CONVC1], ws.cor1, 256, P, h, w, 256, 1, 1, 1), true, true), s));
+        TRY(launch_conv(gemm(conv_desc(ws.corr, ws.ld_corr, ws.ld_corr, nullptr, 0, 0, G[W_CONVC1], W[B_CONVC1], ws.cor1, 256, P, h, w, 256, 1, 1, 1), false, true), s));
         if (forked) {
             TRY(launch_conv(c2, s));
             if (hipStreamWaitEvent(s, r->ev_join, 0) != hipSuccess) return fail(MFTX_E_STATE, "raft_refine: join failed");

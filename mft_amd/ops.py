@@ -526,7 +526,7 @@ class RaftEngine:
                "delta", "mask", "ouin", "ouh", "ou", "flow_lr")
 
     #: regions stored in split form when the engine runs the split arithmetic (they feed GEMMs), and their row strides
-    SPLIT_REGIONS = {"corr": 328, "cor1": 256, "corflo": 256, "flo1": 128, "hx": 384, "rh": 128, "ouin": 712}
+    SPLIT_REGIONS = {"cor1": 256, "corflo": 256, "flo1": 128, "hx": 384, "rh": 128, "ouin": 712}
 
     def region(self, name, P, h, w, cols):
         """A workspace region as [P*h*w, cols] fp32 (parity tests): a view, or -- for the regions the split arithmetic
