@@ -405,7 +405,7 @@ def main():
             "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.arith == "fp32" else
             "f32 (update-block products as split fp16 x 3 on the fp16 matrix cores, fp32 accumulation; error per product "
-            "<= ~2^-23, see DESIGN.md section 3 and parity below)",
+            "<= ~2^-23, see DESIGN.md section 4 and parity below)",
             "arith": args.arith, "data": "synthetic",
             "config": {"workload": f"MFT.track on synthetic {args.height}x{args.width} video, deltas "
                                    f"[inf,1,2,4,8,16,32], {min(timed_pairs)}/{np.mean(timed_pairs):.2f}/{max(timed_pairs)} "
