@@ -229,7 +229,10 @@ __device__ __forceinline__ void wait_vmcnt() {   // counted wait: leaves N LDS-D
 #ifndef MFTX_MINW1
 #define MFTX_MINW1 4      // 128 registers: nothing spills; 5 (96 registers, spills in the GRU epilogues) measures 0.5 % slower
 #endif
-constexpr int min_waves(int wave_tiles) { return wave_tiles == 1 ? MFTX_MINW1 : wave_tiles == 2 ? 3 : 2; }
+constexpr int min_waves(int wave_tiles, int epi = 0) {
+    // (the q-gate epilogue keeps z and h of a tile in registers: at 128 it spills 34 of them)
+    return wave_tiles == 1 ? (epi == 3 ? 3 : MFTX_MINW1) : wave_tiles == 2 ? 3 : 2;
+}
 // split arithmetic: two accumulator sets and raw + split fragments
 constexpr int min_waves_split(int wave_tiles, int waves) { return waves == 8 ? 2 : wave_tiles == 1 ? 3 : 2; }
 
@@ -467,41 +470,78 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
             woff[i] = (n < p.w_rows && srow + RPP * i < BN) ? (unsigned)n * ktot_b + col4 * 4u : OOB;
         }
     }
-    // Byte offsets of the NEXT chunk to fetch, per row and channel segment (a0 / a1 of a concatenated input): computed
-    // once per filter tap for both segments, +128 B per chunk after that -- a segment change inside a tap costs nothing
-    // (it used to recompute every row's offset, ~100 instructions in front of the chunk's DMA: with a ring of two chunks
-    // that delay showed in full on the two-segment GRU gate GEMMs, 75 vs 64 us).
-    unsigned acur0[RA], acur1[RA];
+    // Byte offsets of the NEXT chunk to fetch.
+    //  * split arithmetic: per row and channel segment (a0 / a1 of a concatenated input), computed once per filter tap
+    //    for both segments, +128 B per chunk after that -- a segment change inside a tap costs nothing (recomputing
+    //    every row's offset there, ~100 instructions in front of the chunk's DMA, showed in full with a ring of two
+    //    chunks and 0.4 us of matrix work per chunk);
+    //  * fp32 MFMA (1 us of matrix work per chunk hides it; fewer instructions and registers per chunk count): per
+    //    RUN -- a tap's chunks form up to three runs inside which every offset advances by 128 B: segment 0, segment 1,
+    //    and the last, partly zero-filled chunk when the channel count is not a multiple of 32.
+    unsigned acur0[RA], acur1[SPLIT ? RA : 1];
+    unsigned acell[SPLIT ? 1 : RA];          // fp32: this tap's source cell of each row, or OOB (conv halo / M tail)
     __amdgpu_buffer_rsrc_t rA = rA0;
-    int cc = 0, dy = 0, dx = 0;              // next chunk to fetch: channel chunk, filter tap (dy, dx)
+    int cc = 0, dy = 0, dx = 0, left = 0;    // next chunk to fetch: channel chunk, filter tap (dy, dx); fp32: chunks left in the run
     // ragged last chunk (channel count not a multiple of 32): this lane's piece lies beyond the last channel -> zeros
     // (pre-split A: a 16-byte piece holds one half of 8 channels)
     const bool rag_dead = (cpt - 1) * BK + (PRE ? (col4 & ~7) : col4) >= ctot;
-    auto new_tap = [&]() {
+    auto new_tap = [&]() {                   // split arithmetic
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int yy = ay[i] + dy, xx = ax[i] + dx;
             const bool ok = (yy >= 0) & (yy < p.hin) & (xx >= 0) & (xx < p.win);
             const unsigned cell = (unsigned)(am[i] + yy * p.win + xx);
             acur0[i] = ok ? (cell * (unsigned)p.lda0 + col4) * 4u : OOB;      // conv halo / M tail: out of range -> zeros
-            acur1[i] = ok ? (cell * (unsigned)p.lda1 + col4) * 4u : OOB;
+            if constexpr (SPLIT) acur1[i] = ok ? (cell * (unsigned)p.lda1 + col4) * 4u : OOB;
         }
     };
-    // global -> LDS (DMA) for the next chunk, in RA + RB pieces of 1 KiB per wave: begin (a new tap's offsets),
+    auto next_run = [&]() {                  // fp32 MFMA: (tap, cc) starts a run, offsets from scratch
+        if constexpr (!SPLIT) {
+            if (cc == 0) {
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    const int yy = ay[i] + dy, xx = ax[i] + dx;
+                    const bool ok = (yy >= 0) & (yy < p.hin) & (xx >= 0) & (xx < p.win);
+                    acell[i] = ok ? (unsigned)(am[i] + yy * p.win + xx) : OOB;
+                }
+            }
+            const bool seg1 = cc >= seg_cc;      // wave-uniform
+            const bool ragged = cc >= rag_cc;
+            const unsigned lda = (unsigned)(seg1 ? p.lda1 : p.lda0);
+            const unsigned cb = (unsigned)(cc * BK - (seg1 ? p.c0 : 0)) * 4u;
+            const bool lane_ok = !ragged || !rag_dead;
+            rA = seg1 ? rA1 : rA0;
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                acur0[i] = (acell[i] != OOB && lane_ok) ? (acell[i] * lda + col4) * 4u + cb : OOB;
+            const int stop = ragged ? cpt : (seg1 ? rag_cc : (seg_cc < rag_cc ? seg_cc : rag_cc));
+            left = stop - cc;
+        }
+    };
+    // global -> LDS (DMA) for the next chunk, in RA + RB pieces of 1 KiB per wave: begin (a new tap's / run's offsets),
     // the pieces -- issued one by one between the MFMAs of the split-arithmetic loop: eight of them back to back
     // fill the address unit's queue and hold the wave (and its MFMAs) for most of a microsecond -- and end (advance)
     auto fetch_begin = [&]() {
-        if (cc == 0) new_tap();
-        rA = cc >= seg_cc ? rA1 : rA0;       // (wave-uniform)
+        if constexpr (SPLIT) {
+            if (cc == 0) new_tap();
+            rA = cc >= seg_cc ? rA1 : rA0;       // (wave-uniform)
+        } else {
+            if (left == 0) next_run();
+        }
     };
     auto fetch_piece = [&](int buf, int k) {
         if (k < RA) {
-            const bool seg1 = cc >= seg_cc;
-            unsigned off = seg1 ? acur1[k] : acur0[k];
-            if (cc >= rag_cc && rag_dead) off = OOB;
+            unsigned off = acur0[k];
+            if constexpr (SPLIT) {
+                const bool seg1 = cc >= seg_cc;
+                off = seg1 ? acur1[k] : acur0[k];
+                if (cc >= rag_cc && rag_dead) off = OOB;
+                if (seg1) acur1[k] += BK * 4u; else acur0[k] += BK * 4u;     // an OOB offset stays out of range
+            } else {
+                acur0[k] += BK * 4u;
+            }
             if (MFTX_ABLATE != 5 && (MFTX_ABLATE != 6 || cc % 5 == 0) && (BM % RPP == 0 || wid * 8 + RPP * k < BM))
                 buf_load_lds(rA, a_dst + buf * BM * LDK + RPP * k * LDK, off);
-            if (seg1) acur1[k] += BK * 4u; else acur0[k] += BK * 4u;     // an OOB offset stays out of range
         } else {
             const int i = k - RA;
             if (MFTX_ABLATE != 4 && (BN % RPP == 0 || wid * 8 + RPP * i < BN))
@@ -510,6 +550,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         }
     };
     auto fetch_end = [&]() {
+        if constexpr (!SPLIT) --left;
         if (++cc == cpt) {
             cc = 0;
             if (++dx == p.kw) { dx = 0; ++dy; }
@@ -982,7 +1023,7 @@ __device__ __forceinline__ int n_virtual_tiles(const ConvArgs &p, int BM, int BN
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, int MT = 32, int AR = AR_F32, int NS = 2>
-__global__ __launch_bounds__(64 * WM * WN, AR != AR_F32 ? min_waves_split((BM / WM / MT) * (BN / WN / MT), WM * WN) : min_waves((BM / WM / MT) * (BN / WN / MT)))
+__global__ __launch_bounds__(64 * WM * WN, AR != AR_F32 ? min_waves_split((BM / WM / MT) * (BN / WN / MT), WM * WN) : min_waves((BM / WM / MT) * (BN / WN / MT), EPI))
 void conv_gemm_kernel(ConvArgs p) {
     conv_gemm_body<BM, BN, WM, WN, EPI, MT, AR, NS>(p, blockIdx.x);
 }
