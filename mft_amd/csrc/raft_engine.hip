@@ -356,8 +356,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         // 512 x 512 pairs: the kernels leave CUs idle): the flow branch runs on the handle's SIDE STREAM beside the
         // correlation branch and joins in front of `conv` -- 3.67 -> 3.45 ms at one pair, 5.94 -> 5.59 at four
         // (tools/bench_pairs.py); at seven pairs every kernel fills the chip and the two stream hand-overs per iteration
-        // cost more than the overlap gives (106.7 vs 111.5 frames/s in order on one stream, 108.8 with lookup + convf1
-        // as one launch): in order on one stream.  fp32 MFMA keeps round 1's grouping (lookup + convf1 in one launch,
+        // cost more than the overlap gives (106.7 vs 111.5 frames/s): in order on one stream.  fp32 MFMA keeps round 1's grouping (lookup + convf1 in one launch,
         // convc2 + convf2 in one launch).  The per-kernel timing pass and MFTX_RAFT_NOFUSE run everything in order.
         const ConvF1Args f1{ws.coords1, W[W_CONVF1], W[B_CONVF1], ws.flo1, ws.hx, h, w, strips, P * h * strips, SP ? 1 : 0};
         const int f1_blocks = cdiv(f1.n_strips, 2);
@@ -377,7 +376,9 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
             TRY(launch_conv(f2, r->side));
             if (hipEventRecord(r->ev_join, r->side) != hipSuccess) return fail(MFTX_E_STATE, "raft_refine: join event failed");
         }
-        if (serial || forked || ondemand) {
+        // lookup + convf1 as ONE launch (HBM gathers beside VALU work) whenever the flow branch is not on the side stream:
+        // 113.7 vs 113.2 frames/s with the split arithmetic; the timing pass and MFTX_RAFT_NOFUSE keep them apart
+        if (prof_enabled() || nofuse || forked || ondemand) {
             // (the 324 features stay fp32: written in split form the lookup takes 31 instead of 27 us, more than convc1
             // gains from a pre-split A -- and its HBM roofline is the one with a north-star target)
             if (ondemand) TRY(launch_corr_ondemand(fmap1, f2lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr, s));
