@@ -31,6 +31,7 @@
 #include "common.h"
 #include "profile.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace mftx {
 
@@ -234,7 +235,7 @@ constexpr int min_waves(int wave_tiles, int epi = 0) {
     return wave_tiles == 1 ? (epi == 3 ? 3 : MFTX_MINW1) : wave_tiles == 2 ? 3 : 2;
 }
 // split arithmetic: two accumulator sets and raw + split fragments
-constexpr int min_waves_split(int wave_tiles, int waves) { return waves == 8 ? 2 : wave_tiles == 1 ? 3 : 2; }
+constexpr int min_waves_split(int wave_tiles, int waves, int mt = 32) { return mt == 16 ? 1 : waves == 8 ? 2 : wave_tiles == 1 ? 3 : 2; }
 
 // Epilogue of the correlation-volume GEMM: one wave holds 32 query rows x one super-block (2 x 2 blocks of
 // 8 x 4 target cells, 128 columns) in acc[4].  The tile goes through the wave's private 16 KiB of LDS once:
@@ -334,7 +335,7 @@ __device__ __forceinline__ void volume_epilogue(const ConvArgs &p, const f32x16 
 // tile choice still does not show in the results.
 template <int BM, int BN, int WM, int WN, int EPI, int MT = 32, int AR = AR_F32, int NS = 2>
 __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
-    static_assert(AR == AR_F32 || MT == 32, "split arithmetic: 32x32 MFMA tiles");
+    static_assert(AR == AR_F32 || MT == 32 || AR == AR_PRESPLIT, "split arithmetic: 32x32 MFMA tiles; 16x16 for a pre-split A only");
     // NS: LDS ring of K chunks.  fp32 MFMA: two (a chunk is > 1000 matrix cycles per wave, deeper rings were
     // measured: no gain).  Split arithmetic: a chunk is 192 matrix cycles per MFMA tile, well below the L2 latency:
     // three or four chunks are kept in flight.
@@ -348,9 +349,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
     static_assert(MT == 32 || MT == 16, "MFMA tile");
     static_assert(TM >= 1 && TN >= 1 && RA >= 1 && RB >= 1, "tile");
     static_assert(RPP % 16 == 0, "the chunk swizzle must not depend on the pass");
+    constexpr int BMS = RA * RPP, BNS = RB * RPP;   // rows per ring slot: whole staging passes (112-row tile: 128, the last 16 zero-filled and never read)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;                       // [NS][BM][LDK]
-    float *Bs = smem + NS * BM * LDK;       // [NS][BN][LDK]
+    float *As = smem;                       // [NS][BMS][LDK]
+    float *Bs = smem + NS * BMS * LDK;      // [NS][BNS][LDK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -359,7 +361,12 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
     const int srow = tid >> 3;  // 0..RPP-1: staging row of this lane within an RPP-row group
     // this lane's LDS chunk (tid & 7) receives logical chunk (tid & 7) ^ swz(row); rows advance by
     // RPP (a multiple of 16) per group, so swz = (row >> 1) & 7 depends on srow only
-    const int col4 = ((tid & 7) ^ ((srow >> 1) & 7)) * 4;
+    // (16-row MFMA tiles read with another lane -> row mapping and carry their own swizzle, below)
+    auto swz = [](int row) {
+        const int s2 = (row >> 1) & 7;
+        return (SPLIT && MT == 16) ? s2 ^ ((((s2 >> 1) ^ (s2 >> 2)) & 1) << 1) : s2;
+    };
+    const int col4 = ((tid & 7) ^ swz(srow)) * 4;
 
     // Persistent workgroups with an XCD-aware tile order.  The hardware dispatcher
     // fills free slots greedily, which leaves whole CUs idle in a ragged last
@@ -393,7 +400,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
     // elements (g >> 1) and (g >> 1) + 2 of it
     const int khalf = MT == 32 ? lane >> 5 : (lane >> 4) & 1;
     const bool hi_pair = MT == 16 && (lane >> 5) != 0;
-    const int a_sw = (a_row0 >> 1) & 7, b_sw = (b_row0 >> 1) & 7;   // same for every 32-row step
+    const int a_sw = swz(a_row0), b_sw = swz(b_row0);   // same for every 16- / 32-row step
     // fragment addresses of the four 8-wide k groups (the XOR swizzle is not additive: one each)
     const float *a_frag[4], *b_frag[4];
 #pragma unroll
@@ -411,6 +418,25 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
             a_frag2[g][c] = As + a_row0 * LDK + (((4 * g + 2 * khalf + c) ^ a_sw) * 4);
             b_frag2[g][c] = Bs + b_row0 * LDK + (((4 * g + 2 * khalf + c) ^ b_sw) * 4);
         }
+    // Split arithmetic on 16x16x32 MFMAs (A pre-split).  A row of a chunk is 8 pieces of 16 bytes: h0 l0 h1 l1 h2 l2 h3 l3,
+    // the high / low halves of channels 8 g .. 8 g + 7.  Lane quarter q = lane >> 4 supplies k slots 8 q .. 8 q + 7 of an
+    // instruction, and the three products' operands are plain ds_read_b128 with a per-quarter piece:
+    //   operand 0 (hi hi, k = all 32 channels):          h_q                              piece 2 q
+    //   operand 1 (cross terms of channels  0..15):  A: h0 h1 l0 l1   W: l0 l1 h0 h1      (slots 0..15: hi_a lo_b, 16..31: lo_a hi_b)
+    //   operand 2 (cross terms of channels 16..31):  A: h2 h3 l2 l3   W: l2 l3 h2 h3
+    // Swizzle: ds_read_b128 is served in groups of 16 lanes = rows {0-3, 12-15} of one quarter and {4-11} of the next
+    // (or the other way round), whose pieces differ by 2; s ^ 2 for row pairs s = 2..5 spreads each group over all 64 banks.
+    const float *a_frag16[3], *b_frag16[3];
+    {
+        const int q = lane >> 4;
+        const int pa[3] = {2 * q, 2 * (q & 1) + (q >> 1), 4 + 2 * (q & 1) + (q >> 1)};
+        const int pb[3] = {2 * q, 2 * (q & 1) + 1 - (q >> 1), 4 + 2 * (q & 1) + 1 - (q >> 1)};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a_frag16[c] = As + a_row0 * LDK + ((pa[c] ^ a_sw) * 4);
+            b_frag16[c] = Bs + b_row0 * LDK + ((pb[c] ^ b_sw) * 4);
+        }
+    }
     // LDS-DMA destinations: wave `wid` fills rows [RPP i + 8 wid, +8) of each RPP-row group (1 KiB, lane-linear)
     float *const a_dst = As + wid * 8 * LDK;
     float *const b_dst = Bs + wid * 8 * LDK;
@@ -540,12 +566,12 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
             } else {
                 acur0[k] += BK * 4u;
             }
-            if (MFTX_ABLATE != 5 && (MFTX_ABLATE != 6 || cc % 5 == 0) && (BM % RPP == 0 || wid * 8 + RPP * k < BM))
-                buf_load_lds(rA, a_dst + buf * BM * LDK + RPP * k * LDK, off);
+            if (MFTX_ABLATE != 5 && (MFTX_ABLATE != 6 || cc % 5 == 0) && (BM % RPP == 0 || SPLIT || wid * 8 + RPP * k < BM))   // (split: counted waits, every wave issues every piece)
+                buf_load_lds(rA, a_dst + buf * BMS * LDK + RPP * k * LDK, off);
         } else {
             const int i = k - RA;
-            if (MFTX_ABLATE != 4 && (BN % RPP == 0 || wid * 8 + RPP * i < BN))
-                buf_load_lds(rW, b_dst + buf * BN * LDK + RPP * i * LDK, woff[i]);
+            if (MFTX_ABLATE != 4 && (BN % RPP == 0 || SPLIT || wid * 8 + RPP * i < BN))
+                buf_load_lds(rW, b_dst + buf * BNS * LDK + RPP * i * LDK, woff[i]);
             woff[i] += BK * 4u;
         }
     };
@@ -589,12 +615,12 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
-                    ra[slot][i][c] = *reinterpret_cast<const f32x4 *>(a_frag2[g][c] + buf * BM * LDK + MT * i * LDK);
+                    ra[slot][i][c] = *reinterpret_cast<const f32x4 *>(a_frag2[g][c] + buf * BMS * LDK + MT * i * LDK);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
-                    rb[slot][j][c] = *reinterpret_cast<const f32x4 *>(b_frag2[g][c] + buf * BN * LDK + MT * j * LDK);
+                    rb[slot][j][c] = *reinterpret_cast<const f32x4 *>(b_frag2[g][c] + buf * BNS * LDK + MT * j * LDK);
         }
     };
     const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));   // scalar register operand
@@ -604,7 +630,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
     // of the tile about to be multiplied (tile 0 on entry); the order is pinned with scheduling barriers.
     f16x8 ah[SPLIT ? TM : 1], al[SPLIT ? TM : 1];
     auto group = [&](int set, int nset, bool have_next, int refill = -1) {
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT && MT == 32) {
             f16x8 bh[TN], bl[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {           // the weights arrive split: [hi x 8 | lo x 8] per 8 k = the two chunks read
@@ -661,10 +687,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         if (MFTX_ABLATE == 3) return;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-            fa[slot][i] = *reinterpret_cast<const f32x4 *>(a_frag[kk] + buf * BM * LDK + MT * i * LDK);
+            fa[slot][i] = *reinterpret_cast<const f32x4 *>(a_frag[kk] + buf * BMS * LDK + MT * i * LDK);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-            fb[slot][j] = *reinterpret_cast<const f32x4 *>(b_frag[kk] + buf * BN * LDK + MT * j * LDK);
+            fb[slot][j] = *reinterpret_cast<const f32x4 *>(b_frag[kk] + buf * BNS * LDK + MT * j * LDK);
     };
     auto mma = [&](int slot) {
         if constexpr (MT == 32) {
@@ -729,6 +755,96 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    if constexpr (SPLIT && MT == 16) {
+        // 16-row MFMA tiles (v_mfma_f32_16x16x32_f16), so that the workgroup tile can be 112 rows: 7 x 4096 cells are
+        // 256 x 112 -- one tile for every CU, where 128-row tiles leave 32 of the 256 CUs idle.  ONE wave per SIMD, each
+        // owning all TM row tiles x 64 columns (224 accumulator registers): per 32-wide chunk a wave reads 2 TM + 2 TN
+        // fragments from LDS for 3 TM TN MFMAs -- half the LDS traffic per matrix cycle of the 64 x 64 waves of the
+        // 32-row form.
+        //   The instruction rounds exactly like two 32x32x16 ones over k 0..15 and k 16..31 (tools/micro/
+        // mfma_f16_order.hip), so results stay independent of the tile shape if every accumulator sees the same
+        // sequence: acc += hi hi (k 0..31) as it stands; the cross terms of the 32-row form arrive as hi lo (g 0),
+        // lo hi (g 0), hi lo (g 1), lo hi (g 1) for the chunk's two 16-wide groups g -- here one instruction per group
+        // whose k slots 0..15 carry (hi_a, lo_b) and 16..31 (lo_a, hi_b) of that group (operands 1 and 2 above).
+        static_assert(PRE, "16-row tiles: A arrives split");
+        static_assert(NS == 3 && TN == 4 && TM >= 7, "16-row tiles: schedule below");
+        // Ring of three chunks, ONE barrier per chunk, taken before row tile BAR of chunk c: it certifies that chunk c + 1
+        // has landed (issued a whole chunk earlier) and that every wave is past chunk c - 1, whose slot takes chunk c + 2
+        // -- its DMA pieces go out three per row tile behind MFMAs, as do the reads of the next chunk's weight fragments
+        // (one column tile per row tile; all four waves reading 12 KiB at once right behind a barrier would hold the LDS
+        // port for 200 cycles); the next chunk's first A tile is read under the last row tile's MFMAs.  No VALU work at
+        // all in the loop.  With one wave per SIMD nothing else hides latency: every ds_read is issued >= 12 MFMAs ahead.
+        constexpr int L = RA + RB, BAR = 2, PPT = (L + 3) / 4;
+        fetch(0);
+        if (T > 1) fetch(1);
+        wait_vmcnt<0>();
+        block_barrier();
+        f16x8 fb16[2][TN][3];               // weights of this / the next chunk
+        f16x8 fa16[2][3];                   // A row tile i in set (i + parity) & 1
+        auto read_b = [&](int buf, int j, int set) {
+#pragma unroll
+            for (int o = 0; o < 3; ++o) fb16[set][j][o] = *reinterpret_cast<const f16x8 *>(b_frag16[o] + buf * BNS * LDK + 16 * j * LDK);
+        };
+        auto read_a = [&](int buf, int i, int set) {
+#pragma unroll
+            for (int o = 0; o < 3; ++o) fa16[set][o] = *reinterpret_cast<const f16x8 *>(a_frag16[o] + buf * BMS * LDK + 16 * i * LDK);
+        };
+#pragma unroll
+        for (int j = 0; j < TN; ++j) read_b(0, j, 0);
+        read_a(0, 0, 0);
+        int slot = 0;
+        // Every chunk runs the same straight-line schedule, the last two included: what they read ahead (the ring's next
+        // slot) is never used, what they fetch ahead (chunks T, T + 1: offsets past the last filter tap -- valid or
+        // out-of-range addresses, 3 % more L2 reads) lands in slots nobody reads, and is waited for before the ring
+        // becomes epilogue staging.  (Peeled tails with their own schedules cost the register allocator its mind.)
+        auto chunk = [&](auto pa_, auto pb_) {
+            constexpr int PA = decltype(pa_)::value, PB = decltype(pb_)::value;
+            const int nslot = slot + 1 == NS ? 0 : slot + 1;
+            const int rslot = nslot + 1 == NS ? 0 : nslot + 1;     // slot of chunk c - 1 = of chunk c + 2
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int set = (i + PA) & 1;
+                if (i + 1 < TM && !(MFTX_SABL & 8)) read_a(slot, i + 1, set ^ 1);
+                if (i == BAR) {
+                    if (!(MFTX_SABL & 4)) {
+                        wait_vmcnt<0>();             // own pieces of chunk c + 1
+                        block_barrier();
+                    }
+                    fetch_begin();
+                }
+                if (i >= BAR && i < BAR + TN && !(MFTX_SABL & 8)) read_b(nslot, i - BAR, PB ^ 1);
+                if (i == TM - 1 && !(MFTX_SABL & 8)) read_a(nslot, 0, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 3 * TN; ++m) {
+                    const int j = m % TN, o = m / TN;
+                    // (as assembly, accumulating in place in AGPRs: given the builtin and 512 registers the allocator shuttles
+                    // half the accumulators between the two files on every trip.  Hazards by construction: operands come
+                    // from ds_reads the compiler waits for; an accumulator is touched again 4 MFMAs later at the earliest.)
+                    if (o == 0) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa16[set][0]), "v"(fb16[PB][j][0]));
+                    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(accx[i][j]) : "v"(fa16[set][o]), "v"(fb16[PB][j][o]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (m % 4 == 1 && i >= BAR && i < BAR + 4 && (i - BAR) * PPT + m / 4 < L && !(MFTX_SABL & 2)) {
+                        fetch_piece(rslot, (i - BAR) * PPT + m / 4);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (i == BAR + 3) fetch_end();
+            }
+            slot = nslot;
+        };
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        using PA1 = std::integral_constant<int, TM & 1>;
+        int c = 0;
+        for (; c + 1 < T; c += 2) {
+            chunk(P0{}, P0{});
+            chunk(PA1{}, P1{});
+        }
+        if (c < T) chunk(P0{}, P0{});
+        wait_vmcnt<0>();
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // the last MFMAs' results, before the VALU reads them
+    } else
     if constexpr (SPLIT) {
         // Ring of NS chunks, slot of chunk c = c % NS (run-time index: the K loop is not unrolled over the slots).
         // Per chunk: two 16-wide k groups; the raw fragments of the next group are read from LDS before the
@@ -858,8 +974,12 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         // per row.  Two phases per tile as below: every global read first, then arithmetic and stores.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         block_barrier();                      // every wave is done with the ring: it becomes epilogue staging
-        float *st = smem + wid * 1024;
-        const int c4 = lane & 7, rq = lane >> 3;
+        // (16-row MFMA tiles: the epilogue tile is one 16-row tile x the wave's 64 columns -- four passes of 4 rows x 16
+        // float4; staging rows padded to 68 floats so that the four lane groups' C/D writes spread over all banks)
+        constexpr int ETN = MT == 32 ? TM * TN : TM;            // epilogue tiles per wave
+        constexpr int STS = MT == 32 ? 32 : 68, RS = MT == 32 ? 8 : 4;
+        float *st = smem + wid * (MT == 32 ? 1024 : 16 * STS);
+        const int c4 = MT == 32 ? lane & 7 : lane & 15, rq = MT == 32 ? lane >> 3 : lane >> 4;
         const bool pre_add = p.addend != nullptr && p.residual_mode == 0;
         const bool any_add = pre_add || p.residual_mode == 1;
         // (an output whose rows are not 16-byte aligned -- ldo = 126 -- is stored value by value)
@@ -869,15 +989,14 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         // launch moves 73 MB through its epilogue (addend + h in, z + r h out) against 29 MB for a plain layer
         struct TileLoads { f32x4 add[4], a0[4], a1[4]; };
         TileLoads ld[2];
-        auto tile_nb = [&](int j) { return n0 + wn * TN * 32 + j * 32 + c4 * 4; };          // first of this lane's four columns
-        auto tile_mb = [&](int i) { return m0 + wm * TM * 32 + i * 32 + rq; };
+        auto tile_nb = [&](int k) { return MT == 32 ? n0 + wn * TN * 32 + (k / TM) * 32 + c4 * 4 : n0 + wn * TN * 16 + c4 * 4; };   // first of this lane's four columns
+        auto tile_mb = [&](int k) { return MT == 32 ? m0 + wm * TM * 32 + (k % TM) * 32 + rq : m0 + wm * TM * 16 + k * 16 + rq; };
         auto issue_loads = [&](int k, TileLoads &L) {
-            const int j = k / TM, i = k % TM;
-            const int nb = tile_nb(j), mb = tile_mb(i);
+            const int nb = tile_nb(k), mb = tile_mb(k);
             const bool full = nb + 3 < p.N;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const long long m = mb + t * 8;
+                const long long m = mb + t * RS;
                 L.add[t] = L.a0[t] = L.a1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (m >= p.M || nb >= p.N) continue;
                 if (full) {
@@ -897,11 +1016,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         };
         issue_loads(0, ld[0]);
 #pragma unroll
-        for (int k = 0; k < TM * TN; ++k) {
-            const int j = k / TM, i = k % TM;
-            if (k + 1 < TM * TN) issue_loads(k + 1, ld[(k + 1) & 1]);
+        for (int k = 0; k < ETN; ++k) {
+            if (k + 1 < ETN) issue_loads(k + 1, ld[(k + 1) & 1]);
             const TileLoads &L = ld[k & 1];
-            const int nb = tile_nb(j);
+            const int nb = tile_nb(k);
             const bool full = nb + 3 < p.N;
             f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
             if (p.bias != nullptr) {
@@ -910,18 +1028,24 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) bias4[e] = nb + e < p.N ? p.bias[nb + e] : 0.f;
             }
-            {
+            if constexpr (MT == 32) {
                 float *w = st + (4 * (lane >> 5)) * 32 + (lane & 31);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2)) * 32] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2)) * 32] = acc[k % TM][k / TM][r];
+            } else {
+                float *w = st + (4 * (lane >> 4)) * STS + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w[r * STS + 16 * j] = acc[k][j][r];
             }
-            const int mb = tile_mb(i);
+            const int mb = tile_mb(k);
             f32x4 v[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const f32x4 *>(st + (t * 8 + rq) * 32 + c4 * 4);
+            for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const f32x4 *>(st + (t * RS + rq) * STS + c4 * 4);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const long long m = mb + t * 8;
+                const long long m = mb + t * RS;
                 if (m >= p.M || nb >= p.N) continue;
                 f32x4 o;
 #pragma unroll
@@ -1023,7 +1147,7 @@ __device__ __forceinline__ int n_virtual_tiles(const ConvArgs &p, int BM, int BN
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, int MT = 32, int AR = AR_F32, int NS = 2>
-__global__ __launch_bounds__(64 * WM * WN, AR != AR_F32 ? min_waves_split((BM / WM / MT) * (BN / WN / MT), WM * WN) : min_waves((BM / WM / MT) * (BN / WN / MT), EPI))
+__global__ __launch_bounds__(64 * WM * WN, AR != AR_F32 ? min_waves_split((BM / WM / MT) * (BN / WN / MT), WM * WN, MT) : min_waves((BM / WM / MT) * (BN / WN / MT), EPI))
 void conv_gemm_kernel(ConvArgs p) {
     conv_gemm_body<BM, BN, WM, WN, EPI, MT, AR, NS>(p, blockIdx.x);
 }
@@ -1057,7 +1181,8 @@ static int num_cus() {
 
 template <int BM, int BN, int WM, int WN, int EPI, int MT = 32, int AR = AR_F32, int NS = 2>
 static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat, double work = -1.0) {
-    constexpr size_t lds = (size_t)NS * (BM + BN) * LDK * sizeof(float);
+    constexpr int RPP = 8 * WM * WN;                  // ring slots hold whole staging passes
+    constexpr size_t lds = (size_t)NS * ((BM + RPP - 1) / RPP + (BN + RPP - 1) / RPP) * RPP * LDK * sizeof(float);
     static bool attr_set = false;
     auto kern = conv_gemm_kernel<BM, BN, WM, WN, EPI, MT, AR, NS>;
     if (!attr_set) {
@@ -1093,6 +1218,7 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
             case 6: return launch_cfg<128, 128, 4, 2, EPI, 32, AR_PRESPLIT, 4>(a, batch, s, cat);
             case 10: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_PRESPLIT, 2>(a, batch, s, cat);
             case 12: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
+            case 13: return launch_cfg<112, 256, 1, 4, EPI, 16, AR_PRESPLIT, 3>(a, batch, s, cat);  // four waves of 112 x 64 on 16-row MFMAs: 7 x 4096 cells = 256 tiles
             default: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
         }
     }
@@ -1124,7 +1250,7 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
 static int pick_tile(const ConvArgs &a, int batch) {
     // debug/tuning override: MFTX_CONV_TILE=0..9
     static const int forced = [] { const char *e = getenv("MFTX_CONV_TILE"); return e ? atoi(e) : -1; }();
-    if (forced >= 0 && forced <= 12) return forced;
+    if (forced >= 0 && forced <= 13) return forced;
     if (a.arith == AR_SPLIT) {
         // Measured (tools/bench_conv.py --arith 1, M = 7 x 4096).  The staging path (global -> LDS) is what limits
         // these kernels, so the biggest tile that still fills the chip wins:
@@ -1135,6 +1261,8 @@ static int pick_tile(const ConvArgs &a, int batch) {
         const long long cus = num_cus();
         const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128);
         if (a.N <= 64) return 9;
+        static const bool try13 = getenv("MFTX_CONV_TILE13") != nullptr;     // tuning: the 112-row tile where it fills the chip in one round
+        if (try13 && a.a_pre && a.N % 256 == 0 && (long long)cdiv(a.M, 112) * (a.N / 256) <= cus && (long long)cdiv(a.M, 112) * (a.N / 256) * 8 >= cus * 7) return 13;
         if (a.N % 256 == 0 && (long long)cdiv(a.M, 128) * (a.N / 256) * 4 >= cus * 3) return 10;
         if (t128 * 2 >= cus * 3) return 0;
         if (t128 * 4 >= cus * 3 && t128 <= cus) return 6;     // one round only: five pairs, N = 256 (320 tiles) would take two
