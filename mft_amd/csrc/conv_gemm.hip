@@ -178,7 +178,8 @@ __device__ __forceinline__ void store_split4(float *row, int nb, const f32x4 &o,
 #define MFTX_ABLATE 0
 #endif
 // split-arithmetic loop (timing only, results are garbage): bit 0 operands taken as if they arrived split, 1 no
-// refills after the prologue, 2 no waits / barriers, 3 no LDS reads, 4 no MFMAs
+// refills after the prologue, 2 no waits / barriers, 3 no LDS reads, 4 no MFMAs, 5 no correlation-volume epilogue (the compiler then
+// drops the MFMAs too), 6 correlation volume: N tiles innermost
 #ifndef MFTX_SABL
 #define MFTX_SABL 0
 #endif
@@ -449,10 +450,11 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
     // conv layers: N tiles innermost (they share the gathered A tile); correlation volume: M tiles innermost --
     // the B tile (128 target rows of f2) stays put while the XCD's band of A tiles (a few hundred KB of f1)
     // cycles through its L2, instead of every XCD re-reading all of f2 once per M tile (fabric reads 879 -> ~270 MB)
-    const int tm = EPI == EPI_VOLUME ? xcd * band + r % band : xcd * band + r / tiles_n;
+    constexpr bool VOL_M_INNER = EPI == EPI_VOLUME && !(MFTX_SABL & 64);
+    const int tm = VOL_M_INNER ? xcd * band + r % band : xcd * band + r / tiles_n;
     if (tm >= tiles_m) continue;                       // ragged band (uniform per workgroup)
     const int m0 = tm * BM;
-    const int n0 = (EPI == EPI_VOLUME ? r / band : r % tiles_n) * BN;
+    const int n0 = (VOL_M_INNER ? r / band : r % tiles_n) * BN;
     float *out = p.out + bz * p.o_bstride;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     block_barrier();                      // previous tile's last LDS reads are done
@@ -658,7 +660,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
 #pragma unroll
                 for (int m = 0; m < 3 * TN; ++m) {
                     const int j = m % TN, prod = m / TN;
-                    if (prod == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    if (MFTX_SABL & 16) {}
+                    else if (prod == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     else if (prod == 1) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
                     else accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -963,7 +966,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         static_assert(MT == 32 && TM == 1 && TN == 4 && WN == 1 && BN == 128, "volume tile: 32 queries x one super-block per wave");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         block_barrier();                      // every wave is done with the ring: it becomes epilogue staging
-        volume_epilogue(p, acc[0], smem + wid * 4096, lane, m0 + wm * 32, n0 / BN, bz);
+        if (!(MFTX_SABL & 32)) volume_epilogue(p, acc[0], smem + wid * 4096, lane, m0 + wm * 32, n0 / BN, bz);
         continue;
     }
     if constexpr (SPLIT) {
@@ -1218,6 +1221,8 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
             case 6: return launch_cfg<128, 128, 4, 2, EPI, 32, AR_PRESPLIT, 4>(a, batch, s, cat);
             case 10: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_PRESPLIT, 2>(a, batch, s, cat);
             case 12: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
+            case 1: return launch_cfg<128, 64, 2, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
+            case 14: return launch_cfg<128, 192, 4, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);   // eight waves of 32 x 96: N = 192 without a half-empty column tile
             case 13: return launch_cfg<112, 256, 1, 4, EPI, 16, AR_PRESPLIT, 3>(a, batch, s, cat);  // four waves of 112 x 64 on 16-row MFMAs: 7 x 4096 cells = 256 tiles
             default: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
         }
@@ -1232,6 +1237,7 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
             case 10: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);  // eight waves of 64 x 64: the A tile is staged once for 256 output channels
             case 11: return launch_cfg<256, 128, 4, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);  // eight waves of 64 x 64: the W tile is staged once for 256 cells
             case 12: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);  // as 10, ring of three chunks (144 KiB)
+            case 14: return launch_cfg<128, 192, 4, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
             case 8: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);
             case 9: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
             default: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 4>(a, batch, s, cat);
@@ -1250,7 +1256,7 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
 static int pick_tile(const ConvArgs &a, int batch) {
     // debug/tuning override: MFTX_CONV_TILE=0..9
     static const int forced = [] { const char *e = getenv("MFTX_CONV_TILE"); return e ? atoi(e) : -1; }();
-    if (forced >= 0 && forced <= 13) return forced;
+    if (forced >= 0 && forced <= 14) return forced;
     if (a.arith == AR_SPLIT) {
         // Measured (tools/bench_conv.py --arith 1, M = 7 x 4096).  The staging path (global -> LDS) is what limits
         // these kernels, so the biggest tile that still fills the chip wins:
@@ -1261,6 +1267,10 @@ static int pick_tile(const ConvArgs &a, int batch) {
         const long long cus = num_cus();
         const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128);
         if (a.N <= 64) return 9;
+        //   14: 128 x 192, eight 32 x 96 waves, one workgroup per CU: N = 192 (convc2) without the half-empty second column tile
+        //       of the 128-wide shapes -- a quarter of their matrix work (measured at M = 7 x 4096: 110.5 -> 88.7 us)
+        static const bool no14 = getenv("MFTX_CONV_NO14") != nullptr;
+        if (!no14 && a.N % 192 == 0 && a.N % 128 != 0 && (long long)cdiv(a.M, 128) * (a.N / 192) * 2 >= cus) return 14;
         static const bool try13 = getenv("MFTX_CONV_TILE13") != nullptr;     // tuning: the 112-row tile where it fills the chip in one round
         if (try13 && a.a_pre && a.N % 256 == 0 && (long long)cdiv(a.M, 112) * (a.N / 256) <= cus && (long long)cdiv(a.M, 112) * (a.N / 256) * 8 >= cus * 7) return 13;
         if (a.N % 256 == 0 && (long long)cdiv(a.M, 128) * (a.N / 256) * 4 >= cus * 3) return 10;
