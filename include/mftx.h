@@ -69,6 +69,10 @@ int mftx_profile_end(double *ms, double *work, long long *count, int n);
  * lvl_l must hold P*h*w*stride[l] floats, 16-byte aligned. */
 int mftx_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, int w,
                       float *lvl0, float *lvl1, float *lvl2, float *lvl3, void *stream);
+/* The same in split-fp16 arithmetic (MFTX_ARITH_SPLIT: three fp16 MFMAs per product, fp32 accumulation; what the
+ * refinement engine runs by default).  f2_scratch: P*h*w*C floats, 32-byte aligned -- receives f2 in split form. */
+int mftx_corr_pyramid_split(const float *f1, const float *f2, int P, int C, int h, int w,
+                            float *lvl0, float *lvl1, float *lvl2, float *lvl3, float *f2_scratch, void *stream);
 /* stride[4]: floats per query cell of each level; block_grid[4] = {hb_0, wb_0, hb_1, wb_1}. */
 int mftx_corr_pyramid_layout(int h, int w, long long *stride, int *block_grid);
 

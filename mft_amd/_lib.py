@@ -36,6 +36,8 @@ SIGNATURES = {
     "mftx_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
     "mftx_corr_pyramid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mftx_corr_pyramid_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mftx_corr_pyramid_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "mftx_corr_lookup": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p, C.c_int, C.c_void_p]),
     "mftx_fmap_pyramid": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 4),

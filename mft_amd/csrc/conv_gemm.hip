@@ -458,6 +458,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
     float *out = p.out + bz * p.o_bstride;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     block_barrier();                      // previous tile's last LDS reads are done
+#ifdef MFTX_TIMING
+    unsigned long long tt0, tt1 = 0, tt2 = 0;       // tile phases: [8] prologue, [9] K loop, [10] epilogue, [11] tiles
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt0));
+#endif
 
     const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.a0 + bz * p.a_bstride), 0, p.a0_bytes, 0x00020000);
@@ -874,6 +878,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         unsigned tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         STAMP(6);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ts[6]));
+        tt1 = ts[6];
 #endif
         for (int c = 0; c < T; ++c) {
             const int nslot = slot + 1 == NS ? 0 : slot + 1;
@@ -917,6 +923,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
 #pragma unroll
             for (int i = 0; i < 7; ++i) atomicAdd(&mftx_dbg[i], (unsigned long long)tot[i]);
         }
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt2));
 #endif
     } else {
     // prologue: chunks 0 and 1 in flight, chunk 0 landed, first fragments -> slot 0
@@ -967,6 +974,15 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         block_barrier();                      // every wave is done with the ring: it becomes epilogue staging
         if (!(MFTX_SABL & 32)) volume_epilogue(p, acc[0], smem + wid * 4096, lane, m0 + wm * 32, n0 / BN, bz);
+#ifdef MFTX_TIMING
+        {
+            unsigned long long tt3;
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt3)::"memory");     // (stores drained: the epilogue's real length)
+            if (lane == 0) {
+                atomicAdd(&mftx_dbg[8], tt1 - tt0); atomicAdd(&mftx_dbg[9], tt2 - tt1); atomicAdd(&mftx_dbg[10], tt3 - tt2); atomicAdd(&mftx_dbg[11], 1ull);
+            }
+        }
+#endif
         continue;
     }
     if constexpr (SPLIT) {

@@ -457,6 +457,18 @@ extern "C" int mftx_corr_pyramid(const float *f1, const float *f2, int P, int C,
     return launch_corr_pyramid(f1, f2, P, C, h, w, lv, (hipStream_t)stream);
 }
 
+extern "C" int mftx_corr_pyramid_split(const float *f1, const float *f2, int P, int C, int h, int w, float *lvl0,
+                                       float *lvl1, float *lvl2, float *lvl3, float *f2_scratch, void *stream) {
+    if (!f1 || !f2 || !lvl0 || !lvl1 || !lvl2 || !lvl3 || !f2_scratch) return fail(MFTX_E_ARG, "corr_pyramid_split: null pointer");
+    if (P <= 0 || C <= 0 || C % 32 || h < 8 || w < 8) return fail(MFTX_E_ARG, "corr_pyramid_split: need C %% 32 == 0, h, w >= 8");
+    if (!aligned16(f1) || !aligned16(f2) || (reinterpret_cast<uintptr_t>(f2_scratch) & 31))
+        return fail(MFTX_E_ALIGN, "corr_pyramid_split: features must be 16-byte aligned, the scratch 32-byte aligned");
+    if (!aligned16(lvl0) || !aligned16(lvl1) || !aligned16(lvl2) || !aligned16(lvl3))
+        return fail(MFTX_E_ALIGN, "corr_pyramid_split: levels must be 16-byte aligned");
+    float *const lv[4] = {lvl0, lvl1, lvl2, lvl3};
+    return launch_corr_pyramid(f1, f2, P, C, h, w, lv, (hipStream_t)stream, f2_scratch);
+}
+
 extern "C" int mftx_corr_pyramid_layout(int h, int w, long long *stride, int *block_grid) {
     if (h < 8 || w < 8 || !stride || !block_grid) return fail(MFTX_E_ARG, "corr_pyramid_layout: bad arguments");
     const PyramidLayout L = pyramid_layout(h, w);

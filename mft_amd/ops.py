@@ -267,14 +267,22 @@ def block_level(t: torch.Tensor, l: int, h: int, w: int) -> torch.Tensor:
     return out
 
 
-def corr_pyramid(f1: torch.Tensor, f2: torch.Tensor, h: int, w: int):
+def corr_pyramid(f1: torch.Tensor, f2: torch.Tensor, h: int, w: int, arith: int = ARITH_F32):
     """f1, f2: pixel-major [P, h*w, C] -> 4 levels [P, h*w, stride_l] in the stored layout
-    (``unblock_level`` gives the reference's row-major view)."""
+    (``unblock_level`` gives the reference's row-major view).  ``arith``: ARITH_F32 (fp32 MFMA) or ARITH_SPLIT
+    (split-fp16 products, what the refinement engine runs by default)."""
     lib = _lib.load()
     P, N, Cc = f1.shape
     assert N == h * w and f2.shape == f1.shape
     stride, _ = pyramid_layout(h, w)
     lv = [torch.empty(P, N, stride[l], dtype=torch.float32, device=f1.device) for l in range(4)]
+    if arith == ARITH_SPLIT:
+        scratch = torch.empty_like(f2)
+        check(lib.mftx_corr_pyramid_split(_chk(f1, "f1"), _chk(f2, "f2"), P, Cc, h, w,
+                                          *[t.data_ptr() for t in lv], scratch.data_ptr(), _stream()), "mftx_corr_pyramid_split")
+        return lv
+    if arith != ARITH_F32:
+        raise MftxError("corr_pyramid: arith must be ARITH_F32 or ARITH_SPLIT")
     check(lib.mftx_corr_pyramid(_chk(f1, "f1"), _chk(f2, "f2"), P, Cc, h, w,
                                 *[t.data_ptr() for t in lv], _stream()), "mftx_corr_pyramid")
     return lv

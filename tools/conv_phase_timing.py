@@ -39,3 +39,22 @@ for name, cin, cout, kh, kw in (("gru zr 1x5 256->256", 256, 256, 1, 5), ("gru q
     tot = sum(buf[i] for i in range(6))
     print(f"{name}: {e0.elapsed_time(e1) / reps * 1e3:.1f} us; per wave-chunk {tot / n:.0f} ticks (100 MHz ticks x 24 = cycles at 2.4 GHz?): "
           + ", ".join(f"{nm} {buf[i] / n:.1f}" for i, nm in enumerate(names)))
+
+# the correlation volume (split arithmetic): tile phases per wave -- prologue (first two chunks in flight -> landed), K loop
+# (8 chunks), epilogue (stage through LDS, four levels stored, stores drained)
+f1 = torch.randn(P, h * w, 256, device="cuda")
+f2 = torch.randn(P, h * w, 256, device="cuda")
+for _ in range(3):
+    ops.corr_pyramid(f1, f2, h, w, arith=1)
+torch.cuda.synchronize()
+raw.mftx_debug_timing(buf, 1)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    ops.corr_pyramid(f1, f2, h, w, arith=1)
+e1.record()
+torch.cuda.synchronize()
+raw.mftx_debug_timing(buf, 1)
+n = max(buf[11], 1)
+print(f"corr volume 7 x 4096 x 4096: {e0.elapsed_time(e1) / reps * 1e3:.1f} us; per wave-tile (ticks): prologue {buf[8] / n:.0f}, K loop {buf[9] / n:.0f}, "
+      f"epilogue {buf[10] / n:.0f}; wave-tiles per launch {n / reps:.0f}")
