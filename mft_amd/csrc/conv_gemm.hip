@@ -343,7 +343,11 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
     static_assert(AR != AR_F32 || NS == 2, "ring depth");
     constexpr bool SPLIT = AR != AR_F32;          // split arithmetic, A split in registers (AR_SPLIT) or by its producer (AR_PRESPLIT)
     constexpr bool PRE = AR == AR_PRESPLIT;
-    constexpr int TM = BM / WM / MT, TN = BN / WN / MT;
+    // BM need not be a multiple of WM MT: the last row of waves then owns fewer MFMA row tiles (224 x 128: four waves of
+    // 4 x 1 tiles over four of 3 x 1 -- paired per SIMD, 7 tiles each; 7 x 4096 cells = 128 x 224, two column tiles: 256 tiles)
+    constexpr int BMW = (BM + WM * MT - 1) / (WM * MT) * (WM * MT);
+    static_assert((BMW - BM) % MT == 0, "tile rows: whole MFMA tiles");
+    constexpr int TM = BMW / WM / MT, TN = BN / WN / MT;
     constexpr int NR = MT == 32 ? 16 : 4;       // accumulator registers per MFMA tile
     constexpr int RPP = 8 * WM * WN;            // rows staged per pass: 8 per wave (one 1 KiB LDS-DMA)
     constexpr int RA = (BM + RPP - 1) / RPP, RB = (BN + RPP - 1) / RPP;   // (a small tile leaves some waves without A rows)
@@ -394,6 +398,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
     const int seg_cc = p.c1 > 0 ? p.c0 / BK : cpt;           // first chunk of segment 1
     const int rag_cc = (ctot % BK) ? cpt - 1 : cpt;          // the ragged chunk, if any
 
+    const int tm_act = wm == WM - 1 ? TM - (BMW - BM) / MT : TM;      // this wave's live row tiles (wave-uniform)
     const int a_row0 = wm * TM * MT + (lane & (MT - 1));
     const int b_row0 = wn * TN * MT + (lane & (MT - 1));
     // 16-byte chunk of an 8-wide k group this lane reads: MT = 32: lanes 0-31 chunk 2kk, lanes 32-63 chunk
@@ -664,7 +669,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
 #pragma unroll
                 for (int m = 0; m < 3 * TN; ++m) {
                     const int j = m % TN, prod = m / TN;
-                    if (MFTX_SABL & 16) {}
+                    if ((MFTX_SABL & 16) || (BMW != BM && i >= tm_act)) {}
                     else if (prod == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     else if (prod == 1) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
                     else accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
@@ -859,7 +864,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         // it certifies both that chunk c + 1 has landed (each lane waits for its own DMA pieces: counted vmcnt,
         // NS - 2 younger chunks may still fly) and that every wave has read the last of chunk c, whose slot
         // is then refilled with chunk c + NS.
-        static_assert(BM % RPP == 0 && BN % RPP == 0, "counted waits: every wave issues all RA + RB pieces of a chunk");
+        // (counted waits: every wave issues all RA + RB pieces of a chunk -- fetch_piece does, whatever BM % RPP)
         constexpr int L = RA + RB;
 #pragma unroll
         for (int i = 0; i < NS; ++i)
@@ -1010,7 +1015,9 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         TileLoads ld[2];
         auto tile_nb = [&](int k) { return MT == 32 ? n0 + wn * TN * 32 + (k / TM) * 32 + c4 * 4 : n0 + wn * TN * 16 + c4 * 4; };   // first of this lane's four columns
         auto tile_mb = [&](int k) { return MT == 32 ? m0 + wm * TM * 32 + (k % TM) * 32 + rq : m0 + wm * TM * 16 + k * 16 + rq; };
+        auto tile_live = [&](int k) { return BMW == BM || MT != 32 || (k % TM) < tm_act; };      // (rows past BM belong to the next tile)
         auto issue_loads = [&](int k, TileLoads &L) {
+            if (!tile_live(k)) return;
             const int nb = tile_nb(k), mb = tile_mb(k);
             const bool full = nb + 3 < p.N;
 #pragma unroll
@@ -1037,6 +1044,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
 #pragma unroll
         for (int k = 0; k < ETN; ++k) {
             if (k + 1 < ETN) issue_loads(k + 1, ld[(k + 1) & 1]);
+            if (!tile_live(k)) continue;
             const TileLoads &L = ld[k & 1];
             const int nb = tile_nb(k);
             const bool full = nb + 3 < p.N;
@@ -1239,6 +1247,7 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
             case 12: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
             case 1: return launch_cfg<128, 64, 2, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
             case 14: return launch_cfg<128, 192, 4, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);   // eight waves of 32 x 96: N = 192 without a half-empty column tile
+            case 15: return launch_cfg<224, 128, 2, 4, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);   // four waves of 128 x 32 over four of 96 x 32: 7 x 4096 cells = 128 x 224
             case 13: return launch_cfg<112, 256, 1, 4, EPI, 16, AR_PRESPLIT, 3>(a, batch, s, cat);  // four waves of 112 x 64 on 16-row MFMAs: 7 x 4096 cells = 256 tiles
             default: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
         }
@@ -1254,6 +1263,7 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
             case 11: return launch_cfg<256, 128, 4, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);  // eight waves of 64 x 64: the W tile is staged once for 256 cells
             case 12: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);  // as 10, ring of three chunks (144 KiB)
             case 14: return launch_cfg<128, 192, 4, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
+            case 15: return launch_cfg<224, 128, 2, 4, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
             case 8: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);
             case 9: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
             default: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 4>(a, batch, s, cat);
@@ -1272,7 +1282,7 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
 static int pick_tile(const ConvArgs &a, int batch) {
     // debug/tuning override: MFTX_CONV_TILE=0..9
     static const int forced = [] { const char *e = getenv("MFTX_CONV_TILE"); return e ? atoi(e) : -1; }();
-    if (forced >= 0 && forced <= 14) return forced;
+    if (forced >= 0 && forced <= 15) return forced;
     if (a.arith == AR_SPLIT) {
         // Measured (tools/bench_conv.py --arith 1, M = 7 x 4096).  The staging path (global -> LDS) is what limits
         // these kernels, so the biggest tile that still fills the chip wins:
