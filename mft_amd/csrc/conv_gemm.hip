@@ -522,7 +522,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
     // ragged last chunk (channel count not a multiple of 32): this lane's piece lies beyond the last channel -> zeros
     // (pre-split A: a 16-byte piece holds one half of 8 channels)
     const bool rag_dead = (cpt - 1) * BK + (PRE ? (col4 & ~7) : col4) >= ctot;
-    auto new_tap = [&]() {                   // split arithmetic
+    auto new_tap = [&]() {                   // split arithmetic: acur0 = the offsets in use, acur1 = where segment 1 will start
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int yy = ay[i] + dy, xx = ax[i] + dx;
@@ -560,23 +560,26 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
     // fill the address unit's queue and hold the wave (and its MFMAs) for most of a microsecond -- and end (advance)
     auto fetch_begin = [&]() {
         if constexpr (SPLIT) {
-            if (cc == 0) new_tap();
-            rA = cc >= seg_cc ? rA1 : rA0;       // (wave-uniform)
+            // the per-chunk work is three wave-uniform tests; everything per row happens once per tap, at its first chunk, at
+            // the segment change and at the ragged last chunk (the pieces themselves: load, + 128 B)
+            if (cc == 0) { new_tap(); rA = rA0; }
+            if (cc == seg_cc) {                  // (seg_cc == cpt: one segment, never)
+#pragma unroll
+                for (int i = 0; i < RA; ++i) acur0[i] = acur1[i];
+                rA = rA1;
+            }
+            if (cc == rag_cc) {                  // a lane whose piece lies beyond the last channel: zeros (the next tap starts afresh)
+#pragma unroll
+                for (int i = 0; i < RA; ++i) acur0[i] = rag_dead ? OOB : acur0[i];
+            }
         } else {
             if (left == 0) next_run();
         }
     };
     auto fetch_piece = [&](int buf, int k) {
         if (k < RA) {
-            unsigned off = acur0[k];
-            if constexpr (SPLIT) {
-                const bool seg1 = cc >= seg_cc;
-                off = seg1 ? acur1[k] : acur0[k];
-                if (cc >= rag_cc && rag_dead) off = OOB;
-                if (seg1) acur1[k] += BK * 4u; else acur0[k] += BK * 4u;     // an OOB offset stays out of range
-            } else {
-                acur0[k] += BK * 4u;
-            }
+            const unsigned off = acur0[k];
+            acur0[k] += BK * 4u;                 // (an OOB offset stays out of range)
             if (MFTX_ABLATE != 5 && (MFTX_ABLATE != 6 || cc % 5 == 0) && (BM % RPP == 0 || SPLIT || wid * 8 + RPP * k < BM))   // (split: counted waits, every wave issues every piece)
                 buf_load_lds(rA, a_dst + buf * BMS * LDK + RPP * k * LDK, off);
         } else {
@@ -640,7 +643,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
     // this group, or tile 0 of the next group (raw set `nset`, when `have_next`).  ah / al hold the split operands
     // of the tile about to be multiplied (tile 0 on entry); the order is pinned with scheduling barriers.
     f16x8 ah[SPLIT ? TM : 1], al[SPLIT ? TM : 1];
-    auto group = [&](int set, int nset, bool have_next, int refill = -1) {
+    // (have_next, do_refill: compile-time -- as run-time flags they were a branch around every DMA piece and eight selects
+    // per chunk; the K loop below is peeled into its steady part, the chunks without refill and the last one instead)
+    auto group = [&](int set, int nset, auto have_next_, auto do_refill_, int refill) {
+        constexpr bool have_next = decltype(have_next_)::value, do_refill = decltype(do_refill_)::value;
         if constexpr (SPLIT && MT == 32) {
             f16x8 bh[TN], bl[TN];
 #pragma unroll
@@ -675,11 +681,11 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                     else accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (m < 4) { piece(m); __builtin_amdgcn_sched_barrier(0); }
-                    if (refill >= 0 && i * 3 * TN + m < RA + RB) { fetch_piece(refill, i * 3 * TN + m); __builtin_amdgcn_sched_barrier(0); }   // one DMA piece per MFMA
+                    if (do_refill && i * 3 * TN + m < RA + RB) { fetch_piece(refill, i * 3 * TN + m); __builtin_amdgcn_sched_barrier(0); }   // one DMA piece per MFMA
                 }
 #pragma unroll
                 for (int q = 3 * TN; q < 4; ++q) piece(q);       // (TN = 1: fewer MFMAs than pairs)
-                if (i == TM - 1 && refill >= 0) {
+                if (i == TM - 1 && do_refill) {
 #pragma unroll
                     for (int k = 3 * TN * TM; k < RA + RB; ++k) fetch_piece(refill, k);     // (fewer MFMAs than pieces)
                 }
@@ -886,9 +892,10 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ts[6]));
         tt1 = ts[6];
 #endif
-        for (int c = 0; c < T; ++c) {
+        int c = 0;
+        auto chunk = [&](auto more_, auto refill_) {
+            constexpr bool more = decltype(more_)::value, refill = decltype(refill_)::value && !(MFTX_SABL & 2);
             const int nslot = slot + 1 == NS ? 0 : slot + 1;
-            const bool more = c + 1 < T;
 #ifdef MFTX_TIMING
             asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ts[0]), "+s"(ts[1]), "+s"(ts[2]), "+s"(ts[3]), "+s"(ts[4]), "+s"(ts[5]), "+s"(ts[6]));
             if (c > 0) {
@@ -899,13 +906,14 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
             ts[0] = ts[6];
 #endif
             read_raw(slot, 1, 1);
-            group(0, 1, true);
+            group(0, 1, std::true_type{}, std::false_type{}, 0);
             STAMP(1);
-            if (more) {
+            if constexpr (more) {
                 if (!(MFTX_SABL & 4)) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     STAMP(2);
-                    if (c + NS - 1 < T) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+                    if constexpr (decltype(refill_)::value || NS == 2) wait_vmcnt<(NS - 2) * L>();      // (steady part: chunks c + 1 .. c + NS - 1 are in flight)
+                    else if (c + NS - 1 < T) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
                     STAMP(3);
                     block_barrier();
                     STAMP(4);
@@ -914,15 +922,17 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
             }
             __builtin_amdgcn_sched_barrier(0);
             // every wave has read the last of chunk c (the barrier above): its slot takes chunk c + NS
-            const bool refill = c + NS < T && !(MFTX_SABL & 2);
-            if (refill) fetch_begin();
+            if constexpr (refill) fetch_begin();
             STAMP(5);
             __builtin_amdgcn_sched_barrier(0);
-            group(1, 0, more, refill ? slot : -1);
-            if (refill) fetch_end();
+            group(1, 0, std::integral_constant<bool, more>{}, std::integral_constant<bool, refill>{}, slot);
+            if constexpr (refill) fetch_end();
             STAMP(6);
             slot = nslot;
-        }
+        };
+        for (; c + NS < T; ++c) chunk(std::true_type{}, std::true_type{});      // steady part: a chunk follows, the slot is refilled
+        for (; c + 1 < T; ++c) chunk(std::true_type{}, std::false_type{});      // the last NS - 1 chunks before
+        chunk(std::false_type{}, std::false_type{});                            // the last one
 #ifdef MFTX_TIMING
         if (lane == 0) {
 #pragma unroll
