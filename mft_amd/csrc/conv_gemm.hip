@@ -57,7 +57,10 @@ enum Arith { AR_F32 = 0, AR_SPLIT = 1, AR_PRESPLIT = 2 };
 // (s_memtime stamps; read back with mftx_debug_timing from tools/conv_phase_timing.py)
 #ifdef MFTX_TIMING
 __device__ unsigned long long mftx_dbg[16];
+#endif
+#if defined(MFTX_TIMING) && MFTX_TIMING == 1       // (2: tile phases only -- prologue / K loop / epilogue, the loop itself unperturbed)
 #define STAMP(i) asm volatile("s_memtime %0" : "=s"(ts[i]))
+#define MFTX_TIMING_LOOP 1
 #else
 #define STAMP(i)
 #endif
@@ -885,18 +888,19 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
             split8(ra[0][0][0], ra[0][0][1], k2048, ah[0], al[0]);      // the only split that no MFMA hides
         }
         int slot = 0;
-#ifdef MFTX_TIMING
+#ifdef MFTX_TIMING_LOOP
         unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         unsigned tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        STAMP(6);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ts[6]));
-        tt1 = ts[6];
 #endif
+#ifdef MFTX_TIMING
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt1));
+#endif
+        STAMP(6);
         int c = 0;
         auto chunk = [&](auto more_, auto refill_) {
             constexpr bool more = decltype(more_)::value, refill = decltype(refill_)::value && !(MFTX_SABL & 2);
             const int nslot = slot + 1 == NS ? 0 : slot + 1;
-#ifdef MFTX_TIMING
+#ifdef MFTX_TIMING_LOOP
             asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ts[0]), "+s"(ts[1]), "+s"(ts[2]), "+s"(ts[3]), "+s"(ts[4]), "+s"(ts[5]), "+s"(ts[6]));
             if (c > 0) {
                 tot[0] += (unsigned)(ts[1] - ts[0]); tot[1] += (unsigned)(ts[2] - ts[1]); tot[2] += (unsigned)(ts[3] - ts[2]);
@@ -933,11 +937,13 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         for (; c + NS < T; ++c) chunk(std::true_type{}, std::true_type{});      // steady part: a chunk follows, the slot is refilled
         for (; c + 1 < T; ++c) chunk(std::true_type{}, std::false_type{});      // the last NS - 1 chunks before
         chunk(std::false_type{}, std::false_type{});                            // the last one
-#ifdef MFTX_TIMING
+#ifdef MFTX_TIMING_LOOP
         if (lane == 0) {
 #pragma unroll
             for (int i = 0; i < 7; ++i) atomicAdd(&mftx_dbg[i], (unsigned long long)tot[i]);
         }
+#endif
+#ifdef MFTX_TIMING
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt2));
 #endif
     } else {
@@ -1022,10 +1028,130 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         // before tile k is staged, combined and stored -- per tile they are a full memory round trip, and a z|r
         // launch moves 73 MB through its epilogue (addend + h in, z + r h out) against 29 MB for a plain layer
         struct TileLoads { f32x4 add[4], a0[4], a1[4]; };
+        auto tile_live = [&](int k) { return BMW == BM || MT != 32 || (k % TM) < tm_act; };      // (rows past BM belong to the next tile)
+        // ---- straight-line form (the common case: N a multiple of 4, 16-byte aligned rows, operands below 2 GiB): every
+        // global access is a raw buffer access whose offset is out of range where the branchy form below skips it (rows
+        // past M: beyond the resource's extent by themselves; columns past N: the offset is made so) -- no divergent
+        // branch around a memory instruction, so the compiler COUNTS what is in flight when it waits for tile k + 1's
+        // loads.  Behind per-lane `continue`s it cannot, waits for everything (s_waitcnt vmcnt(0)) in front of every
+        // row's stores, and each of the 16 row groups of a 64 x 64 wave tile sat out the round trip of the previous
+        // group's stores: 27 of a z|r launch's 80 us (tile-phase stamps, tools/conv_phase_timing.py).
+        const long long max_ld = EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q ? (p.ld_hx > p.ld_hf ? p.ld_hx : p.ld_hf) : (p.ldo > p.ld_addend ? p.ldo : p.ld_addend);
+        const bool straight = vec_out && (p.N & 3) == 0 && (long long)(p.M + BMW) * (max_ld > 256 ? max_ld : 256) * 4 < 0x7fffffffLL && !(MFTX_SABL & 2048);
+        if (straight) {
+            auto run = [&](auto osplit_, auto add_) {
+                constexpr bool OS = decltype(osplit_)::value, ADD = decltype(add_)::value;
+                auto mk = [&](const void *ptr, long long ld) {
+                    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ptr), 0, (unsigned)((long long)p.M * ld * 4), 0x00020000);
+                };
+                const __amdgpu_buffer_rsrc_t rBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.bias ? p.bias : p.w), 0, p.bias ? (unsigned)p.N * 4u : 0u, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rAdd = mk(ADD ? p.addend : p.w, ADD ? p.ld_addend : 0);
+                const __amdgpu_buffer_rsrc_t rOut = mk(out, p.ldo);
+                const __amdgpu_buffer_rsrc_t rZ = mk(p.z ? p.z : out, 128), rRh = mk(p.rh ? p.rh : out, 128);
+                const __amdgpu_buffer_rsrc_t rHf = mk(p.hf ? p.hf : out, p.ld_hf), rHx = mk(p.hx ? p.hx : out, p.ld_hx);
+                auto tnb = [&](int k) { return MT == 32 ? n0 + wn * TN * 32 + (k / TM) * 32 + c4 * 4 : n0 + wn * TN * 16 + c4 * 4; };
+                auto tmb = [&](int k) { return MT == 32 ? m0 + wm * TM * 32 + (k % TM) * 32 + rq : m0 + wm * TM * 16 + k * 16 + rq; };
+                // byte offset of (row m, column col) in a map of row stride ld, out of range unless ok
+                auto off = [&](int m, int ld, int col, bool ok) { return ok ? (unsigned)(m * ld + col) * 4u : OOB; };
+                auto st128 = [&](const f32x4 &v, __amdgpu_buffer_rsrc_t r, unsigned o) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, o, 0, 0); };
+                // four channels nb .. nb + 3 of a split-form row (row_bytes = its byte offset): high halves, low halves 16 bytes on
+                auto st_split = [&](const f32x4 &v, __amdgpu_buffer_rsrc_t r, unsigned row_bytes, int nb, bool ok) {
+                    unsigned h0, h1, l0, l1;
+                    const float k2048s = 2048.f;
+                    split_pair(v[0], v[1], k2048s, h0, l0);
+                    split_pair(v[2], v[3], k2048s, h1, l1);
+                    const unsigned o = ok ? row_bytes + (unsigned)split_row_offset(nb) : OOB;
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{h0, h1}, r, o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{l0, l1}, r, o + 16u, 0, 0);       // (OOB + 16 stays out of range)
+                };
+                TileLoads ld[2];
+                auto loads = [&](int k, TileLoads &L) {
+                    const int nb = tnb(k), mb = tmb(k);
+                    const bool okc = nb < p.N && tile_live(k);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int m = mb + t * RS;
+                        if constexpr (ADD) L.add[t] = buf_load(rAdd, off(m, p.ld_addend, nb, okc));
+                        else L.add[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        L.a0[t] = L.a1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if constexpr (EPI == EPI_GRU_ZR) {
+                            L.a1[t] = buf_load(rHf, off(m, p.ld_hf, nb - 128, okc && nb >= 128));
+                        } else if constexpr (EPI == EPI_GRU_Q) {
+                            L.a0[t] = buf_load(rZ, off(m, 128, nb, okc));
+                            L.a1[t] = buf_load(rHf, off(m, p.ld_hf, nb, okc));
+                        }
+                    }
+                };
+                constexpr int NBIAS = MT == 32 ? TN : 1;
+                f32x4 bias_c[NBIAS];
+#pragma unroll
+                for (int j = 0; j < NBIAS; ++j) { const int nb = tnb(j * (MT == 32 ? TM : 1)); bias_c[j] = buf_load(rBias, nb < p.N ? (unsigned)nb * 4u : OOB); }
+                loads(0, ld[0]);
+#pragma unroll
+                for (int k = 0; k < ETN; ++k) {
+                    if (k + 1 < ETN) loads(k + 1, ld[(k + 1) & 1]);
+                    const TileLoads &L = ld[k & 1];
+                    const int nb = tnb(k), mb = tmb(k);
+                    const bool okc = nb < p.N && tile_live(k);
+                    const f32x4 bias4 = bias_c[MT == 32 ? k / TM : 0];
+                    if constexpr (MT == 32) {
+                        float *w = st + (4 * (lane >> 5)) * 32 + (lane & 31);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) w[((r & 3) + 8 * (r >> 2)) * 32] = acc[k % TM][k / TM][r];
+                    } else {
+                        float *w = st + (4 * (lane >> 4)) * STS + (lane & 15);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) w[r * STS + 16 * j] = acc[k][j][r];
+                    }
+                    f32x4 v[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const f32x4 *>(st + (t * RS + rq) * STS + c4 * 4);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int m = mb + t * RS;
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float sv = v[t][e] + bias4[e];
+                            if (ADD && p.residual_mode == 0) sv += L.add[t][e];
+                            if constexpr (EPI == EPI_RELU) {
+                                o[e] = fmaxf(sv, 0.f) * p.out_scale;
+                            } else if constexpr (EPI == EPI_GRU_ZR) {
+                                const float g = fast_sigmoid(sv);
+                                o[e] = nb < 128 ? g : g * L.a1[t][e];
+                            } else if constexpr (EPI == EPI_GRU_Q) {
+                                o[e] = (1.f - L.a0[t][e]) * L.a1[t][e] + L.a0[t][e] * fast_tanh(sv);
+                            } else {
+                                float g = act_fn(sv, p.act) * p.out_scale;
+                                if (ADD && p.residual_mode == 1) g = fmaxf(g + L.add[t][e], 0.f);
+                                o[e] = g;
+                            }
+                        }
+                        if constexpr (EPI == EPI_GRU_ZR) {
+                            st128(o, rZ, off(m, 128, nb, okc && nb < 128));                        // z: fp32, read by the q epilogue only
+                            if constexpr (OS) st_split(o, rRh, (unsigned)m * 512u, nb - 128, okc && nb >= 128);      // r h: an A operand of the q GEMM
+                            else st128(o, rRh, off(m, 128, nb - 128, okc && nb >= 128));
+                        } else if constexpr (EPI == EPI_GRU_Q) {
+                            st128(o, rHf, off(m, p.ld_hf, nb, okc));
+                            if constexpr (OS) st_split(o, rHx, (unsigned)(m * p.ld_hx) * 4u, nb, okc);
+                        } else if constexpr (OS) {
+                            st_split(o, rOut, (unsigned)(m * p.ldo) * 4u, nb, okc);
+                        } else {
+                            st128(o, rOut, off(m, p.ldo, nb, okc));
+                        }
+                    }
+                }
+            };
+            const bool has_add = pre_add || p.residual_mode == 1;
+            if (p.out_split) { if (has_add) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{}); }
+            else { if (has_add) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{}); }
+        } else {
         TileLoads ld[2];
         auto tile_nb = [&](int k) { return MT == 32 ? n0 + wn * TN * 32 + (k / TM) * 32 + c4 * 4 : n0 + wn * TN * 16 + c4 * 4; };   // first of this lane's four columns
         auto tile_mb = [&](int k) { return MT == 32 ? m0 + wm * TM * 32 + (k % TM) * 32 + rq : m0 + wm * TM * 16 + k * 16 + rq; };
-        auto tile_live = [&](int k) { return BMW == BM || MT != 32 || (k % TM) < tm_act; };      // (rows past BM belong to the next tile)
         auto issue_loads = [&](int k, TileLoads &L) {
             if (!tile_live(k)) return;
             const int nb = tile_nb(k), mb = tile_mb(k);
@@ -1125,6 +1251,16 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                         if (nb + e < p.N) dst[e] = o[e];
             }
         }
+        }   // branchy form
+#ifdef MFTX_TIMING
+        if constexpr (MT == 32) {
+            unsigned long long tt3;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt3)::"memory");      // (stores issued, not drained)
+            if (lane == 0) {
+                atomicAdd(&mftx_dbg[8], tt1 - tt0); atomicAdd(&mftx_dbg[9], tt2 - tt1); atomicAdd(&mftx_dbg[10], tt3 - tt2); atomicAdd(&mftx_dbg[11], 1ull);
+            }
+        }
+#endif
         continue;
     }
     const int col_l = lane & (MT - 1);

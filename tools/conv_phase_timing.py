@@ -18,7 +18,8 @@ buf = (C.c_ulonglong * 16)()
 P, h, w = 7, 64, 64
 M = P * h * w
 for name, cin, cout, kh, kw in (("gru zr 1x5 256->256", 256, 256, 1, 5), ("gru q 1x5 256->128", 256, 128, 1, 5),
-                                ("fh1 3x3 128->256", 128, 256, 3, 3), ("convc1 1x1 324->256", 324, 256, 1, 1)):
+                                ("fh1 3x3 128->256", 128, 256, 3, 3), ("convc1 1x1 324->256", 324, 256, 1, 1),
+                                ("convc2 3x3 256->192", 256, 192, 3, 3), ("convf2 3x3 128->64", 128, 64, 3, 3)):
     x = torch.randn(M, cin, device="cuda")
     wt = ops.split_weights(ops.pack_conv_weight(torch.randn(cout, cin, kh, kw, device="cuda") * 0.05))
     b = torch.randn(cout, device="cuda")
@@ -37,6 +38,8 @@ for name, cin, cout, kh, kw in (("gru zr 1x5 256->256", 256, 256, 1, 5), ("gru q
     n = max(buf[6], 1)
     names = ("group0", "waitLDS", "waitDMA", "barrier", "reads+refill", "group1")
     tot = sum(buf[i] for i in range(6))
+    nt = max(buf[11], 1)
+    print(f"{name}: per wave-tile (ticks): prologue {buf[8] / nt:.0f}, K loop {buf[9] / nt:.0f}, epilogue (stores issued) {buf[10] / nt:.0f}; wave-tiles per launch {nt / reps:.0f}")
     print(f"{name}: {e0.elapsed_time(e1) / reps * 1e3:.1f} us; per wave-chunk {tot / n:.0f} ticks (100 MHz ticks x 24 = cycles at 2.4 GHz?): "
           + ", ".join(f"{nm} {buf[i] / n:.1f}" for i, nm in enumerate(names)))
 
