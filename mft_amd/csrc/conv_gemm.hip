@@ -1037,10 +1037,15 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         // row's stores, and each of the 16 row groups of a 64 x 64 wave tile sat out the round trip of the previous
         // group's stores: 27 of a z|r launch's 80 us (tile-phase stamps, tools/conv_phase_timing.py).
         const long long max_ld = EPI == EPI_GRU_ZR || EPI == EPI_GRU_Q ? (p.ld_hx > p.ld_hf ? p.ld_hx : p.ld_hf) : (p.ldo > p.ld_addend ? p.ldo : p.ld_addend);
-        const bool straight = vec_out && (p.N & 3) == 0 && (long long)(p.M + BMW) * (max_ld > 256 ? max_ld : 256) * 4 < 0x7fffffffLL && !(MFTX_SABL & 2048);
+        const bool has_add = pre_add || p.residual_mode == 1;
+        // (N % 4 != 0 -- the motion encoder's 126 channels: the last column group is stored value by value behind one
+        // wave-uniform branch per tile; with an addend as well, the branchy form)
+        const bool n_tail = (p.N & 3) != 0 && EPI != EPI_GRU_ZR && EPI != EPI_GRU_Q;
+        const bool straight = vec_out && ((p.N & 3) == 0 || (n_tail && !has_add)) && (long long)(p.M + BMW) * (max_ld > 256 ? max_ld : 256) * 4 < 0x7fffffffLL && !(MFTX_SABL & 2048);
         if (straight) {
-            auto run = [&](auto osplit_, auto add_) {
-                constexpr bool OS = decltype(osplit_)::value, ADD = decltype(add_)::value;
+            auto run = [&](auto osplit_, auto add_, auto tail_) {
+                constexpr bool OS = decltype(osplit_)::value, ADD = decltype(add_)::value, TAIL = decltype(tail_)::value;
+                const int nbt = p.N & ~3;                 // TAIL: first column of the ragged group
                 auto mk = [&](const void *ptr, long long ld) {
                     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(ptr), 0, (unsigned)((long long)p.M * ld * 4), 0x00020000);
                 };
@@ -1055,7 +1060,8 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                 auto off = [&](int m, int ld, int col, bool ok) { return ok ? (unsigned)(m * ld + col) * 4u : OOB; };
                 auto st128 = [&](const f32x4 &v, __amdgpu_buffer_rsrc_t r, unsigned o) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, o, 0, 0); };
                 // four channels nb .. nb + 3 of a split-form row (row_bytes = its byte offset): high halves, low halves 16 bytes on
-                auto st_split = [&](const f32x4 &v, __amdgpu_buffer_rsrc_t r, unsigned row_bytes, int nb, bool ok) {
+                // (tail > 0, wave-uniform: this tile holds the ragged group; its lane stores `valid` values as 2-byte pieces)
+                auto st_split = [&](const f32x4 &v, __amdgpu_buffer_rsrc_t r, unsigned row_bytes, int nb, bool ok, bool tail = false, int valid = 0) {
                     unsigned h0, h1, l0, l1;
                     const float k2048s = 2048.f;
                     split_pair(v[0], v[1], k2048s, h0, l0);
@@ -1064,6 +1070,15 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2{h0, h1}, r, o, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(u32x2{l0, l1}, r, o + 16u, 0, 0);       // (OOB + 16 stays out of range)
+                    if (TAIL && tail) {
+                        const unsigned hs[4] = {h0 & 0xffffu, h0 >> 16, h1 & 0xffffu, h1 >> 16}, ls[4] = {l0 & 0xffffu, l0 >> 16, l1 & 0xffffu, l1 >> 16};
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) {
+                            const unsigned oe = e < valid ? row_bytes + (unsigned)split_row_offset(nb) + 2u * e : OOB;
+                            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)hs[e], r, oe, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)ls[e], r, oe + 16u, 0, 0);
+                        }
+                    }
                 };
                 TileLoads ld[2];
                 auto loads = [&](int k, TileLoads &L) {
@@ -1086,14 +1101,26 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                 constexpr int NBIAS = MT == 32 ? TN : 1;
                 f32x4 bias_c[NBIAS];
 #pragma unroll
-                for (int j = 0; j < NBIAS; ++j) { const int nb = tnb(j * (MT == 32 ? TM : 1)); bias_c[j] = buf_load(rBias, nb < p.N ? (unsigned)nb * 4u : OOB); }
+                for (int j = 0; j < NBIAS; ++j) {
+                    const int nb = tnb(j * (MT == 32 ? TM : 1));
+                    if constexpr (TAIL) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bias_c[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rBias, nb + e < p.N ? (unsigned)(nb + e) * 4u : OOB, 0, 0));
+                    } else {
+                        bias_c[j] = buf_load(rBias, nb < p.N ? (unsigned)nb * 4u : OOB);
+                    }
+                }
                 loads(0, ld[0]);
 #pragma unroll
                 for (int k = 0; k < ETN; ++k) {
                     if (k + 1 < ETN) loads(k + 1, ld[(k + 1) & 1]);
                     const TileLoads &L = ld[k & 1];
                     const int nb = tnb(k), mb = tmb(k);
-                    const bool okc = nb < p.N && tile_live(k);
+                    const bool okc = (TAIL ? nb + 3 < p.N : nb < p.N) && tile_live(k);
+                    // TAIL: does this tile hold the ragged column group (wave-uniform), and is it this lane's
+                    const int tile_c0 = nb - c4 * 4;
+                    const bool tail_here = TAIL && tile_c0 <= nbt && nbt < tile_c0 + (MT == 32 ? 32 : 64) && tile_live(k);
+                    const int valid = TAIL && nb == nbt ? p.N - nbt : 0;
                     const f32x4 bias4 = bias_c[MT == 32 ? k / TM : 0];
                     if constexpr (MT == 32) {
                         float *w = st + (4 * (lane >> 5)) * 32 + (lane & 31);
@@ -1138,16 +1165,27 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                             st128(o, rHf, off(m, p.ld_hf, nb, okc));
                             if constexpr (OS) st_split(o, rHx, (unsigned)(m * p.ld_hx) * 4u, nb, okc);
                         } else if constexpr (OS) {
-                            st_split(o, rOut, (unsigned)(m * p.ldo) * 4u, nb, okc);
+                            st_split(o, rOut, (unsigned)(m * p.ldo) * 4u, nb, okc, tail_here, valid);
                         } else {
                             st128(o, rOut, off(m, p.ldo, nb, okc));
+                            if (TAIL && tail_here) {
+#pragma unroll
+                                for (int e = 0; e < 3; ++e)
+                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[e]), rOut, off(m, p.ldo, nb + e, e < valid), 0, 0);
+                            }
                         }
                     }
                 }
             };
-            const bool has_add = pre_add || p.residual_mode == 1;
-            if (p.out_split) { if (has_add) run(std::true_type{}, std::true_type{}); else run(std::true_type{}, std::false_type{}); }
-            else { if (has_add) run(std::false_type{}, std::true_type{}); else run(std::false_type{}, std::false_type{}); }
+            using Y = std::true_type;
+            using N_ = std::false_type;
+            bool done = false;
+            if constexpr (EPI != EPI_GRU_ZR && EPI != EPI_GRU_Q) {
+                if ((p.N & 3) != 0) { if (p.out_split) run(Y{}, N_{}, Y{}); else run(N_{}, N_{}, Y{}); done = true; }
+            }
+            if (done) {}
+            else if (p.out_split) { if (has_add) run(Y{}, Y{}, N_{}); else run(Y{}, N_{}, N_{}); }
+            else { if (has_add) run(N_{}, Y{}, N_{}); else run(N_{}, N_{}, N_{}); }
         } else {
         TileLoads ld[2];
         auto tile_nb = [&](int k) { return MT == 32 ? n0 + wn * TN * 32 + (k / TM) * 32 + c4 * 4 : n0 + wn * TN * 16 + c4 * 4; };   // first of this lane's four columns
@@ -1383,15 +1421,16 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat, 
 // tile shapes: 0 = 128x128, 1 = 128x64, 2 = 64x64, 3 = 128x32.  LDS rings of 3 and 4 chunks (counted
 // vmcnt) were measured twice and do not pay at either M = 28672 or M = 4096 (tools/bench_conv.py):
 // the ring is fixed at two chunks, which lets the K loop be unrolled over the slots.
+// (One instantiation per epilogue, each with ~19 kernels: compiled as four translation units beside this one -- the same
+// file with -DMFTX_CONV_PART=<epilogue>, see the Makefile -- so that the build parallelises; -DMFTX_CONV_SINGLE_TU keeps
+// everything here, for the tuning builds of tools/build_ablations.sh.)
 template <int EPI>
-static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) {
+int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) {
     if (a.arith == AR_SPLIT && a.a_pre) {              // A already in split form: the production tiles only
         switch (tile) {
             case 0: return launch_cfg<128, 128, 2, 2, EPI, 32, AR_PRESPLIT, 2>(a, batch, s, cat);
             case 6: return launch_cfg<128, 128, 4, 2, EPI, 32, AR_PRESPLIT, 4>(a, batch, s, cat);
             case 10: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_PRESPLIT, 2>(a, batch, s, cat);
-            case 12: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
-            case 1: return launch_cfg<128, 64, 2, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
             case 14: return launch_cfg<128, 192, 4, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);   // eight waves of 32 x 96: N = 192 without a half-empty column tile
             case 15: return launch_cfg<224, 128, 2, 4, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);   // four waves of 128 x 32 over four of 96 x 32: 7 x 4096 cells = 128 x 224
             case 13: return launch_cfg<112, 256, 1, 4, EPI, 16, AR_PRESPLIT, 3>(a, batch, s, cat);  // four waves of 112 x 64 on 16-row MFMAs: 7 x 4096 cells = 256 tiles
@@ -1401,18 +1440,11 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
     if (a.arith == AR_SPLIT) {
         switch (tile) {
             case 0: return launch_cfg<128, 128, 2, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);   // two workgroups of four 64 x 64 waves per CU
-            case 1: return launch_cfg<128, 64, 2, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
-            case 4: return launch_cfg<64, 128, 2, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
             case 6: return launch_cfg<128, 128, 4, 2, EPI, 32, AR_SPLIT, 4>(a, batch, s, cat);   // eight waves of 32 x 64
-            case 7: return launch_cfg<64, 128, 2, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);
             case 10: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);  // eight waves of 64 x 64: the A tile is staged once for 256 output channels
-            case 11: return launch_cfg<256, 128, 4, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);  // eight waves of 64 x 64: the W tile is staged once for 256 cells
-            case 12: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);  // as 10, ring of three chunks (144 KiB)
             case 14: return launch_cfg<128, 192, 4, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
             case 15: return launch_cfg<224, 128, 2, 4, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
-            case 8: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);
-            case 9: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
-            default: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 4>(a, batch, s, cat);
+            default: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);        // 9
         }
     }
     switch (tile) {
@@ -1424,6 +1456,16 @@ static int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, Pr
         default: return launch_cfg<128, 32, 4, 1, EPI>(a, batch, s, cat);
     }
 }
+
+#if defined(MFTX_CONV_PART)
+template int launch_tile<MFTX_CONV_PART>(int, const ConvArgs &, int, hipStream_t, ProfCat);
+#else
+#if !defined(MFTX_CONV_SINGLE_TU)
+extern template int launch_tile<EPI_GENERIC>(int, const ConvArgs &, int, hipStream_t, ProfCat);
+extern template int launch_tile<EPI_RELU>(int, const ConvArgs &, int, hipStream_t, ProfCat);
+extern template int launch_tile<EPI_GRU_ZR>(int, const ConvArgs &, int, hipStream_t, ProfCat);
+extern template int launch_tile<EPI_GRU_Q>(int, const ConvArgs &, int, hipStream_t, ProfCat);
+#endif
 
 static int pick_tile(const ConvArgs &a, int batch) {
     // debug/tuning override: MFTX_CONV_TILE=0..9
@@ -1644,5 +1686,7 @@ int launch_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, i
     }
     return launch_cfg<128, 128, 4, 1, EPI_VOLUME>(a, P, s, PC_CORR_VOLUME, 2.0 * N * N * (double)C * P);
 }
+
+#endif  // MFTX_CONV_PART
 
 }  // namespace mftx

@@ -687,21 +687,21 @@ def test_conv_tile_shapes_bitwise(tmp_path):
         outs[tile] = np.load(f)
     for tile in (0, 1, 5):
         assert np.array_equal(outs[tile], outs[2]), tile
-    # the same for the split-arithmetic kernels: 128x128 (four and eight waves), 64x128, 64x64, 128x256, 256x128,
-    # rings of two to four chunks
+    # the same for the split-arithmetic kernels: 128x128 (four and eight waves), 64x64, 128x256, 128x192, 224x128 (uneven
+    # wave rows), rings of two to four chunks
     outs = {}
-    for tile in (0, 6, 7, 9, 10, 11, 14, 15):
+    for tile in (0, 6, 9, 10, 14, 15):
         f = tmp_path / f"s{tile}.npy"
         env = dict(os.environ, MFTX_CONV_TILE=str(tile), MFTX_TILE_WORKER_ARITH="1")
         res = subprocess.run([sys.executable, str(worker), str(f)], env=env, capture_output=True, text=True, timeout=300)
         assert res.returncode == 0, res.stderr[-2000:]
         outs[tile] = np.load(f)
-    for tile in (6, 7, 9, 10, 11, 14, 15):
+    for tile in (6, 9, 10, 14, 15):
         assert np.array_equal(outs[tile], outs[0]), tile
     # and for a pre-split A operand, including the 112 x 256 tile on 16x16x32 MFMAs (whose k slots are fed so that every
     # accumulator sees the sequence of the 32x32x16 form)
     outs = {}
-    for tile in (0, 1, 6, 9, 10, 12, 13, 14, 15):
+    for tile in (0, 6, 9, 10, 13, 14, 15):
         f = tmp_path / f"p{tile}.npy"
         env = dict(os.environ, MFTX_CONV_TILE=str(tile), MFTX_TILE_WORKER_ARITH="2")
         if tile == 0:
@@ -709,5 +709,5 @@ def test_conv_tile_shapes_bitwise(tmp_path):
         res = subprocess.run([sys.executable, str(worker), str(f)], env=env, capture_output=True, text=True, timeout=300)
         assert res.returncode == 0, res.stderr[-2000:]
         outs[tile] = np.load(f)
-    for tile in (1, 6, 9, 10, 12, 13, 14, 15):
+    for tile in (6, 9, 10, 13, 14, 15):
         assert np.array_equal(outs[tile], outs[0]), tile

@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../mft_amd/csrc"
 mkdir -p abl
 for b in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DMFTX_SABL=${b/[TP]/0} $( [ "$b" = T ] && echo -DMFTX_TIMING=1 ) $( [ "$b" = P ] && echo -DMFTX_TIMING=2 ) -c conv_gemm.hip -o abl/conv_gemm_$b.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DMFTX_CONV_SINGLE_TU -DMFTX_SABL=${b/[TP]/0} $( [ "$b" = T ] && echo -DMFTX_TIMING=1 ) $( [ "$b" = P ] && echo -DMFTX_TIMING=2 ) -c conv_gemm.hip -o abl/conv_gemm_$b.o &
 done
 wait
 for b in "$@"; do
