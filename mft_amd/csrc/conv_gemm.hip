@@ -1171,7 +1171,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                             if (TAIL && tail_here) {
 #pragma unroll
                                 for (int e = 0; e < 3; ++e)
-                                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[e]), rOut, off(m, p.ldo, nb + e, e < valid), 0, 0);
+                                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[e]), rOut, off(m, p.ldo, nb + e, e < valid), 0, 0);   // (not __builtin_bit_cast of a vector element: this compiler then stores element 0 every time)
                             }
                         }
                     }

@@ -259,6 +259,34 @@ def test_conv2d_split_form_operands(ops_mod, cin, cout, kh, kw, P, h, w, x2c):
         assert bool((dec[:, cout:] == 7.0).all())
 
 
+@pytest.mark.parametrize("N,ldo,act", [(126, 128, "relu"), (125, 128, None), (62, 64, "relu"), (254, 256, "tanh"), (190, 192, "relu")])
+def test_conv2d_split_ragged_n_into_wider_rows(ops_mod, N, ldo, act):
+    """N % 4 != 0 with 16-byte aligned output rows (the motion encoder's 126 channels next to the 2 flow channels): the
+    straight-line epilogue stores the last column group value by value -- fp32 and split-form outputs, every tile
+    shape the layer sizes select; the columns past N keep their contents."""
+    g = torch.Generator().manual_seed(N)
+    P, h, w, cin = 2, 40, 56, 64
+    M = P * h * w
+    x = torch.randn(M, cin, generator=g).to(DEV)
+    wt = (torch.randn(N, cin, 3, 3, generator=g) * 0.05).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    ref = F.conv2d(x.double().reshape(P, h, w, cin).permute(0, 3, 1, 2), wt.double(), b.double(), padding=1)
+    ref = {"relu": torch.relu, "tanh": torch.tanh, None: lambda t: t}[act](ref).permute(0, 2, 3, 1).reshape(M, N)
+    ws = ops_mod.split_weights(ops_mod.pack_conv_weight(wt))
+    xs = ops_mod.split_activations(x)
+    out = torch.full((M, ldo), 7.0, device=DEV)
+    ops_mod.conv2d(xs, ws, b, P, h, w, N, 3, 3, act=act, arith=ops_mod.ARITH_SPLIT, a_split=True, out=out)
+    assert maxerr(out[:, :N].double(), ref) < 2e-5
+    assert bool((out[:, N:] == 7.0).all())
+    if ldo % 8 == 0:
+        outs = ops_mod.split_activations(torch.full((M, ldo), 7.0, device=DEV))
+        ops_mod.conv2d(xs, ws, b, P, h, w, N, 3, 3, act=act, arith=ops_mod.ARITH_SPLIT, a_split=True, out_split=True, out=outs)
+        dec = ops_mod.unsplit_activations(outs)
+        assert torch.equal(dec[:, :N], ops_mod.unsplit_activations(ops_mod.split_activations(
+            torch.cat([out[:, :N], torch.zeros(M, ldo - N, device=DEV)], 1)))[:, :N])
+        assert bool((dec[:, N:] == 7.0).all())
+
+
 def test_conv2d_split_arith_errors(ops_mod):
     from mft_amd._lib import MftxError
     x = torch.zeros(16 * 24, 256, device=DEV)
