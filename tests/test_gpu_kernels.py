@@ -697,6 +697,28 @@ def test_raft_engine_argument_errors(ops_mod, weights_np):
     assert bool(torch.isfinite(flow).all()) and float(occl.min()) >= 0 and float(sigma.min()) >= 0
 
 
+def test_engine_register_split_bitwise(tmp_path):
+    """The refinement engine with fp32 activations split in the GEMMs' registers (MFTX_RAFT_NOPRESPLIT: other kernels,
+    other epilogue variants, GRU state in fp32 only) agrees with the default engine (activations stored in split form by
+    their producers) to the last digits; with the lookup / convf1 launches kept apart (MFTX_RAFT_NOFUSE) bit for bit."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    worker = Path(__file__).with_name("engine_worker.py")
+    outs = {}
+    for tag, extra in (("default", {}), ("nopresplit", {"MFTX_RAFT_NOPRESPLIT": "1"}), ("nofuse", {"MFTX_RAFT_NOFUSE": "1"})):
+        f = tmp_path / f"{tag}.npy"
+        res = subprocess.run([sys.executable, str(worker), str(f)], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs[tag] = np.load(f)
+    assert np.isfinite(outs["default"]).all()
+    assert np.array_equal(outs["nofuse"], outs["default"])
+    # (not bit for bit: the OU heads' gather reads h back from its split form, hi + lo / 2048, which re-splits to another
+    # pair of halves in rare rounding ties -- differences of an ulp in their inputs)
+    assert np.abs(outs["nopresplit"] - outs["default"]).max() < 2e-5
+
+
 def test_conv_tile_shapes_bitwise(tmp_path):
     """Every tile shape -- 128x128, 128x64, 64x64 on v_mfma_f32_32x32x2_f32 and the 32x32 tile of
     v_mfma_f32_16x16x4_f32 waves used for very small M x N -- gives the same bits: the reduction order
