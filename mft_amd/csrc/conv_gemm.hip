@@ -197,6 +197,10 @@ __device__ __forceinline__ float fast_tanh(float s) {
     return copysignf((1.f - t) * __frcp_rn(1.f + t), s);
 }
 
+// h <- (1 - z) h + z q, with the contraction spelled out: the scalar and the vectorised epilogues (and every tile shape) must
+// round alike, whatever the compiler would fuse in each
+__device__ __forceinline__ float gru_blend(float z, float h, float q) { return __fmaf_rn(z, q, __fmul_rn(__fsub_rn(1.f, z), h)); }
+
 __device__ __forceinline__ float act_fn(float v, int act) {
     switch (act) {
         case 1: return fmaxf(v, 0.f);
@@ -1006,7 +1010,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
 #endif
         continue;
     }
-    if constexpr (SPLIT) {
+    if constexpr (SPLIT || MT == 32) {      // (the fp32-MFMA kernels of 32 x 32 tiles too: same C/D layout)
         // Vectorised epilogue: each 32 x 32 accumulator tile goes through 4 KiB of the wave's own LDS (the ring is
         // free now) and comes back as four float4 per lane -- row t * 8 + (lane >> 3), columns 4 (lane & 7) .. + 3:
         // the addend / z / h reads and the stores become 16-byte accesses, a quarter of the instructions of the
@@ -1150,7 +1154,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                                 const float g = fast_sigmoid(sv);
                                 o[e] = nb < 128 ? g : g * L.a1[t][e];
                             } else if constexpr (EPI == EPI_GRU_Q) {
-                                o[e] = (1.f - L.a0[t][e]) * L.a1[t][e] + L.a0[t][e] * fast_tanh(sv);
+                                o[e] = gru_blend(L.a0[t][e], L.a1[t][e], fast_tanh(sv));
                             } else {
                                 float g = act_fn(sv, p.act) * p.out_scale;
                                 if (ADD && p.residual_mode == 1) g = fmaxf(g + L.add[t][e], 0.f);
@@ -1180,11 +1184,16 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
             using Y = std::true_type;
             using N_ = std::false_type;
             bool done = false;
+            // (split-form outputs exist in the split arithmetic only)
             if constexpr (EPI != EPI_GRU_ZR && EPI != EPI_GRU_Q) {
-                if ((p.N & 3) != 0) { if (p.out_split) run(Y{}, N_{}, Y{}); else run(N_{}, N_{}, Y{}); done = true; }
+                if ((p.N & 3) != 0) {
+                    if constexpr (SPLIT) { if (p.out_split) run(Y{}, N_{}, Y{}); else run(N_{}, N_{}, Y{}); }
+                    else run(N_{}, N_{}, Y{});
+                    done = true;
+                }
             }
             if (done) {}
-            else if (p.out_split) { if (has_add) run(Y{}, Y{}, N_{}); else run(Y{}, N_{}, N_{}); }
+            else if (SPLIT && p.out_split) { if constexpr (SPLIT) { if (has_add) run(Y{}, Y{}, N_{}); else run(Y{}, N_{}, N_{}); } }
             else { if (has_add) run(N_{}, Y{}, N_{}); else run(N_{}, N_{}, N_{}); }
         } else {
         TileLoads ld[2];
@@ -1259,7 +1268,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                         const float g = fast_sigmoid(sv);
                         o[e] = nb < 128 ? g : g * L.a1[t][e];
                     } else if constexpr (EPI == EPI_GRU_Q) {    // candidate q, h <- (1-z) h + z q
-                        o[e] = (1.f - L.a0[t][e]) * L.a1[t][e] + L.a0[t][e] * fast_tanh(sv);
+                        o[e] = gru_blend(L.a0[t][e], L.a1[t][e], fast_tanh(sv));
                     } else {
                         float g = act_fn(sv, p.act) * p.out_scale;
                         if (p.residual_mode == 1) g = fmaxf(g + L.add[t][e], 0.f);
@@ -1341,7 +1350,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                     else p.rh[m * 128 + (n - 128)] = v * aux1[r];
                 } else if constexpr (EPI == EPI_GRU_Q) {    // candidate q, h <- (1-z) h + z q
                     const float v = fast_tanh(s);
-                    p.hx[m * p.ld_hx + n] = (1.f - aux0[r]) * aux1[r] + aux0[r] * v;
+                    p.hx[m * p.ld_hx + n] = gru_blend(aux0[r], aux1[r], v);
                 } else {
                     float v = act_fn(s, p.act) * p.out_scale;
                     if (p.residual_mode == 1) v = fmaxf(v + add[r], 0.f);
