@@ -1,4 +1,7 @@
-// fp32-MFMA implicit-GEMM convolution / NT-GEMM for gfx950 (MI355X).
+// MFMA implicit-GEMM convolution / NT-GEMM for gfx950 (MI355X): fp32 products either on the fp32 matrix instructions or,
+// by default, as three fp16 MFMAs on split operands (enum Arith below).  What this header describes is common to both;
+// the split-arithmetic K loop (LDS ring of 2-4 chunks, peeled, DMA pieces and operand splits slotted between the MFMAs)
+// and the vectorised, branch-free epilogue are described where they stand.
 //
 //   out[m][n] = epilogue( sum_{tap,c} A[cell(m)+off(tap)][c] * W[n][tap][c] + bias[n] )
 //
