@@ -287,6 +287,26 @@ def test_conv2d_split_ragged_n_into_wider_rows(ops_mod, N, ldo, act):
         assert bool((dec[:, N:] == 7.0).all())
 
 
+@pytest.mark.parametrize("cin", [32, 64, 96, 128, 160])
+@pytest.mark.parametrize("cout,P", [(256, 7), (128, 7), (192, 7), (64, 7), (256, 1)])
+def test_conv2d_split_short_k(ops_mod, cin, cout, P):
+    """One to five K chunks -- fewer than, as many as, and more than the chunks of the LDS ring (2 to 4 by tile shape): the
+    peeled K loop's three parts in every combination, on the tile shapes the sizes select (128 x 256, 128 x 128 of eight
+    waves, 128 x 192, 64 x 64), A split in registers and stored split."""
+    g = torch.Generator().manual_seed(cin + cout + P)
+    h = w = 64
+    M = P * h * w
+    x = torch.randn(M, cin, generator=g).to(DEV)
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) * 0.1).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    ref = x.double() @ wt.double().reshape(cout, cin).t() + b.double()
+    ws = ops_mod.split_weights(ops_mod.pack_conv_weight(wt))
+    y = ops_mod.conv2d(x, ws, b, P, h, w, cout, 1, 1, arith=ops_mod.ARITH_SPLIT)
+    assert maxerr(y.double(), ref) < 1e-5
+    y2 = ops_mod.conv2d(ops_mod.split_activations(x), ws, b, P, h, w, cout, 1, 1, arith=ops_mod.ARITH_SPLIT, a_split=True)
+    assert torch.equal(y2, y)
+
+
 def test_conv2d_split_arith_errors(ops_mod):
     from mft_amd._lib import MftxError
     x = torch.zeros(16 * 24, 256, device=DEV)
