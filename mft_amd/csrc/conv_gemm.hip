@@ -1441,8 +1441,8 @@ int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, ProfCat c
     if (a.arith == AR_SPLIT && a.a_pre) {              // A already in split form: the production tiles only
         switch (tile) {
             case 0: return launch_cfg<128, 128, 2, 2, EPI, 32, AR_PRESPLIT, 2>(a, batch, s, cat);
-            case 6: return launch_cfg<128, 128, 4, 2, EPI, 32, AR_PRESPLIT, 4>(a, batch, s, cat);
-            case 10: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_PRESPLIT, 2>(a, batch, s, cat);
+            case 6: return launch_cfg<128, 128, 4, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);       // (ring of three: 125.1 -> 126.2 frames/s against four)
+            case 10: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
             case 14: return launch_cfg<128, 192, 4, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);   // eight waves of 32 x 96: N = 192 without a half-empty column tile
             case 15: return launch_cfg<224, 128, 2, 4, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);   // four waves of 128 x 32 over four of 96 x 32: 7 x 4096 cells = 128 x 224
             case 13: return launch_cfg<112, 256, 1, 4, EPI, 16, AR_PRESPLIT, 3>(a, batch, s, cat);  // four waves of 112 x 64 on 16-row MFMAs: 7 x 4096 cells = 256 tiles
@@ -1453,7 +1453,7 @@ int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, ProfCat c
         switch (tile) {
             case 0: return launch_cfg<128, 128, 2, 2, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);   // two workgroups of four 64 x 64 waves per CU
             case 6: return launch_cfg<128, 128, 4, 2, EPI, 32, AR_SPLIT, 4>(a, batch, s, cat);   // eight waves of 32 x 64
-            case 10: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_SPLIT, 2>(a, batch, s, cat);  // eight waves of 64 x 64: the A tile is staged once for 256 output channels
+            case 10: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);  // eight waves of 64 x 64: the A tile is staged once for 256 output channels; ring of three chunks (144 KiB): standalone layers lose a microsecond to it, the engine -- inputs fresh from the previous kernel, longer latencies -- gains 2.3 % (123.9 -> 126.7 frames/s)
             case 14: return launch_cfg<128, 192, 4, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
             case 15: return launch_cfg<224, 128, 2, 4, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
             default: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);        // 9

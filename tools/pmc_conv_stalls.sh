@@ -4,7 +4,7 @@ set -u
 TILE=${1:-6}; AR=${2:-1}; LAYER=${3:-gru zr 1x5}
 OUT=gpurun_out/stalls_t${TILE}_a${AR}
 mkdir -p $OUT; export TMPDIR=/tmp
-CMD="python tools/bench_conv.py --P 7 --arith $AR --reps 5 --only"
+CMD="python tools/bench_conv.py --P 7 --arith $AR --a-split --out-split --reps 5 --only"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC" \
