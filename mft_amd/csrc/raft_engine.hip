@@ -355,8 +355,10 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         // and convf1 -> convf2 on the flow.  Both need only coords1.  Split arithmetic, small batches (up to four
         // 512 x 512 pairs: the kernels leave CUs idle): the flow branch runs on the handle's SIDE STREAM beside the
         // correlation branch and joins in front of `conv` -- 3.67 -> 3.45 ms at one pair, 5.94 -> 5.59 at four
-        // (tools/bench_pairs.py); at seven pairs every kernel fills the chip and the two stream hand-overs per iteration
-        // cost more than the overlap gives (106.7 vs 111.5 frames/s): in order on one stream.  fp32 MFMA keeps round 1's grouping (lookup + convf1 in one launch,
+        // (tools/bench_pairs.py).  At seven pairs this used to lose (every kernel filled the chip: 106.7 vs 111.5 frames/s);
+        // since convc2 runs as 224 workgroups of the 128 x 192 tile, 32 CUs are free beside it and its 1 x 1 predecessor
+        // for the flow branch's small kernels: 129.2 -> 130.3 frames/s (MFTX_RAFT_FORK=0: in order on one stream, with
+        // lookup + convf1 as one launch).  fp32 MFMA keeps round 1's grouping (lookup + convf1 in one launch,
         // convc2 + convf2 in one launch).  The per-kernel timing pass and MFTX_RAFT_NOFUSE run everything in order.
         const ConvF1Args f1{ws.coords1, W[W_CONVF1], W[B_CONVF1], ws.flo1, ws.hx, h, w, strips, P * h * strips, SP ? 1 : 0};
         const int f1_blocks = cdiv(f1.n_strips, 2);
@@ -365,7 +367,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         const mftx_conv_desc c2 = gemm(conv_desc(ws.cor1, 256, 256, nullptr, 0, 0, G[W_CONVC2], W[B_CONVC2], ws.corflo, 256, P, h, w, 192, 3, 3, 1), true, true);
         const mftx_conv_desc f2 = gemm(conv_desc(ws.flo1, 128, 128, nullptr, 0, 0, G[W_CONVF2], W[B_CONVF2], ws.corflo + 192, 256, P, h, w, 64, 3, 3, 1), true, true);
         static const int fork_env = [] { const char *e = getenv("MFTX_RAFT_FORK"); return e ? atoi(e) : -1; }();   // tuning: 0 never, 1 always
-        const bool serial = prof_enabled() || nofuse || (AR == MFTX_ARITH_SPLIT && (fork_env == 0 || (fork_env < 0 && M > 20000)));
+        const bool serial = prof_enabled() || nofuse || (AR == MFTX_ARITH_SPLIT && fork_env == 0);
         const bool forked = !serial && AR == MFTX_ARITH_SPLIT;
         if (forked) {
             TRY(ensure_side_stream(r));
