@@ -57,7 +57,7 @@ F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16 /
 SPLIT_PRODUCTS = 3              # split arithmetic: fp16 MFMA products per fp32 product (hi hi + hi lo + lo hi)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak
 CATS = ["corr_volume_gemm", "corr_pool", "corr_lookup", "conv_gemm", "convf1", "glue", "convex_upsample",
-        "chain_select", "conv_small_n", "encoder_instnorm"]
+        "chain_select", "conv_small_n", "encoder_instnorm", "lookup_convc1_fused"]
 FLOP_CATS = {0, 3, 4, 8}
 VALU_CATS = {4, 8}
 FULL_PAIRS = 7                  # flow pairs per frame once every delta is live

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MFTX_VERSION 200
+#define MFTX_VERSION 300
 
 #define MFTX_E_ARG (-1)      /* null pointer / non-positive size / unsupported shape */
 #define MFTX_E_ALIGN (-2)    /* pointer or leading dimension not 16-byte aligned */
@@ -49,9 +49,9 @@ const char *mftx_last_error_string(void);
 /* Optional per-kernel timing (HIP events on the launch stream; bench.py's
  * roofline leg).  Categories: 0 corr volume GEMM, 1 pyramid pooling, 2 lookup,
  * 3 conv implicit GEMM, 4 convf1, 5 glue, 6 convex upsample, 7 chain/select,
- * 8 small-N conv, 9 encoder instance-norm passes.
- * work[] = algorithmic flops (0, 3, 4, 8) or bytes (1, 2, 6, 7, 9) booked per launch. */
-#define MFTX_PROFILE_CATEGORIES 10
+ * 8 small-N conv, 9 encoder instance-norm passes, 10 lookup fused into convc1.
+ * work[] = algorithmic flops (0, 3, 4, 8) or bytes (1, 2, 6, 7, 9, 10) booked per launch. */
+#define MFTX_PROFILE_CATEGORIES 11
 int mftx_profile_begin(void);
 int mftx_profile_end(double *ms, double *work, long long *count, int n);
 
@@ -85,6 +85,21 @@ int mftx_corr_pyramid_layout(int h, int w, long long *stride, int *block_grid);
 int mftx_corr_lookup(const float *lvl0, const float *lvl1, const float *lvl2, const float *lvl3,
                      const float *coords, int P, int h, int w, int r,
                      float *out, int ld_out, void *stream);
+
+/* ---- a6 + first layer of a7, fused: lookup -> convc1 without materialising the 324 features ----------------------
+ * Replaces CorrBlock.__call__ (core/corr.py:30-51) TOGETHER WITH its consumer, the first layer of the motion encoder
+ * cor = relu(convc1(corr)) (core/update.py:152-153), in the split-fp16 arithmetic (MFTX_ARITH_SPLIT):
+ *   out[m][n] = relu(sum_k lookup(m)[k] * W[n][k] + bias[n]),  n < 256,
+ * with lookup(m) exactly what mftx_corr_lookup writes for cell m -- it stays in the CU's LDS.
+ * wfused: MFTX_LOOKUP_CONVC1_WEIGHT_BYTES bytes (16-byte aligned) filled by mftx_pack_lookup_convc1_weights from
+ * convc1's weight in the mftx_conv2d packing, wpk = [256][ld_w] fp32 with ld_w >= 324 (channel l*81 + a*9 + b).
+ * out: pixel-major [P*h*w][ld_out] (ld_out >= 256; a multiple of 8 and 32-byte aligned rows when out_split), fp32 or
+ * -- out_split != 0 -- the split form of mftx_conv_desc.out_split.  bias: 256 floats, 16-byte aligned. */
+#define MFTX_LOOKUP_CONVC1_WEIGHT_BYTES 393216
+int mftx_pack_lookup_convc1_weights(const float *wpk, int ld_w, void *wfused, void *stream);
+int mftx_corr_lookup_convc1(const float *lvl0, const float *lvl1, const float *lvl2, const float *lvl3,
+                            const float *coords, int P, int h, int w, const void *wfused, const float *bias,
+                            float *out, int ld_out, int out_split, void *stream);
 
 /* ---- a17: on-demand correlation lookup (no stored volume) ------------------------------------------------
  * Replaces AlternateCorrBlock + the optional CUDA op alt_cuda_corr (MFT/RAFT/core/corr.py:72-100,
@@ -137,9 +152,24 @@ typedef struct mftx_conv_desc {
 #define MFTX_ARITH_F32 0
 #define MFTX_ARITH_SPLIT 1
 int mftx_conv2d(const mftx_conv_desc *d, void *stream);
+/* The same with the workgroup tile shape forced (tests and micro-benchmarks; -1 = the library's choice, as mftx_conv2d).
+ * Every shape gives the same bits.  fp32 MFMA: 0 128x128, 1 128x64, 2 64x64, 3 128x32, 4 64x128, 5 32x32 of 16x16 MFMAs;
+ * split arithmetic: 0 128x128 (4 waves), 6 128x128 (8 waves), 9 64x64, 10 128x256, 14 128x192 (13, 15: measurement-only
+ * shapes, built with -DMFTX_EXPERIMENTAL_TILES only).  A shape that does not exist for the arithmetic falls back to the
+ * arithmetic's default small tile. */
+int mftx_conv2d_tile(const mftx_conv_desc *d, int tile, void *stream);
 /* packed fp32 weights (n_floats of them, a multiple of 8) -> the split form MFTX_ARITH_SPLIT streams: same size,
  * every 8 consecutive floats replaced by their 8 fp16 high halves and 8 fp16 low halves (x 2048) */
 int mftx_split_weights(const float *wpk, void *out, long long n_floats, void *stream);
+/* Range guard of MFTX_ARITH_SPLIT.  The high half of an operand is fp16(x): finite for |x| < 65520 (documented limit:
+ * 65504, the largest fp16).  Beyond it hi = +-inf, the residual is -+inf and every product the operand takes part in
+ * is NaN -- an out-of-range operand surfaces as NaN in the outputs of that cell's receptive field, never as a finite wrong
+ * value (tests/test_gpu_kernels.py::test_split_arith_out_of_range_is_nan).  *count (device, caller-zeroed) is incremented
+ * by the number of elements with !(|x| < limit), NaN included; limit = INFINITY counts the non-finite ones.  The Python
+ * plugin checks every weight tensor with it at load (falls back to MFTX_ARITH_F32 with a logged reason) and, with
+ * raft_params.check_finite, the outputs of every refinement (raises). */
+#define MFTX_SPLIT_LIMIT 65504.0f
+int mftx_count_not_below(const float *x, long long n, float limit, unsigned *count, void *stream);
 
 /* ---- a2, a7-a12: the whole RAFT refinement loop ----------------------------
  * Replaces RAFT.forward from the correlation volume on (core/raft.py:141-226)
@@ -161,6 +191,20 @@ int mftx_raft_set_ondemand(mftx_raft *r, int on);
  * MFTX_ARITH_F32 (the state after mftx_raft_create).  The pointers are kept, not copied.  mftx_raft_arith: current mode. */
 int mftx_raft_set_split_weights(mftx_raft *r, const void *const *split, int n);
 int mftx_raft_arith(const mftx_raft *r);
+/* wfused (mftx_pack_lookup_convc1_weights of the engine's convc1 weight; the pointer is kept): with the split arithmetic
+ * and the stored pyramid, every iteration then runs lookup + convc1 as the one fused kernel above; the 324 features are
+ * materialised on the last iteration only, for the occlusion / uncertainty heads (core/raft.py:199-206).  NULL: off. */
+int mftx_raft_set_lookup_fused(mftx_raft *r, const void *wfused);
+/* Per-handle scheduling options (no global state; defaults are the measured best):
+ *   MFTX_RAFT_OPT_FORK      -1 default (flow branch of the motion encoder on a side stream with the split arithmetic), 0 never, 1 always
+ *   MFTX_RAFT_OPT_PRESPLIT   1 default (GEMM inputs kept in split form in the workspace), 0 fp32 activations split in registers
+ *   MFTX_RAFT_OPT_GROUP      1 default (fp32 MFMA: lookup + convf1 and convc2 + convf2 as grouped launches), 0 one launch per layer
+ *   MFTX_RAFT_OPT_FUSE_LOOKUP 1 default (use the fused lookup + convc1 kernel when its weights are set), 0 keep them apart */
+#define MFTX_RAFT_OPT_FORK 0
+#define MFTX_RAFT_OPT_PRESPLIT 1
+#define MFTX_RAFT_OPT_GROUP 2
+#define MFTX_RAFT_OPT_FUSE_LOOKUP 3
+int mftx_raft_set_option(mftx_raft *r, int option, int value);
 size_t mftx_raft_workspace_bytes_for(const mftx_raft *r, int P, int h, int w);
 /* Byte offsets (19 of them) of the workspace regions lvl0..3, coords1, corr,
  * cor1, corflo, flo1, hx, z, rh, fh, delta, mask, ouin, ouh, ou, flow_lr: after

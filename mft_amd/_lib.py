@@ -11,6 +11,8 @@ LIB_PATH = _HERE / "libmftx.so"
 
 MAX_CANDIDATES = 16
 NUM_RAFT_WEIGHTS = 34
+LOOKUP_CONVC1_WEIGHT_BYTES = 393216
+SPLIT_LIMIT = 65504.0      # MFTX_SPLIT_LIMIT: operands of the split arithmetic must stay below it in magnitude
 
 
 class ConvDesc(C.Structure):
@@ -45,10 +47,17 @@ SIGNATURES = {
     "mftx_raft_set_ondemand": (C.c_int, [C.c_void_p, C.c_int]),
     "mftx_raft_workspace_bytes_for": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "mftx_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "mftx_conv2d_tile": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_void_p]),
     "mftx_encoder_set_split_weights": (C.c_int, [C.c_void_p, _PP, C.c_int]),
     "mftx_raft_set_split_weights": (C.c_int, [C.c_void_p, _PP, C.c_int]),
     "mftx_raft_arith": (C.c_int, [C.c_void_p]),
+    "mftx_raft_set_lookup_fused": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mftx_raft_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mftx_pack_lookup_convc1_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mftx_corr_lookup_convc1": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p, C.c_void_p,
+                                                                            C.c_int, C.c_int, C.c_void_p]),
     "mftx_split_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "mftx_count_not_below": (C.c_int, [C.c_void_p, C.c_longlong, C.c_float, C.c_void_p, C.c_void_p]),
     "mftx_raft_create": (C.c_int, [_PP, C.c_int, C.POINTER(C.c_void_p)]),
     "mftx_raft_destroy": (None, [C.c_void_p]),
     "mftx_raft_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

@@ -138,6 +138,22 @@ extern "C" int mftx_dequantize_u16(const uint16_t *q, long long n, float lo, flo
 // IDAT stream of a non-interlaced image: height x (1 filter byte + row_bytes); the reconstructed
 // pixels are compacted to the front (height x row_bytes).  Host code: byte-serial by definition
 // (every byte depends on its left neighbour), so it lives here rather than in a Python loop.
+// ---- range guard of the split arithmetic (MFTX_ARITH_SPLIT): hi = fp16(x) needs |x| < 65504 ---------------------------------
+__global__ void count_not_below_kernel(const float *__restrict__ x, long long n, float limit, unsigned *__restrict__ count) {
+    unsigned bad = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        bad += !(fabsf(x[i]) < limit);                    // (NaN counts)
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor((int)bad, o);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, bad);
+}
+
+extern "C" int mftx_count_not_below(const float *x, long long n, float limit, unsigned *count, void *stream) {
+    if (!x || !count || n <= 0) return fail(MFTX_E_ARG, "count_not_below: bad arguments");
+    const long long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(count_not_below_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, x, n, limit, count);
+    return check_launch("count_not_below");
+}
+
 extern "C" int mftx_png_unfilter(uint8_t *rows, int height, int row_bytes, int bpp) {
     if (!rows || height <= 0 || row_bytes <= 0 || bpp <= 0 || bpp > 8) return fail(MFTX_E_ARG, "png_unfilter: bad arguments");
     const uint8_t *prev = nullptr;

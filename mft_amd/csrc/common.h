@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include "../../include/mftx.h"
 
 namespace mftx {
@@ -27,6 +28,18 @@ inline int check_launch(const char *what) {
         return (int)e;
     }
     return 0;
+}
+
+// Tuning switches of tools/ (micro-benchmarks, A/B builds): environment variables are read in -DMFTX_TUNING builds only;
+// the product build compiles the defaults in and reads no global state.
+inline int tune_env(const char *name, int dflt) {
+#ifdef MFTX_TUNING
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -101,7 +114,7 @@ __device__ __forceinline__ void store_split4v(float *row, int c, float4 v) {
     *reinterpret_cast<uint2 *>(dst + 16) = make_uint2((a >> 16) | (b & 0xffff0000u), (cc >> 16) | (d & 0xffff0000u));
 }
 #endif
-int launch_conv(const mftx_conv_desc &d, hipStream_t s);
+int launch_conv(const mftx_conv_desc &d, hipStream_t s, int tile = -1);      // tile >= 0: forced tile shape (mftx_conv2d_tile)
 int launch_conv_pair(const mftx_conv_desc &a, const mftx_conv_desc &b, hipStream_t s);   // two independent ReLU convs, one launch
 // conv whose epilogue is a GRU gate (see conv_gemm.hip)
 struct GruEpilogue {
@@ -124,6 +137,11 @@ int launch_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, i
                         float *f2_split = nullptr);
 int launch_corr_lookup(const float *const lvl[4], const float *coords, int P, int h, int w,
                        float *out, int ld_out, hipStream_t s);
+// lookup fused into convc1 (csrc/lookup_convc1.hip): out = relu(convc1(lookup(coords)) + bias), [M][ld_out], fp32 or split form
+int launch_pack_lookup_convc1(const float *w, int ld_w, void *out, hipStream_t s);
+bool lookup_convc1_applicable(int P, int h, int w, int ld_out);
+int launch_lookup_convc1(const float *const lvl[4], const float *coords, int P, int h, int w, const void *wf,
+                         const float *bias, float *out, int ld_out, int out_split, hipStream_t s);
 // on-demand correlation (csrc/corr_ondemand.hip): pooled feature pyramid + lookup without a stored volume
 int launch_fmap_pyramid(const float *f2, int P, int C, int h, int w, float *const lvl[3], hipStream_t s);
 int launch_corr_ondemand(const float *f1, const float *const f2lvl[4], const float *coords, int P, int h, int w,

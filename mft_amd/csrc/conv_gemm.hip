@@ -1417,11 +1417,11 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat, 
     ConvArgs args = a;
     args.batch = batch;
     // resident workgroups per CU: LDS-bound (160 KiB per CU), at most MFTX_CONV_RESIDENT_WAVES waves
-    static const int max_waves = [] { const char *e = getenv("MFTX_CONV_RESIDENT_WAVES"); return e ? atoi(e) : 16; }();
+    static const int max_waves = tune_env("MFTX_CONV_RESIDENT_WAVES", 16);
     const int max_res = max_waves / (WM * WN);
     const int resident = (160 * 1024) / (int)lds < max_res ? (160 * 1024) / (int)lds : max_res;
     const long long n_virtual = 8ll * cdiv(cdiv(a.M, BM), 8) * cdiv(a.N, BN) * batch;
-    static const bool one_tile_per_wg = getenv("MFTX_CONV_NONPERSISTENT") != nullptr;   // tuning: let the dispatcher interleave kernels of two streams
+    static const bool one_tile_per_wg = tune_env("MFTX_CONV_NONPERSISTENT", 0) != 0;   // tuning: let the dispatcher interleave kernels of two streams
     const long long slots = one_tile_per_wg ? n_virtual : (long long)num_cus() * resident;
     dim3 grid((unsigned)(n_virtual < slots ? n_virtual : slots));
     // algorithmic flops: real (unpadded) reduction length
@@ -1444,8 +1444,10 @@ int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, ProfCat c
             case 6: return launch_cfg<128, 128, 4, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);       // (ring of three: 125.1 -> 126.2 frames/s against four)
             case 10: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
             case 14: return launch_cfg<128, 192, 4, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);   // eight waves of 32 x 96: N = 192 without a half-empty column tile
+#ifdef MFTX_EXPERIMENTAL_TILES       // measurement-only shapes: bit-identical, slower
             case 15: return launch_cfg<224, 128, 2, 4, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);   // four waves of 128 x 32 over four of 96 x 32: 7 x 4096 cells = 128 x 224
             case 13: return launch_cfg<112, 256, 1, 4, EPI, 16, AR_PRESPLIT, 3>(a, batch, s, cat);  // four waves of 112 x 64 on 16-row MFMAs: 7 x 4096 cells = 256 tiles
+#endif
             default: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
         }
     }
@@ -1455,7 +1457,9 @@ int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, ProfCat c
             case 6: return launch_cfg<128, 128, 4, 2, EPI, 32, AR_SPLIT, 4>(a, batch, s, cat);   // eight waves of 32 x 64
             case 10: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);  // eight waves of 64 x 64: the A tile is staged once for 256 output channels; ring of three chunks (144 KiB): standalone layers lose a microsecond to it, the engine -- inputs fresh from the previous kernel, longer latencies -- gains 2.3 % (123.9 -> 126.7 frames/s)
             case 14: return launch_cfg<128, 192, 4, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
+#ifdef MFTX_EXPERIMENTAL_TILES
             case 15: return launch_cfg<224, 128, 2, 4, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);
+#endif
             default: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_SPLIT, 3>(a, batch, s, cat);        // 9
         }
     }
@@ -1479,9 +1483,10 @@ extern template int launch_tile<EPI_GRU_ZR>(int, const ConvArgs &, int, hipStrea
 extern template int launch_tile<EPI_GRU_Q>(int, const ConvArgs &, int, hipStream_t, ProfCat);
 #endif
 
-static int pick_tile(const ConvArgs &a, int batch) {
-    // debug/tuning override: MFTX_CONV_TILE=0..9
-    static const int forced = [] { const char *e = getenv("MFTX_CONV_TILE"); return e ? atoi(e) : -1; }();
+static int pick_tile(const ConvArgs &a, int batch, int forced_arg) {
+    // forced: mftx_conv2d_tile (tests, micro-benchmarks); tuning builds also read MFTX_CONV_TILE
+    static const int forced_env = tune_env("MFTX_CONV_TILE", -1);
+    const int forced = forced_arg >= 0 ? forced_arg : forced_env;
     if (forced >= 0 && forced <= 15) return forced;
     if (a.arith == AR_SPLIT) {
         // Measured (tools/bench_conv.py --arith 1, M = 7 x 4096).  The staging path (global -> LDS) is what limits
@@ -1495,10 +1500,10 @@ static int pick_tile(const ConvArgs &a, int batch) {
         if (a.N <= 64) return 9;
         //   14: 128 x 192, eight 32 x 96 waves, one workgroup per CU: N = 192 (convc2) without the half-empty second column tile
         //       of the 128-wide shapes -- a quarter of their matrix work (measured at M = 7 x 4096: 110.5 -> 88.7 us)
-        static const bool no14 = getenv("MFTX_CONV_NO14") != nullptr;
+        static const bool no14 = tune_env("MFTX_CONV_NO14", 0) != 0;
         // (one round of workgroups only: N = 576 at seven pairs, 672 tiles in three rounds, is faster on 128-wide tiles: 45.3 vs 38.5 us)
         if (!no14 && a.N % 192 == 0 && a.N % 128 != 0 && (long long)cdiv(a.M, 128) * (a.N / 192) * 2 >= cus && (long long)cdiv(a.M, 128) * (a.N / 192) <= cus) return 14;
-        static const bool try13 = getenv("MFTX_CONV_TILE13") != nullptr;     // tuning: the 112-row tile where it fills the chip in one round
+        static const bool try13 = tune_env("MFTX_CONV_TILE13", 0) != 0;     // tuning: the 112-row tile where it fills the chip in one round
         if (try13 && a.a_pre && a.N % 256 == 0 && (long long)cdiv(a.M, 112) * (a.N / 256) <= cus && (long long)cdiv(a.M, 112) * (a.N / 256) * 8 >= cus * 7) return 13;
         if (a.N % 256 == 0 && (long long)cdiv(a.M, 128) * (a.N / 256) * 4 >= cus * 3) return 10;
         if (t128 * 2 >= cus * 3) return 0;
@@ -1520,14 +1525,17 @@ static int pick_tile(const ConvArgs &a, int batch) {
     // bit.  Measured at M = 4096 (tools/bench_conv.py): N = 64 25.5 -> 18.9 us; already at N = 128 the
     // 16x16 form loses (27.5 -> 29 us; a 32x64 tile of 8 waves 47.6 -> 81 us at N = 192): per MFMA cycle it
     // needs four times the LDS fragment traffic and twice the LDS-DMA pieces of the 32x32 form.
-    static const bool small_off = getenv("MFTX_CONV_NO16") != nullptr;
+    static const bool small_off = tune_env("MFTX_CONV_NO16", 0) != 0;
     const long long t64 = (long long)cdiv(a.M, 64) * cdiv(a.N, 64);
     if (!small_off && t64 * 4 <= num_cus()) return 5;
     return 2;
 }
 
-static int dispatch(const ConvArgs &a, int epi, int batch, hipStream_t s, ProfCat cat) {
-    const int tile = pick_tile(a, batch);
+static int dispatch(const ConvArgs &a, int epi, int batch, hipStream_t s, ProfCat cat, int forced_tile = -1) {
+    const int tile = pick_tile(a, batch, forced_tile);
+#ifndef MFTX_EXPERIMENTAL_TILES
+    if (tile == 13 || tile == 15) return fail(MFTX_E_ARG, "conv2d: tile %d is a measurement-only shape (build with -DMFTX_EXPERIMENTAL_TILES)", tile);
+#endif
     switch (epi) {
         case EPI_RELU: return launch_tile<EPI_RELU>(tile, a, batch, s, cat);
         case EPI_GRU_ZR: return launch_tile<EPI_GRU_ZR>(tile, a, batch, s, cat);
@@ -1590,14 +1598,14 @@ static ConvArgs to_args(const mftx_conv_desc &d) {
     return a;
 }
 
-int launch_conv(const mftx_conv_desc &d, hipStream_t s) {
+int launch_conv(const mftx_conv_desc &d, hipStream_t s, int tile) {
     if (int e = validate(d)) return e;
     if (d.addend == nullptr && d.stride <= 1 && d.hin == 0 && conv_small_applicable(d)) {
         if (d.arith != AR_F32) return fail(MFTX_E_ARG, "conv2d: split arithmetic is for the matrix path (N > 4); this layer runs on the VALU kernel, with fp32 weights");
         return launch_conv_small(d, s);
     }   // N <= 4: VALU kernel, no MFMA padding waste
     const bool relu = d.act == 1 && d.residual_mode == 0;   // the residual tail lives in the generic epilogue
-    return dispatch(to_args(d), relu ? EPI_RELU : EPI_GENERIC, 1, s, PC_CONV_GEMM);
+    return dispatch(to_args(d), relu ? EPI_RELU : EPI_GENERIC, 1, s, PC_CONV_GEMM, tile);
 }
 
 int launch_conv_pair(const mftx_conv_desc &da, const mftx_conv_desc &db, hipStream_t s) {
@@ -1618,7 +1626,7 @@ int launch_conv_pair(const mftx_conv_desc &da, const mftx_conv_desc &db, hipStre
         attr_set = true;
     }
     const long long n_virtual = 8ll * cdiv(cdiv(a.M, BM), 8) * cdiv(a.N, BN) + 8ll * cdiv(cdiv(b.M, BM), 8) * cdiv(b.N, BN);
-    static const bool one_tile_per_wg = getenv("MFTX_CONV_NONPERSISTENT") != nullptr;
+    static const bool one_tile_per_wg = tune_env("MFTX_CONV_NONPERSISTENT", 0) != 0;
     const long long slots = one_tile_per_wg ? n_virtual : (long long)num_cus() * 4;
     dim3 grid((unsigned)(n_virtual < slots ? n_virtual : slots));
     ProfScope prof(PC_CONV_GEMM, s, 2.0 * a.M * a.N * (double)(a.kh * a.kw) * (a.c0 + a.c1) +

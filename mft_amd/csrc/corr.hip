@@ -30,7 +30,7 @@ namespace mftx {
 int launch_corr_lookup(const float *const lvl[4], const float *coords, int P, int h, int w, float *out,
                        int ld_out, hipStream_t s) {
     const LookupArgs a = make_lookup_args(lvl, coords, P, h, w, out, ld_out);
-    static const int cpw = [] { const char *e = getenv("MFTX_LOOKUP_CPW"); return e ? atoi(e) : 2; }();
+    static const int cpw = tune_env("MFTX_LOOKUP_CPW", 2);
     // 4 levels x 10x10 unique taps read + coords + 324 outputs written, per cell
     ProfScope prof(PC_LOOKUP, s, lookup_bytes(a));
     if (cpw == 1)

@@ -1,0 +1,453 @@
+// Correlation lookup FUSED into convc1 (core/corr.py:30-51 feeding core/update.py:152-153), split arithmetic.
+//
+// 323 of the lookup's 324 channels have exactly one consumer -- the 1 x 1 convolution convc1 -- 11 iterations out
+// of 12.  Stand-alone, the lookup writes 37 MB of features per iteration (7 pairs of 512 x 512) that convc1 reads
+// back and splits in registers.  Here the features never leave the CU: one workgroup owns a tile of up to 64 query
+// cells; its four PRODUCER waves gather the cells' 10 x 10 windows (LDS-DMA, one dword per tap: what lies outside a
+// level gets an out-of-range offset = grid_sample's zero padding, tap for tap), blend them, split the results into
+// fp16 halves and park them in LDS in the A-operand layout of v_mfma_f32_32x32x16_f16; its four CONSUMER waves
+// multiply them with convc1's weights (64 output channels per wave; the wave's weight fragments stream from L2
+// straight into registers, three 16-wide k groups ahead -- no wave shares them, so LDS would add nothing) and write
+// relu(. + bias) in the form convc2 reads.
+//
+//   unit      = (tile, pyramid level): 64 rows x 96 k -- the level's 81 window samples at k'' = 10 b + a (b: y
+//               offset, a: x offset; a = 9 and k'' >= 90 carry zero weights), so that a sample's index is the index
+//               of its upper-left tap in the 10 x 10 patch: every lane runs the same 24-sample loop on its own
+//               quarter of a patch;
+//   pipeline  = producers and consumers meet at ONE workgroup barrier per unit: barrier u certifies that unit u is
+//               complete in A slot u & 1 and that the consumers are done with unit u - 1, whose slot then takes unit
+//               u + 1 while the consumers multiply unit u.  Gathers run three units ahead of their conversion
+//               (patch ring of three, counted vmcnt waits): the HBM round trip of a window hides under ~3 units of
+//               matrix work.
+//
+// Results are independent of the tile size and of the batch: a row's 324 products are summed in the fixed order of
+// the k groups, by one accumulator pair.
+#include "common.h"
+#include "profile.h"
+
+namespace mftx {
+
+typedef float lf_f32x16 __attribute__((ext_vector_type(16)));
+typedef float lf_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned lf_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned lf_u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 lf_f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int LF_GROUPS = 24;                       // 16-wide k groups: 4 levels x 6
+constexpr int LF_AROW = 400;                        // bytes per A row of a unit: 96 x 4 + 16 (rows r, r + 1 start 25 sixteen-byte slots apart: conflict-free ds_read_b128)
+constexpr int LF_AUNIT = 64 * LF_AROW;              // 25 600
+constexpr int LF_PATCH = 432;                       // bytes per window patch: 100 taps + 8 pad floats (finite: the dummy samples read them)
+constexpr int LF_NP = 3;                            // units of gathers in flight per producer wave
+constexpr int LF_CPP = 16;                          // cells per producer wave and unit (at most)
+constexpr unsigned LF_WBYTES = LF_GROUPS * 4 * 4 * 1024;     // fused weights: [group][wave][fragment][lane] x 16 bytes
+constexpr unsigned LF_OOB = 0x80000000u;
+constexpr int LF_OFF_PATCH = 2 * LF_AUNIT;                                   // 51 200
+constexpr int LF_OFF_STAGE = LF_OFF_PATCH + 4 * LF_NP * LF_CPP * LF_PATCH;   // + 82 944
+constexpr int LF_OFF_COORD = LF_OFF_STAGE + 4 * 4096;                        // + 16 384
+constexpr int LF_LDS = LF_OFF_COORD + 4 * 3 * 128;                           // 152 064 bytes
+
+struct LookupConvArgs {
+    const float *lvl[4];
+    long long stride[4];        // floats per query cell
+    int hl[4], wl[4];
+    int wb0, wb1;               // block-grid widths of levels 0, 1
+    const float *coords;
+    int cells;                  // P * h * w
+    const void *wf;             // fused weights (mftx_pack_lookup_convc1_weights)
+    const float *bias;
+    float *out;
+    int ld_out, out_split;
+    int rpw;                    // cells per producer wave and tile: a tile is 4 rpw cells
+    int n_tiles;
+};
+
+__device__ __forceinline__ void lf_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+#define LF_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+__device__ __forceinline__ void lf_wait_vmcnt(int n) {
+    switch (n < 63 ? n : 63) {
+        LF_W(0) LF_W(1) LF_W(2) LF_W(3) LF_W(4) LF_W(5) LF_W(6) LF_W(7) LF_W(8) LF_W(9) LF_W(10) LF_W(11) LF_W(12) LF_W(13) LF_W(14) LF_W(15)
+        LF_W(16) LF_W(17) LF_W(18) LF_W(19) LF_W(20) LF_W(21) LF_W(22) LF_W(23) LF_W(24) LF_W(25) LF_W(26) LF_W(27) LF_W(28) LF_W(29) LF_W(30) LF_W(31)
+        LF_W(32) LF_W(33) LF_W(34) LF_W(35) LF_W(36) LF_W(37) LF_W(38) LF_W(39) LF_W(40) LF_W(41) LF_W(42) LF_W(43) LF_W(44) LF_W(45) LF_W(46) LF_W(47)
+        LF_W(48) LF_W(49) LF_W(50) LF_W(51) LF_W(52) LF_W(53) LF_W(54) LF_W(55) LF_W(56) LF_W(57) LF_W(58) LF_W(59) LF_W(60) LF_W(61) LF_W(62)
+        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    }
+}
+#undef LF_W
+
+// one dword per lane straight into LDS, lane-linear at `dst` (wave-uniform); an out-of-range offset stores a zero
+__device__ __forceinline__ void lf_dma4(__amdgpu_buffer_rsrc_t r, void *dst, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)dst, 4, voff, 0, 0, 0);
+}
+
+// (hi, lo) halves of two values: 5 instructions (conv_gemm.hip: split_pair)
+__device__ __forceinline__ void lf_split_pair(float x0, float x1, float k2048, unsigned &h, unsigned &l) {
+    float r0, r1;
+    asm("v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %3, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %2, %6, 0\n\t"
+        "v_fma_mixhi_f16 %1, %3, %6, 0"
+        : "=&v"(h), "=&v"(l), "=&v"(r0), "=&v"(r1)
+        : "v"(x0), "v"(x1), "s"(k2048));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// producer waves (pw = 0..3): cells [pw rpw, (pw + 1) rpw) of every tile
+// ---------------------------------------------------------------------------------------------------------------
+struct LfProducer {
+    const LookupConvArgs &p;
+    unsigned char *lds;
+    int pw, lane, rpw, TR, my_tiles, U;
+    int c16, q, trA, tcA, trB, tcB;
+    unsigned char *patches;
+    float *cslots;
+
+    __device__ __forceinline__ int tile_of(int k) const { return (int)blockIdx.x + k * (int)gridDim.x; }
+
+    // VMEM operations of unit v's gather, and of the coordinate prefetch that follows a level-0 unit
+    __device__ __forceinline__ int n_gather(int v) const { return v < U ? 2 * rpw : 0; }
+    __device__ __forceinline__ int n_coord(int v) const { return (v < U && (v & 3) == 0 && (v >> 2) + 1 < my_tiles) ? 1 : 0; }
+
+    // coordinates of tile k's cells of this wave -> slot k % 3 (32 dwords: 16 cells x (x, y))
+    __device__ __forceinline__ void coords_issue(int k) {
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.coords), 0, (unsigned)p.cells * 8u, 0x00020000);
+        const int cell0 = __builtin_amdgcn_readfirstlane(tile_of(k) * TR + pw * rpw);
+        const int cell = cell0 + (lane >> 1);
+        const bool ok = (lane >> 1) < rpw && cell < p.cells;
+        if (lane < 32) lf_dma4(rc, cslots + (k % 3) * 32, ok ? (unsigned)cell * 8u + (unsigned)(lane & 1) * 4u : LF_OOB);
+    }
+
+    __device__ __forceinline__ void level_coords(int v, float &sx, float &sy) const {
+        const int k = v >> 2, l = v & 3;
+        const float2 c = reinterpret_cast<const float2 *>(cslots + (k % 3) * 32)[c16];
+        const float inv = l == 0 ? 1.f : l == 1 ? 0.5f : l == 2 ? 0.25f : 0.125f;     // (x / 2^l, exactly)
+        sx = c.x * inv;
+        sy = c.y * inv;
+    }
+
+    // gather of unit v: two DMA instructions per cell (taps 0..63, 64..99) into patch slot v % 3
+    __device__ __forceinline__ void gather(int v) {
+        const int k = v >> 2, l = v & 3;
+        float sx, sy;
+        level_coords(v, sx, sy);
+        // clamp so that the int conversion is defined for wild coordinates
+        const int x0v = (int)fminf(fmaxf(floorf(sx), -1.0e6f), 1.0e6f) - 4;
+        const int y0v = (int)fminf(fmaxf(floorf(sy), -1.0e6f), 1.0e6f) - 4;
+        const float *base = l == 0 ? p.lvl[0] : l == 1 ? p.lvl[1] : l == 2 ? p.lvl[2] : p.lvl[3];
+        const long long stride = l == 0 ? p.stride[0] : l == 1 ? p.stride[1] : l == 2 ? p.stride[2] : p.stride[3];
+        const unsigned H = (unsigned)(l == 0 ? p.hl[0] : l == 1 ? p.hl[1] : l == 2 ? p.hl[2] : p.hl[3]);
+        const unsigned W = (unsigned)(l == 0 ? p.wl[0] : l == 1 ? p.wl[1] : l == 2 ? p.wl[2] : p.wl[3]);
+        const unsigned wb = (unsigned)(l == 0 ? p.wb0 : p.wb1);
+        const bool blocked = l < 2;
+        unsigned char *pdst = patches + (v % 3) * (LF_CPP * LF_PATCH);
+        const int cell0 = tile_of(k) * TR + pw * rpw;
+        for (int i = 0; i < rpw; ++i) {
+            const int x0 = __builtin_amdgcn_readlane(x0v, i), y0 = __builtin_amdgcn_readlane(y0v, i);
+            // (provably wave-uniform: the buffer descriptor must live in SGPRs, or every DMA becomes a waterfall loop)
+            const int cell = __builtin_amdgcn_readfirstlane(cell0 + i);
+            const bool cv = cell < p.cells;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(base + (long long)(cv ? cell : 0) * stride), 0, (unsigned)stride * 4u, 0x00020000);
+            unsigned offA, offB;
+            {   // unsigned compares fold the lower bounds in
+                const unsigned yy = (unsigned)(y0 + trA), xx = (unsigned)(x0 + tcA);
+                const unsigned o = blocked ? (((yy >> 2) * wb + (xx >> 3)) * 32u + (yy & 3u) * 8u + (xx & 7u)) : yy * W + xx;
+                offA = (cv & (yy < H) & (xx < W)) ? o * 4u : LF_OOB;
+            }
+            {
+                const unsigned yy = (unsigned)(y0 + trB), xx = (unsigned)(x0 + tcB);
+                const unsigned o = blocked ? (((yy >> 2) * wb + (xx >> 3)) * 32u + (yy & 3u) * 8u + (xx & 7u)) : yy * W + xx;
+                offB = (cv & (yy < H) & (xx < W)) ? o * 4u : LF_OOB;
+            }
+            lf_dma4(rs, pdst + i * LF_PATCH, offA);
+            if (lane < 36) lf_dma4(rs, pdst + i * LF_PATCH + 256, offB);
+        }
+        if (n_coord(v)) coords_issue(k + 1);
+    }
+
+    // conversion of unit v: lane (cell c16, quarter q) blends samples k'' = 24 q .. 24 q + 23 of its cell and stores
+    // their halves into the A slot v & 1
+    __device__ __forceinline__ void convert(int v) {
+        float sx, sy;
+        level_coords(v, sx, sy);
+        const float fx = sx - floorf(sx), fy = sy - floorf(sy);
+        const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+        const lf_f32x4 *src = reinterpret_cast<const lf_f32x4 *>(patches + (v % 3) * (LF_CPP * LF_PATCH) + c16 * LF_PATCH + q * 96);
+        float T[36];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const lf_f32x4 t = src[i];
+            T[4 * i] = t[0]; T[4 * i + 1] = t[1]; T[4 * i + 2] = t[2]; T[4 * i + 3] = t[3];
+        }
+        const float k2048 = 2048.f;
+        unsigned char *dst = lds + (v & 1) * LF_AUNIT + (pw * rpw + c16) * LF_AROW + q * 96;
+        const bool live = c16 < rpw;
+#pragma unroll
+        for (int g8 = 0; g8 < 3; ++g8) {
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 8 * g8 + 2 * e;
+                const float v0 = T[j] * w00 + T[j + 1] * w01 + T[j + 10] * w10 + T[j + 11] * w11;
+                const float v1 = T[j + 1] * w00 + T[j + 2] * w01 + T[j + 11] * w10 + T[j + 12] * w11;
+                lf_split_pair(v0, v1, k2048, h[e], l[e]);
+            }
+            if (live) {
+                *reinterpret_cast<lf_u32x4 *>(dst + g8 * 32) = lf_u32x4{h[0], h[1], h[2], h[3]};
+                *reinterpret_cast<lf_u32x4 *>(dst + g8 * 32 + 16) = lf_u32x4{l[0], l[1], l[2], l[3]};
+            }
+        }
+    }
+
+    // operations issued after unit v's gather at the moment unit v is converted: the coordinate prefetch behind it
+    // and the gathers of units v + 1, v + 2 with theirs (unit v + 3 follows the conversion)
+    __device__ __forceinline__ int younger(int v) const {
+        return n_coord(v) + n_gather(v + 1) + n_coord(v + 1) + n_gather(v + 2) + n_coord(v + 2);
+    }
+
+    __device__ __forceinline__ void run() {
+        // pad floats of my patches: finite for ever (no DMA reaches them)
+        if (lane < LF_NP * LF_CPP) {
+            lf_f32x4 *pad = reinterpret_cast<lf_f32x4 *>(patches + lane * LF_PATCH + 400);
+            pad[0] = lf_f32x4{0.f, 0.f, 0.f, 0.f};
+            pad[1] = lf_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        coords_issue(0);
+        lf_wait_vmcnt(0);
+        gather(0);
+        if (1 < U) gather(1);
+        if (2 < U) gather(2);
+        lf_wait_vmcnt(younger(0));
+        convert(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (3 < U) gather(3);
+        for (int u = 0; u < U; ++u) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            lf_barrier();                    // unit u is complete in its slot; the consumers are done with unit u - 1
+            if (u + 1 < U) {
+                lf_wait_vmcnt(younger(u + 1));
+                convert(u + 1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the conversion's patch reads are complete)
+            if (u + 4 < U) gather(u + 4);    // into the patch slot unit u + 1 has just left
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// consumer waves (j = 0..3): output channels [64 j, 64 j + 64) of every tile
+// ---------------------------------------------------------------------------------------------------------------
+template <bool OS>
+__device__ __forceinline__ void lf_consumer(const LookupConvArgs &p, unsigned char *lds, int j, int lane, int U, int TR) {
+    const int col = lane & 31, kh = lane >> 5;
+    const unsigned char *a_lane = lds + col * LF_AROW + kh * 32;      // + slot, + 32 it rows, + 64 g, + 16 (low halves)
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p.wf), 0, LF_WBYTES, 0x00020000);
+    const unsigned w_lane = (unsigned)(j * 4096 + lane * 16);          // + 16384 group + 1024 fragment
+    lf_f16x8 wq[3][4];                    // weight fragments of three k groups: [jt = 0 hi, lo | jt = 1 hi, lo]
+    auto wload = [&](int wg, lf_f16x8 (&d)[4]) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            d[x] = __builtin_bit_cast(lf_f16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, (unsigned)wg * 16384u + (unsigned)x * 1024u + w_lane, 0, 0));
+    };
+    wload(0, wq[0]); wload(1, wq[1]); wload(2, wq[2]);
+    int wg_next = 3;
+    // bias of this lane's four columns in the epilogue's row layout (columns 4 (lane & 7) .. + 3 of a 32-wide tile)
+    lf_f32x4 bias4[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) bias4[jt] = *reinterpret_cast<const lf_f32x4 *>(p.bias + 64 * j + 32 * jt + 4 * (lane & 7));
+    const __amdgpu_buffer_rsrc_t rOut = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (unsigned)((long long)p.cells * p.ld_out * 4), 0x00020000);
+    float *st = reinterpret_cast<float *>(lds + LF_OFF_STAGE + j * 4096);
+
+    lf_f32x16 acc[2][2], accx[2][2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[it][jt][r] = 0.f; accx[it][jt][r] = 0.f; }
+
+    for (int u = 0; u < U; ++u) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lf_barrier();
+        const unsigned char *A = a_lane + (u & 1) * LF_AUNIT;
+        lf_f16x8 ah[2][2], al[2][2];      // [register set][row tile]
+        auto read_a = [&](int g, int set) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                ah[set][it] = *reinterpret_cast<const lf_f16x8 *>(A + it * 32 * LF_AROW + g * 64);
+                al[set][it] = *reinterpret_cast<const lf_f16x8 *>(A + it * 32 * LF_AROW + g * 64 + 16);
+            }
+        };
+        read_a(0, 0);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            const int set = g & 1;
+            if (g < 5) read_a(g + 1, set ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            lf_f16x8 (&w)[4] = wq[g % 3];
+            // product by product: consecutive MFMAs never wait for each other's accumulator
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) acc[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][it], w[2 * jt], acc[it][jt], 0, 0, 0);
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) accx[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][it], w[2 * jt + 1], accx[it][jt], 0, 0, 0);
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) accx[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set][it], w[2 * jt], accx[it][jt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            wload(wg_next, wq[g % 3]);          // three k groups ahead of its use
+            wg_next = wg_next == LF_GROUPS - 1 ? 0 : wg_next + 1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if ((u & 3) != 3) continue;
+        // ---- the tile is complete: out = relu(acc + accx / 2048 + bias), through 4 KiB of the wave's own LDS so that a
+        // lane holds 4 consecutive channels of a row (16-byte accesses; conv_gemm.hip's vectorised epilogue)
+        const long long m_base = (long long)((int)blockIdx.x + (u >> 2) * (int)gridDim.x) * TR;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                float *w = st + (4 * (lane >> 5)) * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    w[((r & 3) + 8 * (r >> 2)) * 32] = acc[it][jt][r] + accx[it][jt][r] * (1.f / 2048.f);
+                    acc[it][jt][r] = 0.f;
+                    accx[it][jt][r] = 0.f;
+                }
+                lf_f32x4 v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const lf_f32x4 *>(st + (t * 8 + (lane >> 3)) * 32 + (lane & 7) * 4);
+                const int nb = 64 * j + 32 * jt + 4 * (lane & 7);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int row = 32 * it + 8 * t + (lane >> 3);
+                    const long long m = m_base + row;
+                    const bool ok = row < TR && m < p.cells;
+                    lf_f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fmaxf(v[t][e] + bias4[jt][e], 0.f);
+                    if constexpr (OS) {
+                        unsigned h0, h1, l0, l1;
+                        const float k2048 = 2048.f;
+                        lf_split_pair(o[0], o[1], k2048, h0, l0);
+                        lf_split_pair(o[2], o[3], k2048, h1, l1);
+                        const unsigned off = ok ? (unsigned)(m * p.ld_out * 4) + (unsigned)split_row_offset(nb) : LF_OOB;
+                        __builtin_amdgcn_raw_buffer_store_b64(lf_u32x2{h0, h1}, rOut, off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(lf_u32x2{l0, l1}, rOut, off + 16u, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lf_u32x4, o), rOut, ok ? (unsigned)((m * p.ld_out + nb) * 4) : LF_OOB, 0, 0);
+                    }
+                }
+            }
+    }
+}
+
+template <bool OS>
+__global__ __launch_bounds__(512, 2) void lookup_convc1_kernel(LookupConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lf_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int TR = 4 * p.rpw;
+    const int my_tiles = (p.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;    // >= 1: the grid never exceeds n_tiles
+    const int U = 4 * my_tiles;
+    if (wid >= 4) {
+        const int pw = wid - 4;
+        LfProducer P{p, lf_lds, pw, lane, p.rpw, TR, my_tiles, U,
+                     lane & 15, lane >> 4, lane / 10, lane % 10, (lane + 64) / 10, (lane + 64) % 10,
+                     lf_lds + LF_OFF_PATCH + pw * (LF_NP * LF_CPP * LF_PATCH),
+                     reinterpret_cast<float *>(lf_lds + LF_OFF_COORD + pw * (3 * 128))};
+        P.run();
+    } else {
+        lf_consumer<OS>(p, lf_lds, wid, lane, U, TR);
+    }
+}
+
+// convc1's packed fp32 weights [256][ld_w] (channel l * 81 + a * 9 + b of the lookup, core/corr.py:45-51) -> the fused
+// kernel's fragment stream: for k group wg, consumer wave j, fragment x = 2 jt + (0: high, 1: low halves) and lane
+// (col = lane & 31, kh = lane >> 5), the 8 halves of W[64 j + 32 jt + col][k'' = 16 (wg % 6) + 8 kh + e of level wg / 6]
+__global__ void pack_lookup_convc1_kernel(const float *__restrict__ w, int ld_w, uint4 *__restrict__ out) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;          // over 24 * 4 * 4 * 64 pieces of 16 bytes
+    if (d >= LF_GROUPS * 4 * 4 * 64) return;
+    const int lane = d & 63, x = (d >> 6) & 3, j = (d >> 8) & 3, wg = d >> 10;
+    const int row = 64 * j + 32 * (x >> 1) + (lane & 31);
+    const int lvl = wg / 6;
+    _Float16 o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int kk = 16 * (wg - 6 * lvl) + 8 * (lane >> 5) + e;      // k'' = 10 b + a
+        const int b = kk / 10, a = kk - 10 * b;
+        float v = 0.f;
+        if (kk < 90 && a < 9) v = w[(long long)row * ld_w + lvl * 81 + a * 9 + b];
+        const _Float16 h = (_Float16)v;
+        o[e] = (x & 1) ? (_Float16)((v - (float)h) * 2048.f) : h;
+    }
+    uint4 r;
+    __builtin_memcpy(&r, o, 16);
+    out[d] = r;
+}
+
+static int lf_num_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        }
+        return cus;
+    }();
+    return n;
+}
+
+int launch_pack_lookup_convc1(const float *w, int ld_w, void *out, hipStream_t s) {
+    const int n = LF_GROUPS * 4 * 4 * 64;
+    hipLaunchKernelGGL(pack_lookup_convc1_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, w, ld_w, reinterpret_cast<uint4 *>(out));
+    return check_launch("pack_lookup_convc1");
+}
+
+bool lookup_convc1_applicable(int P, int h, int w, int ld_out) {
+    const long long M = (long long)P * h * w;
+    return M > 0 && M * ld_out * 4 < 0x7fffffffLL && M * 8 < 0x7fffffffLL;
+}
+
+int launch_lookup_convc1(const float *const lvl[4], const float *coords, int P, int h, int w, const void *wf,
+                         const float *bias, float *out, int ld_out, int out_split, hipStream_t s) {
+    LookupConvArgs a{};
+    const PyramidLayout L = pyramid_layout(h, w);
+    for (int l = 0; l < 4; ++l) { a.lvl[l] = lvl[l]; a.stride[l] = L.stride[l]; a.hl[l] = L.h[l]; a.wl[l] = L.w[l]; }
+    a.wb0 = L.wb[0]; a.wb1 = L.wb[1];
+    a.coords = coords; a.cells = P * h * w;
+    a.wf = wf; a.bias = bias; a.out = out; a.ld_out = ld_out; a.out_split = out_split;
+    // tile = 4 rpw cells (rpw <= 16), sized so that the tiles come in whole rounds of the CUs: 7 x 4096 cells on 256
+    // CUs are 512 tiles of 56, two per CU, instead of 448 of 64 (1.75)
+    const int cus = lf_num_cus();
+    const long long rounds = cdiv(cdiv(a.cells, 64), cus);
+    const int tr0 = cdiv(a.cells, (int)(rounds * cus));
+    a.rpw = cdiv(tr0, 4) < 1 ? 1 : cdiv(tr0, 4) > LF_CPP ? LF_CPP : cdiv(tr0, 4);
+    a.n_tiles = cdiv(a.cells, 4 * a.rpw);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lookup_convc1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(lookup_convc1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS);
+        if (e != hipSuccess) return fail((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    // booked as algorithmic BYTES of the lookup it replaces (unique taps + coordinates + the 324 features
+    // that are no longer written); the flops of convc1 ride along
+    ProfScope prof(PC_LOOKUP_FUSED, s, (double)a.cells * (4 * 100 * 4 + 8 + 324 * 4));
+    const dim3 grid(a.n_tiles < cus ? a.n_tiles : cus);
+    if (out_split) hipLaunchKernelGGL(lookup_convc1_kernel<true>, grid, dim3(512), LF_LDS, s, a);
+    else hipLaunchKernelGGL(lookup_convc1_kernel<false>, grid, dim3(512), LF_LDS, s, a);
+    return check_launch("lookup_convc1");
+}
+
+}  // namespace mftx

@@ -36,7 +36,7 @@ inline LookupArgs make_lookup_args(const float *const lvl[4], const float *coord
     for (int l = 0; l < 2; ++l) { a.wb[l] = L.wb[l]; a.hbwb[l] = (unsigned)(L.hb[l] * L.wb[l]); }
     a.coords = coords; a.out = out; a.ld_out = ld_out;
     a.cells = P * h * w; a.n_per_img = h * w;
-    static const int ablate = [] { const char *e = getenv("MFTX_LOOKUP_ABLATE"); return e ? atoi(e) : 0; }();
+    static const int ablate = tune_env("MFTX_LOOKUP_ABLATE", 0);
     a.ablate = ablate;
     return a;
 }

@@ -178,6 +178,8 @@ struct mftx_raft {
     // the motion encoder's flow branch (convf1 -> convf2) runs on a stream of its own, beside lookup -> convc1 -> convc2
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
+    const void *wfused;            // convc1's weights for the fused lookup + convc1 kernel (csrc/lookup_convc1.hip), or null
+    int opt[4];                    // MFTX_RAFT_OPT_*
 };
 // weights that go through the conv GEMM (the others feed VALU kernels and stay fp32)
 static constexpr int GEMM_SLOTS[] = {W_CONVC1, W_CONVC2, W_CONVF2, W_CONV, W_ZR1_DYN, W_ZR1_INP, W_Q1_DYN, W_Q1_INP,
@@ -197,6 +199,8 @@ extern "C" int mftx_raft_create(const float *const *weights, int n_weights, mftx
     r->ondemand = 0;
     r->arith = MFTX_ARITH_F32;
     r->side = nullptr; r->ev_fork = nullptr; r->ev_join = nullptr;
+    r->wfused = nullptr;
+    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1;
     for (int i = 0; i < W_COUNT; ++i) r->w[i] = r->wg[i] = weights[i];
     *out = r;
     return 0;
@@ -247,6 +251,20 @@ extern "C" int mftx_raft_set_split_weights(mftx_raft *r, const void *const *spli
     }
     for (int slot : GEMM_SLOTS) r->wg[slot] = static_cast<const float *>(split[slot]);
     r->arith = MFTX_ARITH_SPLIT;
+    return 0;
+}
+
+extern "C" int mftx_raft_set_lookup_fused(mftx_raft *r, const void *wfused) {
+    if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_lookup_fused: bad handle");
+    if (wfused && !aligned16(wfused)) return fail(MFTX_E_ALIGN, "raft_set_lookup_fused: weights not 16-byte aligned");
+    r->wfused = wfused;
+    return 0;
+}
+
+extern "C" int mftx_raft_set_option(mftx_raft *r, int option, int value) {
+    if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_option: bad handle");
+    if (option < 0 || option > MFTX_RAFT_OPT_FUSE_LOOKUP) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
+    r->opt[option] = value;
     return 0;
 }
 
@@ -315,8 +333,11 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     const bool ondemand = r->ondemand != 0;
     // split arithmetic: every tensor that feeds a GEMM of the update block / OU heads lives in the workspace in SPLIT
     // form (common.h), written that way by its producer -- the GEMMs' K loops then spend nothing on splitting
-    static const bool no_presplit = getenv("MFTX_RAFT_NOPRESPLIT") != nullptr;     // tuning: fp32 activations, split in the GEMMs' registers
-    const bool SP = r->arith == MFTX_ARITH_SPLIT && !no_presplit;
+    const bool SP = r->arith == MFTX_ARITH_SPLIT && r->opt[MFTX_RAFT_OPT_PRESPLIT] != 0;
+    // lookup fused into convc1 (csrc/lookup_convc1.hip): the 324 features stay in LDS; they are materialised on the last
+    // iteration only, for the occlusion / uncertainty heads
+    const bool fuse_lookup = SP && !ondemand && r->wfused != nullptr && r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] != 0 &&
+                             lookup_convc1_applicable(P, h, w, 256);
     Workspace ws = carve(workspace, P, h, w, ondemand, r->arith == MFTX_ARITH_SPLIT);
     if (ws.bytes > workspace_bytes)
         return fail(MFTX_E_WORKSPACE, "raft_refine: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
@@ -362,11 +383,10 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         // convc2 + convf2 in one launch).  The per-kernel timing pass and MFTX_RAFT_NOFUSE run everything in order.
         const ConvF1Args f1{ws.coords1, W[W_CONVF1], W[B_CONVF1], ws.flo1, ws.hx, h, w, strips, P * h * strips, SP ? 1 : 0};
         const int f1_blocks = cdiv(f1.n_strips, 2);
-        static const bool nofuse = getenv("MFTX_RAFT_NOFUSE") != nullptr;
-        static const bool nopair = getenv("MFTX_RAFT_NOPAIR") != nullptr;
+        const bool nofuse = r->opt[MFTX_RAFT_OPT_GROUP] == 0, nopair = nofuse;
         const mftx_conv_desc c2 = gemm(conv_desc(ws.cor1, 256, 256, nullptr, 0, 0, G[W_CONVC2], W[B_CONVC2], ws.corflo, 256, P, h, w, 192, 3, 3, 1), true, true);
         const mftx_conv_desc f2 = gemm(conv_desc(ws.flo1, 128, 128, nullptr, 0, 0, G[W_CONVF2], W[B_CONVF2], ws.corflo + 192, 256, P, h, w, 64, 3, 3, 1), true, true);
-        static const int fork_env = [] { const char *e = getenv("MFTX_RAFT_FORK"); return e ? atoi(e) : -1; }();   // tuning: 0 never, 1 always
+        const int fork_env = r->opt[MFTX_RAFT_OPT_FORK];      // 0 never, -1 / 1 with the split arithmetic
         const bool serial = prof_enabled() || nofuse || (AR == MFTX_ARITH_SPLIT && fork_env == 0);
         const bool forked = !serial && AR == MFTX_ARITH_SPLIT;
         if (forked) {
@@ -376,11 +396,20 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
             hipLaunchKernelGGL(convf1_kernel, dim3(f1_blocks), dim3(256), 0, r->side, f1);
             TRY(check_launch("convf1"));
             TRY(launch_conv(f2, r->side));
+            // fused lookup: the features themselves are needed once, by ou_gather behind the last iteration -- off the critical path
+            if (fuse_lookup && last) TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr, r->side));
             if (hipEventRecord(r->ev_join, r->side) != hipSuccess) return fail(MFTX_E_STATE, "raft_refine: join event failed");
         }
         // lookup + convf1 as ONE launch (HBM gathers beside VALU work) whenever the flow branch is not on the side stream:
         // 113.7 vs 113.2 frames/s with the split arithmetic; the timing pass and MFTX_RAFT_NOFUSE keep them apart
-        if (prof_enabled() || nofuse || forked || ondemand) {
+        if (fuse_lookup) {
+            if (last && !forked) TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr, s));
+            TRY(launch_lookup_convc1(lv, ws.coords1, P, h, w, r->wfused, W[B_CONVC1], ws.cor1, 256, 1, s));
+            if (!forked) {
+                ProfScope prof(PC_CONVF1, s, 2.0 * M * 128 * 98);
+                hipLaunchKernelGGL(convf1_kernel, dim3(f1_blocks), dim3(256), 0, s, f1);
+            }
+        } else if (prof_enabled() || nofuse || forked || ondemand) {
             // (the 324 features stay fp32: written in split form the lookup takes 31 instead of 27 us, more than convc1
             // gains from a pre-split A -- and its HBM roofline is the one with a north-star target)
             if (ondemand) TRY(launch_corr_ondemand(fmap1, f2lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr, s));
@@ -397,7 +426,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         }
         TRY(check_launch("lookup + convf1"));
         // motion encoder (core/update.py:152-160)
-        TRY(launch_conv(gemm(conv_desc(ws.corr, ws.ld_corr, ws.ld_corr, nullptr, 0, 0, G[W_CONVC1], W[B_CONVC1], ws.cor1, 256, P, h, w, 256, 1, 1, 1), false, true), s));
+        if (!fuse_lookup) TRY(launch_conv(gemm(conv_desc(ws.corr, ws.ld_corr, ws.ld_corr, nullptr, 0, 0, G[W_CONVC1], W[B_CONVC1], ws.cor1, 256, P, h, w, 256, 1, 1, 1), false, true), s));
         if (forked) {
             TRY(launch_conv(c2, s));
             if (hipStreamWaitEvent(s, r->ev_join, 0) != hipSuccess) return fail(MFTX_E_STATE, "raft_refine: join failed");
@@ -490,6 +519,26 @@ extern "C" int mftx_corr_lookup(const float *lvl0, const float *lvl1, const floa
     return launch_corr_lookup(lv, coords, P, h, w, out, ld_out, (hipStream_t)stream);
 }
 
+extern "C" int mftx_pack_lookup_convc1_weights(const float *wpk, int ld_w, void *wfused, void *stream) {
+    if (!wpk || !wfused) return fail(MFTX_E_ARG, "pack_lookup_convc1_weights: null pointer");
+    if (ld_w < 324) return fail(MFTX_E_ARG, "pack_lookup_convc1_weights: need ld_w >= 324");
+    if (!aligned16(wfused)) return fail(MFTX_E_ALIGN, "pack_lookup_convc1_weights: output must be 16-byte aligned");
+    return launch_pack_lookup_convc1(wpk, ld_w, wfused, (hipStream_t)stream);
+}
+
+extern "C" int mftx_corr_lookup_convc1(const float *lvl0, const float *lvl1, const float *lvl2, const float *lvl3,
+                                       const float *coords, int P, int h, int w, const void *wfused, const float *bias,
+                                       float *out, int ld_out, int out_split, void *stream) {
+    if (!lvl0 || !lvl1 || !lvl2 || !lvl3 || !coords || !wfused || !bias || !out) return fail(MFTX_E_ARG, "corr_lookup_convc1: null pointer");
+    if (P <= 0 || h < 8 || w < 8 || ld_out < 256 || ld_out % 4) return fail(MFTX_E_ARG, "corr_lookup_convc1: bad sizes");
+    if (!lookup_convc1_applicable(P, h, w, ld_out)) return fail(MFTX_E_ARG, "corr_lookup_convc1: batch too large");
+    if (!aligned16(wfused) || !aligned16(bias) || !aligned16(out) || !aligned16(coords) ||
+        (out_split && (ld_out % 8 || (reinterpret_cast<uintptr_t>(out) & 31))))
+        return fail(MFTX_E_ALIGN, "corr_lookup_convc1: operands must be 16-byte aligned (a split-form output: 32-byte rows)");
+    const float *lv[4] = {lvl0, lvl1, lvl2, lvl3};
+    return launch_lookup_convc1(lv, coords, P, h, w, wfused, bias, out, ld_out, out_split ? 1 : 0, (hipStream_t)stream);
+}
+
 extern "C" int mftx_fmap_pyramid(const float *f2, int P, int C, int h, int w, float *lvl1, float *lvl2, float *lvl3,
                                  void *stream) {
     if (!f2 || !lvl1 || !lvl2 || !lvl3) return fail(MFTX_E_ARG, "fmap_pyramid: null pointer");
@@ -520,6 +569,12 @@ extern "C" int mftx_split_weights(const float *wpk, void *out, long long n_float
 extern "C" int mftx_conv2d(const mftx_conv_desc *d, void *stream) {
     if (!d) return fail(MFTX_E_ARG, "conv2d: null descriptor");
     return launch_conv(*d, (hipStream_t)stream);
+}
+
+extern "C" int mftx_conv2d_tile(const mftx_conv_desc *d, int tile, void *stream) {
+    if (!d) return fail(MFTX_E_ARG, "conv2d_tile: null descriptor");
+    if (tile < -1 || tile > 15) return fail(MFTX_E_ARG, "conv2d_tile: tile must be -1 (the library's choice) or 0..15");
+    return launch_conv(*d, (hipStream_t)stream, tile);
 }
 
 extern "C" int mftx_convex_upsample(const float *flow_lr, const float *ou, int ld_ou, const float *mask, int P,

@@ -52,10 +52,33 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 ARITH_F32, ARITH_SPLIT = 0, 1
 
 
-def split_weights(wpk: torch.Tensor) -> torch.Tensor:
-    """Packed fp32 conv weights -> the split-fp16 form (same shape and size) that ``conv2d(arith=ARITH_SPLIT)``
-    and the refinement engine's split arithmetic stream (csrc/conv_gemm.hip: split_weights_kernel)."""
+class SplitRangeError(MftxError):
+    """An operand of the split arithmetic is not below 65504 in magnitude (or not finite)."""
+
+
+def count_not_below(x: torch.Tensor, limit: float) -> int:
+    """Number of elements of a float32 device tensor with !(|x| < limit) -- NaN counts; limit = inf counts the
+    non-finite ones (``mftx_count_not_below``).  Synchronises (reads one counter back)."""
     lib = _lib.load()
+    if x.numel() == 0:
+        return 0
+    x = x if x.is_contiguous() else x.contiguous()
+    cnt = torch.zeros(1, dtype=torch.int32, device=x.device)
+    check(lib.mftx_count_not_below(_chk(x, "x"), x.numel(), float(limit), cnt.data_ptr(), _stream()), "mftx_count_not_below")
+    return int(cnt.item())
+
+
+def split_weights(wpk: torch.Tensor, check_range: bool = True) -> torch.Tensor:
+    """Packed fp32 conv weights -> the split-fp16 form (same shape and size) that ``conv2d(arith=ARITH_SPLIT)``
+    and the refinement engine's split arithmetic stream (csrc/conv_gemm.hip: split_weights_kernel).
+    check_range (weights: always; it costs one host sync at load): values that are not below 65504 in magnitude have no
+    finite fp16 high half -- ``SplitRangeError`` instead of NaN products later."""
+    lib = _lib.load()
+    if check_range:
+        bad = count_not_below(wpk, _lib.SPLIT_LIMIT)
+        if bad:
+            raise SplitRangeError(f"split arithmetic: {bad} of {wpk.numel()} values are not below {_lib.SPLIT_LIMIT:g} "
+                                  "in magnitude (fp16 range of the high halves); use arith='fp32'")
     out = torch.empty_like(wpk)
     check(lib.mftx_split_weights(_chk(wpk, "wpk"), out.data_ptr(), wpk.numel(), _stream()), "mftx_split_weights")
     return out
@@ -63,8 +86,9 @@ def split_weights(wpk: torch.Tensor) -> torch.Tensor:
 
 def split_activations(x: torch.Tensor) -> torch.Tensor:
     """fp32 [M, C] (C % 8 == 0) -> the split form the engine stores GEMM inputs in: every 8 channels of a row as
-    [hi x 8 | lo x 8] fp16 (same shape and dtype as a container).  The same kernel as ``split_weights``."""
-    return split_weights(x)
+    [hi x 8 | lo x 8] fp16 (same shape and dtype as a container).  The same kernel as ``split_weights``; no range check
+    (activations out of range surface as NaN, see ``mftx_count_not_below``)."""
+    return split_weights(x, check_range=False)
 
 
 def unsplit_activations(x: torch.Tensor) -> torch.Tensor:
@@ -302,6 +326,36 @@ def corr_lookup(lv, coords: torch.Tensor, h: int, w: int, r: int = 4):
     return out
 
 
+def pack_lookup_convc1_weights(wpk: torch.Tensor) -> torch.Tensor:
+    """convc1's weight in the ``pack_conv_weight`` form [256, 1, 352] -> the fragment stream of the fused
+    lookup + convc1 kernel (``mftx_pack_lookup_convc1_weights``; opaque bytes)."""
+    lib = _lib.load()
+    if wpk.dim() != 3 or wpk.shape[0] != 256 or wpk.shape[1] != 1 or wpk.shape[2] < 324:
+        raise MftxError("pack_lookup_convc1_weights: expected the packed convc1 weight [256, 1, >= 324]")
+    out = torch.empty(_lib.LOOKUP_CONVC1_WEIGHT_BYTES, dtype=torch.uint8, device=wpk.device)
+    check(lib.mftx_pack_lookup_convc1_weights(_chk(wpk, "wpk"), wpk.shape[2], out.data_ptr(), _stream()),
+          "mftx_pack_lookup_convc1_weights")
+    return out
+
+
+def corr_lookup_convc1(lv, coords: torch.Tensor, h: int, w: int, wfused: torch.Tensor, bias: torch.Tensor,
+                       out_split: bool = False):
+    """relu(convc1(lookup(coords)) + bias) without materialising the lookup (``mftx_corr_lookup_convc1``; split-fp16
+    arithmetic): lv as ``corr_lookup``, coords [P, h*w, 2], wfused from ``pack_lookup_convc1_weights`` -> [P*h*w, 256]
+    (fp32, or the split form when out_split)."""
+    lib = _lib.load()
+    P = coords.shape[0]
+    stride, _ = pyramid_layout(h, w)
+    for l, t in enumerate(lv):
+        if tuple(t.shape) != (P, h * w, stride[l]):
+            raise MftxError(f"corr_lookup_convc1: level {l} must be [{P}, {h * w}, {stride[l]}]")
+    out = torch.empty(P * h * w, 256, dtype=torch.float32, device=coords.device)
+    check(lib.mftx_corr_lookup_convc1(*[_chk(t, "level") for t in lv], _chk(coords, "coords"), P, h, w,
+                                      _chk(wfused, "wfused", torch.uint8), _chk(bias, "bias"), out.data_ptr(), 256,
+                                      int(bool(out_split)), _stream()), "mftx_corr_lookup_convc1")
+    return out
+
+
 def fmap_pyramid(f2: torch.Tensor, h: int, w: int):
     """f2 pixel-major [P, h*w, C] -> [f2, pooled level 1, 2, 3] ([P, h_l*w_l, C]); the feature pyramid of the
     on-demand correlation (AlternateCorrBlock, core/corr.py:78-82)."""
@@ -325,9 +379,10 @@ def corr_lookup_ondemand(f1: torch.Tensor, f2_levels, coords: torch.Tensor, h: i
 
 def conv2d(x: torch.Tensor, wpk: torch.Tensor, bias, P, h, w, N, kh, kw, act=None, out_scale=1.0, x2=None,
            addend=None, stride=0, hin=0, win=0, pad_y=0, pad_x=0, residual_mode=0, arith=ARITH_F32, a_split=False,
-           out_split=False, out=None):
+           out_split=False, out=None, tile=None):
     """x: pixel-major [P*h*w, C0] (optionally concatenated with x2 [P*h*w, C1]) ->
-    [P*h*w, N].  arith = ARITH_SPLIT: wpk is the output of ``split_weights``."""
+    [P*h*w, N].  arith = ARITH_SPLIT: wpk is the output of ``split_weights``.  tile: force the workgroup tile shape
+    (``mftx_conv2d_tile``; tests and micro-benchmarks -- every shape gives the same bits)."""
     lib = _lib.load()
     if out is None:
         out = torch.empty(P * h * w, N, dtype=torch.float32, device=x.device)
@@ -346,7 +401,10 @@ def conv2d(x: torch.Tensor, wpk: torch.Tensor, bias, P, h, w, N, kh, kw, act=Non
     d.stride, d.hin, d.win, d.pad_y, d.pad_x, d.residual_mode = stride, hin, win, pad_y, pad_x, residual_mode
     d.arith = arith
     d.a_split, d.out_split = int(bool(a_split)), int(bool(out_split))      # operands in split form (see split_activations)
-    check(lib.mftx_conv2d(C.byref(d), _stream()), "mftx_conv2d")
+    if tile is None:
+        check(lib.mftx_conv2d(C.byref(d), _stream()), "mftx_conv2d")
+    else:
+        check(lib.mftx_conv2d_tile(C.byref(d), int(tile), _stream()), "mftx_conv2d_tile")
     return out
 
 
@@ -496,7 +554,11 @@ class RaftEngine:
     # WeightSlot indices (csrc/raft_engine.hip) of the weights that feed GEMM layers
     GEMM_SLOTS = (0, 2, 6, 8, 10, 11, 13, 14, 16, 17, 19, 20, 22, 26, 28, 30)
 
-    def __init__(self, state_dict: dict, device, ondemand_corr=False, arith=ARITH_SPLIT):
+    OPTIONS = {"fork": 0, "presplit": 1, "group": 2, "fuse_lookup": 3}      # MFTX_RAFT_OPT_*
+
+    def __init__(self, state_dict: dict, device, ondemand_corr=False, arith=ARITH_SPLIT, options=None):
+        """options: {"fork" | "presplit" | "group" | "fuse_lookup": int} scheduling options of this handle
+        (``mftx_raft_set_option``; defaults are the measured best)."""
         lib = _lib.load()
         self.device = torch.device(device)
         self.weights = pack_raft_weights(state_dict, self.device)   # keep alive: the engine holds raw pointers
@@ -510,8 +572,13 @@ class RaftEngine:
             self.split = [split_weights(t) if i in self.GEMM_SLOTS else None for i, t in enumerate(self.weights)]
             sarr, self._keep_split = _lib.ptr_array([t.data_ptr() if t is not None else None for t in self.split])
             check(lib.mftx_raft_set_split_weights(self._h, sarr, len(self.split)), "mftx_raft_set_split_weights")
+            # lookup + convc1 as one kernel (the 324 features never leave the CU): convc1's weights as its fragment stream
+            self.wfused = pack_lookup_convc1_weights(self.weights[0])
+            check(lib.mftx_raft_set_lookup_fused(self._h, self.wfused.data_ptr()), "mftx_raft_set_lookup_fused")
         elif self.arith != ARITH_F32:
             raise MftxError(f"unknown arithmetic {arith!r}")
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
         self.ondemand_corr = bool(ondemand_corr)
         if self.ondemand_corr:                 # raft_params.alternate_corr: no stored correlation volume
             check(lib.mftx_raft_set_ondemand(self._h, 1), "mftx_raft_set_ondemand")
@@ -523,6 +590,9 @@ class RaftEngine:
                 self._h = None
         except Exception:
             pass
+
+    def set_option(self, name, value):
+        check(_lib.load().mftx_raft_set_option(self._h, self.OPTIONS[name], int(value)), "mftx_raft_set_option")
 
     def workspace(self, P, h, w):
         need = _lib.load().mftx_raft_workspace_bytes_for(self._h, P, h, w)

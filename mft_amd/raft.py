@@ -65,9 +65,18 @@ class RAFTWrapper:
         if arith not in ("split", "fp32"):
             raise ValueError(f"raft_params.arith must be 'split' or 'fp32', got {arith!r}")
         self._arith = ops.ARITH_SPLIT if arith == "split" else ops.ARITH_F32
-        self.fnet_engine = ops.EncoderEngine(self.sd, "fnet", True, self.device, arith=self._arith)
-        self.cnet_engine = ops.EncoderEngine(self.sd, "cnet", False, self.device, arith=self._arith)
-        self.engine = ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand, arith=self._arith)
+        # The split arithmetic needs every operand below 65504 in magnitude (the fp16 range of the high halves).  Weights
+        # are checked here, once (ops.split_weights): a checkpoint that does not fit runs on the fp32 matrix cores
+        # instead, with the reason logged.  Activations are not clamped: one that leaves the range turns into NaN in
+        # the outputs (never a finite wrong value); raft_params.check_finite = True checks every result and raises.
+        self._engine_options = dict(getattr(getattr(config, "raft_params", None), "engine_options", None) or {})
+        try:
+            self._build_engines()
+        except ops.SplitRangeError as e:
+            logger.warning("raft_params.arith = 'split' refused (%s): falling back to arith = 'fp32'", e)
+            self._arith = ops.ARITH_F32
+            self._build_engines()
+        self._check_finite = bool(getattr(getattr(config, "raft_params", None), "check_finite", False))
         # C.split_streams (env MFTX_SPLIT_STREAMS overrides): batches of >= 6 pairs run as that many parts on
         # separate HIP streams (see _refine_split); 1 = one stream.  Measured at 7 pairs, 512 x 512
         # (profiles/r2_split_streams.txt): 1 / 2 / 3 / 4 / 7 parts = 63.0 / 64.9 / 59.4 / 60.6 / 49.8 frames/s with fp32 MFMA
@@ -82,6 +91,17 @@ class RAFTWrapper:
         # kernels overlap the tail of frame t-1's GEMM-bound refinement instead of sitting on the
         # critical path.  Device-tensor frames must be complete when passed in.
         self._enc_stream = torch.cuda.Stream(device=self.device) if getattr(config, "async_encode", False) else None
+
+    def _build_engines(self):
+        self.fnet_engine = ops.EncoderEngine(self.sd, "fnet", True, self.device, arith=self._arith)
+        self.cnet_engine = ops.EncoderEngine(self.sd, "cnet", False, self.device, arith=self._arith)
+        self.engine = ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand, arith=self._arith,
+                                     options=self._engine_options)
+
+    @property
+    def arith(self):
+        """'split' or 'fp32': the arithmetic in use (a checkpoint outside the fp16 range falls back to 'fp32')."""
+        return "split" if self._arith == ops.ARITH_SPLIT else "fp32"
 
     @staticmethod
     def _load_weights(config):
@@ -240,6 +260,13 @@ class RAFTWrapper:
         else:
             flow, occl, sigma = self.engine.refine(fmap1, fmap2, net, inp, ref.h, ref.w, iters, pads=ref.pads,
                                                    flow_init=flow_init, packed=packed, planar=want_planar)
+        if self._check_finite:
+            bad = sum(ops.count_not_below(t.reshape(-1), float("inf")) for t in (packed, flow, occl, sigma) if t is not None)
+            if bad:
+                raise FloatingPointError(
+                    f"compute_flow: {bad} non-finite output values" + (
+                        " -- an activation left the fp16 range of the split arithmetic (|x| >= 65504); "
+                        "set raft_params.arith = 'fp32'" if self._arith == ops.ARITH_SPLIT else ""))
         if packed is not None and flow is None:
             return [(None, None, None, packed[i]) for i in range(P)]
         if packed is not None:
@@ -255,7 +282,8 @@ class RAFTWrapper:
         H0, W0 = geom.shape
         S = min(self._split_streams, P)
         while len(self._engines) < S:
-            self._engines.append(ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand, arith=self._arith)
+            self._engines.append(ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand, arith=self._arith,
+                                                options=self._engine_options)
                                  if self._engines else self.engine)
             # part 0 runs on the calling stream, the others on side streams (HIP multiplexes streams onto a handful
             # of hardware queues: every stream saved keeps the copy / encoder streams on queues of their own)

@@ -226,6 +226,121 @@ def test_conv2d_split_arith_vs_fp64(ops_mod, cin, cout, kh, kw, act, scale, P, h
     assert float(err["split"].pow(2).mean().sqrt()) <= 1.05 * float(err["fp32"].pow(2).mean().sqrt()) + 1e-12
 
 
+@pytest.mark.parametrize("band", ["wide", "tiny", "near_limit"])
+def test_conv2d_split_arith_operand_range(ops_mod, band):
+    """The split arithmetic over the whole operand range it is specified for: magnitudes from 1e-8 up to the fp16 limit
+    (wide), entirely inside the fp16-subnormal band |x| < 6.1e-5 (tiny: the halves lose bits there -- the ABSOLUTE error
+    of an operand stays <= 2^-36), and within 1 % of 65504 (near_limit).  Error against an fp64 evaluation, relative to
+    the sum of the products' magnitudes, next to the fp32-MFMA kernel's on the same data."""
+    g = torch.Generator().manual_seed(17)
+    P, h, w, cin, cout = 2, 24, 32, 256, 128
+    M = P * h * w
+    sign = lambda shape: torch.where(torch.rand(shape, generator=g) < 0.5, -1.0, 1.0)     # noqa: E731
+    if band == "wide":
+        x = sign((M, cin)) * torch.exp(torch.empty(M, cin).uniform_(np.log(1e-8), np.log(6.0e4), generator=g))
+        x[::7, ::5] = sign((len(x[::7]), len(x[0, ::5]))) * torch.empty(len(x[::7]), len(x[0, ::5])).uniform_(64850.0, 65503.0, generator=g)
+    elif band == "tiny":
+        x = sign((M, cin)) * torch.exp(torch.empty(M, cin).uniform_(np.log(1e-8), np.log(6.0e-5), generator=g))
+    else:
+        x = sign((M, cin)) * torch.empty(M, cin).uniform_(64850.0, 65503.0, generator=g)
+    wt = sign((cout, cin, 3, 3)) * torch.exp(torch.empty(cout, cin, 3, 3).uniform_(np.log(1e-6), np.log(1e2), generator=g))
+    bias = torch.zeros(cout)
+    xd, wp = x.to(DEV).contiguous(), ops_mod.pack_conv_weight(wt.to(DEV))
+    xi = x.reshape(P, h, w, cin).permute(0, 3, 1, 2).double()
+    ref = F.conv2d(xi, wt.double(), padding=1).permute(0, 2, 3, 1).reshape(M, cout)
+    mag = F.conv2d(xi.abs(), wt.double().abs(), padding=1).permute(0, 2, 3, 1).reshape(M, cout)
+    err = {}
+    for name, ar, wk in (("fp32", ops_mod.ARITH_F32, wp), ("split", ops_mod.ARITH_SPLIT, ops_mod.split_weights(wp))):
+        y = ops_mod.conv2d(xd, wk, bias.to(DEV), P, h, w, cout, 3, 3, arith=ar).cpu().double()
+        assert bool(torch.isfinite(y).all()), name
+        err[name] = float(((y - ref).abs() / mag).max())
+    # relative to sum |a b|: an fp32 dot product of 2304 terms is good to ~1e-6; the split products to the same grade
+    assert err["split"] < (2e-5 if band == "tiny" else 1e-6), err
+    if band != "tiny":
+        assert err["split"] <= 2.0 * err["fp32"] + 1e-8, err
+    # the same operands handed over in split form (what the engine stores): same bits as splitting in registers
+    y_reg = ops_mod.conv2d(xd, ops_mod.split_weights(wp), bias.to(DEV), P, h, w, cout, 3, 3, arith=ops_mod.ARITH_SPLIT)
+    y_pre = ops_mod.conv2d(ops_mod.split_activations(xd), ops_mod.split_weights(wp), bias.to(DEV), P, h, w, cout, 3, 3,
+                           arith=ops_mod.ARITH_SPLIT, a_split=True)
+    assert torch.equal(y_reg, y_pre)
+
+
+def _flow_config(**raft_kw):
+    from mft_amd.config import Config
+    fc, rp = Config(), Config()
+    fc.model, fc.synthetic_weights_seed, fc.flow_iters = None, 7, 2
+    rp.occlusion_module, rp.small, rp.mixed_precision = "separate_with_uncertainty", False, False
+    for k, v in raft_kw.items():
+        setattr(rp, k, v)
+    fc.raft_params = rp
+    return fc
+
+
+def test_split_weights_range_guard(ops_mod, weights_np):
+    """A weight that is not below 65504 in magnitude has no finite fp16 high half: split_weights refuses it
+    (SplitRangeError), RaftEngine with it, and the plugin falls back to the fp32 arithmetic with a logged reason."""
+    from mft_amd.raft import RAFTWrapper
+    w = torch.zeros(128, 1, 64, device=DEV)
+    w[3, 0, 5] = 65503.0
+    ops_mod.split_weights(w)                                  # the largest fp16 itself is fine
+    assert ops_mod.count_not_below(w, 65504.0) == 0
+    for bad in (65504.0, -7.0e4, float("inf"), float("nan")):
+        w[3, 0, 5] = bad
+        assert ops_mod.count_not_below(w, 65504.0) == 1
+        with pytest.raises(ops_mod.SplitRangeError):
+            ops_mod.split_weights(w)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in weights_np.items()}
+    sd["update_block.gru.convz1.weight"][5, 7, 0, 2] = 1.0e5
+    with pytest.raises(ops_mod.SplitRangeError):
+        ops_mod.RaftEngine({k: v.to(DEV) for k, v in sd.items()}, DEV)
+    fc = _flow_config()
+    wrapper = RAFTWrapper(fc, state_dict=sd)
+    assert wrapper.arith == "fp32"                            # refused the split arithmetic, kept working
+    img = np.random.default_rng(0).integers(0, 255, (64, 96, 3), dtype=np.uint8)
+    flow, extra = wrapper.compute_flow(img, img, mode="flow")
+    assert flow.shape == (2, 64, 96)
+    assert RAFTWrapper(fc, state_dict={k: torch.from_numpy(v) for k, v in weights_np.items()}).arith == "split"
+
+
+def test_split_arith_out_of_range_is_nan(ops_mod, weights_np):
+    """Activations are not clamped.  One that leaves the fp16 range (|x| >= 65520: hi = inf, residual = -inf) makes every
+    product it takes part in NaN: the outputs of its receptive field are NaN -- never a finite wrong value -- and
+    raft_params.check_finite turns that into an exception.  The fp32 arithmetic has no such limit."""
+    from mft_amd.raft import RAFTWrapper
+    g = torch.Generator().manual_seed(2)
+    P, h, w = 1, 16, 24
+    x = torch.randn(P * h * w, 128, generator=g)
+    x[100, 17] = 7.0e4
+    wt = ops_mod.pack_conv_weight((torch.randn(128, 128, 3, 3, generator=g) * 0.05).to(DEV))
+    y = ops_mod.conv2d(x.to(DEV), ops_mod.split_weights(wt), None, P, h, w, 128, 3, 3, arith=ops_mod.ARITH_SPLIT).cpu()
+    y32 = ops_mod.conv2d(x.to(DEV), wt, None, P, h, w, 128, 3, 3).cpu()
+    assert bool(torch.isfinite(y32).all())
+    bad = ~torch.isfinite(y).all(1)
+    yy, xx = 100 // w, 100 % w
+    hood = torch.zeros(h, w, dtype=torch.bool)
+    hood[max(yy - 1, 0):yy + 2, max(xx - 1, 0):xx + 2] = True
+    assert torch.equal(bad.reshape(h, w), hood)               # exactly the 3 x 3 receptive field
+    assert torch.allclose(y[~bad], y32[~bad], rtol=1e-4, atol=1e-4)
+    # the engine: features scaled so that the correlation volume leaves the range (<f1, f2> / 16 ~ 1e6)
+    sd = {k: torch.from_numpy(v) for k, v in weights_np.items()}
+    mk = _flow_config
+    wrapper = RAFTWrapper(mk(), state_dict=sd)
+    eng = wrapper.engine
+    N = 16 * 24
+    f = torch.full((1, N, 256), 300.0, device=DEV)
+    net = torch.zeros(1, N, 128, device=DEV)
+    flow, occl, sigma = eng.refine(f, f, net, net, 16, 24, 2)[:3]
+    assert not bool(torch.isfinite(flow).any())               # NaN everywhere, not a finite wrong flow
+    assert ops_mod.count_not_below(flow.reshape(-1), float("inf")) == flow.numel()
+    checked = RAFTWrapper(mk(check_finite=True), state_dict=sd)
+    from mft_amd.raft import FrameFeatures
+    ff = FrameFeatures(f[0], net[0], net[0], 16, 24, (0, 0, 0, 0), (128, 192))
+    checked._frames = {"a": ff, "b": ff}
+    img = np.zeros((128, 192, 3), np.uint8)
+    with pytest.raises(FloatingPointError, match="fp16 range"):
+        checked.compute_pairs([("a", img, "b", img)])
+
+
 @pytest.mark.parametrize("cin,cout,kh,kw,P,h,w,x2c", [(256, 192, 3, 3, 2, 16, 24, 0), (128, 128, 1, 5, 7, 32, 32, 128),
                                                     (328, 256, 1, 1, 1, 17, 23, 0), (256, 126, 3, 3, 3, 33, 47, 0),
                                                     (712, 256, 3, 3, 1, 16, 24, 0)])
@@ -348,25 +463,42 @@ def test_conv2d_argument_errors(ops_mod):
 # a10 + a12
 # ---------------------------------------------------------------------------
 
-def _run_update_block(ops_mod, weights_np, inp_d, iters=1):
+def _run_update_block(ops_mod, weights_np, inp_d, mode="f32"):
     """One engine iteration from the per-op fixture's (net, inp, corr, flow): not reachable through
     mftx_raft_refine (it computes corr itself), so the layers are chained through mftx_conv2d exactly
-    as csrc/raft_engine.hip chains them."""
+    as csrc/raft_engine.hip chains them.  mode: "f32" (fp32 MFMA), "split" (split-fp16 products, activations split in
+    registers) or "presplit" (activations handed over and returned in split form wherever the engine stores them so:
+    channel counts in whole groups of 8); the N <= 4 output layers run on the fp32 VALU kernel in every mode, as in
+    the engine."""
     sd = {k: torch.from_numpy(v).to(DEV) for k, v in weights_np.items()}
     h, w = gi.OPS_H, gi.OPS_W
 
-    def conv(x, name, k, act, x2=None):
+    def conv(x, name, k, act, x2=None, out_scale=1.0):
         wt = sd[name + ".weight"]
         kh, kw = wt.shape[2:]
-        return ops_mod.conv2d(x, ops_mod.pack_conv_weight(wt), sd[name + ".bias"].contiguous(), 1, h, w, wt.shape[0],
-                              kh, kw, act=act, x2=x2)
+        N = wt.shape[0]
+        pk = ops_mod.pack_conv_weight(wt)
+        bias = sd[name + ".bias"].contiguous()
+        if mode == "f32" or N <= 4:
+            return ops_mod.conv2d(x, pk, bias, 1, h, w, N, kh, kw, act=act, x2=x2, out_scale=out_scale)
+        pk = ops_mod.split_weights(pk)
+        groups = x.shape[1] % 8 == 0 and (x2 is None or x2.shape[1] % 8 == 0)
+        if mode == "presplit" and groups:
+            osp = N % 8 == 0
+            y = ops_mod.conv2d(ops_mod.split_activations(x), pk, bias, 1, h, w, N, kh, kw, act=act, out_scale=out_scale,
+                               x2=None if x2 is None else ops_mod.split_activations(x2), arith=ops_mod.ARITH_SPLIT,
+                               a_split=True, out_split=osp)
+            return ops_mod.unsplit_activations(y).contiguous() if osp else y
+        return ops_mod.conv2d(x, pk, bias, 1, h, w, N, kh, kw, act=act, x2=x2, out_scale=out_scale, arith=ops_mod.ARITH_SPLIT)
     return sd, conv, h, w
 
 
-def test_update_block_and_ou_heads_vs_golden(ops_mod, gold, inp, weights_np):
+@pytest.mark.parametrize("mode", ["f32", "split", "presplit"])
+def test_update_block_and_ou_heads_vs_golden(ops_mod, gold, inp, weights_np, mode):
     """a7-a9 + a11 per op against the reference's own update block / occlusion block outputs
-    (gold ub_* / ou_*): the layers run through mftx_conv2d in the engine's order, the gate algebra in torch."""
-    sd, conv, h, w = _run_update_block(ops_mod, weights_np, inp)
+    (gold ub_* / ou_*): the layers run through mftx_conv2d in the engine's order, the gate algebra in torch -- in the fp32
+    MFMA arithmetic and in the DEFAULT product arithmetic (split fp16), with fp32 and with split-form operands."""
+    sd, conv, h, w = _run_update_block(ops_mod, weights_np, inp, mode)
     u, o = "update_block.", "occlusion_block."
     corr, flow, net, ctx = pm(inp["corr"]), pm(inp["flow"]), pm(inp["net"]), pm(inp["inp"])
     cor = conv(conv(corr, u + "encoder.convc1", 1, "relu"), u + "encoder.convc2", 3, "relu")
@@ -375,8 +507,9 @@ def test_update_block_and_ou_heads_vs_golden(ops_mod, gold, inp, weights_np):
     wf1p = torch.zeros(128, 4, 7, 7, device=DEV)
     wf1p[:, :2] = wf1
     flow4 = torch.cat([flow, torch.zeros_like(flow)], 1).contiguous()
-    flo = ops_mod.conv2d(flow4, ops_mod.pack_conv_weight(wf1p), sd[u + "encoder.convf1.bias"].contiguous(), 1, h, w, 128,
-                         7, 7, act="relu")
+    wf1pk = ops_mod.pack_conv_weight(wf1p)
+    flo = ops_mod.conv2d(flow4, wf1pk if mode == "f32" else ops_mod.split_weights(wf1pk), sd[u + "encoder.convf1.bias"].contiguous(),
+                         1, h, w, 128, 7, 7, act="relu", arith=ops_mod.ARITH_F32 if mode == "f32" else ops_mod.ARITH_SPLIT)
     flo = conv(flo, u + "encoder.convf2", 3, "relu")
     mot = conv(torch.cat([cor, flo], 1).contiguous(), u + "encoder.conv", 3, "relu")
     motion = torch.cat([mot, flow], 1).contiguous()
@@ -392,8 +525,7 @@ def test_update_block_and_ou_heads_vs_golden(ops_mod, gold, inp, weights_np):
     assert maxerr(from_pm(hcur, h, w), T(gold["ub_net"])) < 2e-4
     delta = conv(conv(hcur, u + "flow_head.conv1", 3, "relu"), u + "flow_head.conv2", 3, None)
     assert maxerr(from_pm(delta, h, w), T(gold["ub_delta"])) < 2e-4
-    mask = ops_mod.conv2d(conv(hcur, u + "mask.0", 3, "relu"), ops_mod.pack_conv_weight(sd[u + "mask.2.weight"]),
-                          sd[u + "mask.2.bias"].contiguous(), 1, h, w, 576, 1, 1, out_scale=0.25)
+    mask = conv(conv(hcur, u + "mask.0", 3, "relu"), u + "mask.2", 1, None, out_scale=0.25)
     assert maxerr(from_pm(mask, h, w), T(gold["ub_mask"])) < 2e-4
     # a11: OU heads on the fixture's own inputs (core/update.py:196-214)
     ou_in = torch.cat([pm(inp["net"]), pm(inp["inp"]), pm(inp["corr"]), pm(inp["flow"]), pm(inp["delta_flow"]),
@@ -717,67 +849,166 @@ def test_raft_engine_argument_errors(ops_mod, weights_np):
     assert bool(torch.isfinite(flow).all()) and float(occl.min()) >= 0 and float(sigma.min()) >= 0
 
 
-def test_engine_register_split_bitwise(tmp_path):
-    """The refinement engine with fp32 activations split in the GEMMs' registers (MFTX_RAFT_NOPRESPLIT: other kernels,
+# ---------------------------------------------------------------------------
+# lookup fused into convc1 (mftx_corr_lookup_convc1): core/corr.py:30-51 + core/update.py:152-153
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("h,w,P,spread", [(16, 24, 1, 3.0), (17, 23, 3, 6.0), (33, 50, 2, 12.0), (64, 64, 7, 40.0), (46, 62, 5, 500.0)])
+def test_lookup_convc1_fused_vs_separate(ops_mod, h, w, P, spread):
+    """relu(convc1(lookup)) as ONE kernel -- the 324 features live in LDS only -- against the two kernels it replaces
+    (mftx_corr_lookup -> mftx_conv2d in the split arithmetic) and against an fp64 evaluation of the same products:
+    odd 1/8 grids (floor-sized pyramid levels), tiles of every size (4 .. 64 cells), ragged last tiles, windows that
+    leave the level (zeros), wild coordinates."""
+    g = torch.Generator().manual_seed(h * 100 + w)
+    N = h * w
+    f1 = torch.randn(P, N, 256, generator=g).to(DEV)
+    f2 = (f1.cpu() + 0.5 * torch.randn(P, N, 256, generator=g)).to(DEV)
+    lv = ops_mod.corr_pyramid(f1, f2, h, w, arith=ops_mod.ARITH_SPLIT)
+    grid = torch.stack([pm(O.pixel_grid(h, w)[None])] * P)
+    coords = (grid.cpu() + spread * torch.randn(P, N, 2, generator=g)).to(DEV).contiguous()
+    wt = torch.randn(256, 324, 1, 1, generator=g) * 0.05
+    bias = torch.randn(256, generator=g).to(DEV)
+    wpk = ops_mod.pack_conv_weight(wt.to(DEV))
+    feats = ops_mod.corr_lookup(lv, coords, h, w).reshape(P * N, 324)
+    apart = ops_mod.conv2d(feats, ops_mod.split_weights(wpk), bias, P, h, w, 256, 1, 1, act="relu", arith=ops_mod.ARITH_SPLIT)
+    wf = ops_mod.pack_lookup_convc1_weights(wpk)
+    fused = ops_mod.corr_lookup_convc1(lv, coords, h, w, wf, bias)
+    ref64 = torch.relu(feats.double().cpu() @ wt.reshape(256, 324).double().T + bias.double().cpu())
+    scale = float(ref64.abs().max())
+    e_fused, e_apart = maxerr(fused.cpu(), ref64) / scale, maxerr(apart.cpu(), ref64) / scale
+    assert e_fused < 2e-6 and e_fused < 4 * e_apart + 1e-7, (e_fused, e_apart)
+    # split-form output (what convc2 reads in the engine): the same values, bit for bit
+    split = ops_mod.corr_lookup_convc1(lv, coords, h, w, wf, bias, out_split=True)
+    enc = ops_mod.split_activations(fused)
+    assert torch.equal(split.view(torch.int32), enc.view(torch.int32))
+
+
+def test_lookup_convc1_fused_batch_and_tile_invariance(ops_mod):
+    """A cell's row does not depend on the batch it is computed in (tile size, position in the tile, workgroup)."""
+    g = torch.Generator().manual_seed(9)
+    h, w, P = 24, 40, 5
+    N = h * w
+    f1 = torch.randn(P, N, 256, generator=g).to(DEV)
+    f2 = torch.randn(P, N, 256, generator=g).to(DEV)
+    lv = ops_mod.corr_pyramid(f1, f2, h, w, arith=ops_mod.ARITH_SPLIT)
+    coords = (torch.stack([pm(O.pixel_grid(h, w)[None])] * P).cpu() + 5 * torch.randn(P, N, 2, generator=g)).to(DEV).contiguous()
+    wpk = ops_mod.pack_conv_weight((torch.randn(256, 324, 1, 1, generator=g) * 0.05).to(DEV))
+    bias = torch.randn(256, generator=g).to(DEV)
+    wf = ops_mod.pack_lookup_convc1_weights(wpk)
+    whole = ops_mod.corr_lookup_convc1(lv, coords, h, w, wf, bias).reshape(P, N, 256)
+    for i in (0, 3):
+        one = ops_mod.corr_lookup_convc1([t[i:i + 1].contiguous() for t in lv], coords[i:i + 1].contiguous(), h, w, wf, bias)
+        assert torch.equal(one.reshape(N, 256), whole[i])
+
+
+def test_lookup_convc1_argument_errors(ops_mod):
+    h, w = 16, 16
+    stride, _ = ops_mod.pyramid_layout(h, w)
+    lv = [torch.zeros(1, h * w, stride[l], device=DEV) for l in range(4)]
+    coords = torch.zeros(1, h * w, 2, device=DEV)
+    wf = torch.zeros(393216, dtype=torch.uint8, device=DEV)
+    bias = torch.zeros(256, device=DEV)
+    with pytest.raises(ops_mod.MftxError):
+        ops_mod.corr_lookup_convc1(lv[:3] + [lv[3][:, :, :1].contiguous()], coords, h, w, wf, bias)
+    with pytest.raises(ops_mod.MftxError):
+        ops_mod.pack_lookup_convc1_weights(torch.zeros(256, 1, 320, device=DEV))
+    out = ops_mod.corr_lookup_convc1(lv, coords, h, w, wf, bias)
+    assert float(out.abs().max()) == 0.0
+
+
+
+def _engine_outputs(options):
+    """One refinement of the RAFT engine on seeded random features with the given per-handle options."""
+    from mft_amd import ops
+    from mft_amd.weights import make_weights
+    sd = {k: torch.from_numpy(v).cuda() for k, v in make_weights(7).items()}
+    eng = ops.RaftEngine(sd, "cuda", options=options)
+    g = torch.Generator().manual_seed(11)
+    P, h, w = 3, 24, 40
+    f1 = torch.randn(P, h * w, 256, generator=g).cuda()
+    f2 = (f1.cpu() + 0.3 * torch.randn(P, h * w, 256, generator=g)).cuda()
+    net = torch.tanh(torch.randn(P, h * w, 128, generator=g)).cuda()
+    inp = torch.relu(torch.randn(P, h * w, 128, generator=g)).cuda()
+    flow, occl, sigma = eng.refine(f1, f2, net, inp, h, w, 4)[:3]
+    return np.concatenate([t.cpu().numpy().ravel() for t in (flow, occl, sigma)])
+
+
+def test_engine_register_split_bitwise():
+    """The refinement engine with fp32 activations split in the GEMMs' registers (option presplit = 0: other kernels,
     other epilogue variants, GRU state in fp32 only) agrees with the default engine (activations stored in split form by
-    their producers) to the last digits; with the lookup / convf1 launches kept apart (MFTX_RAFT_NOFUSE) bit for bit."""
-    import os
-    import subprocess
-    import sys
-    from pathlib import Path
-    worker = Path(__file__).with_name("engine_worker.py")
-    outs = {}
-    for tag, extra in (("default", {}), ("nopresplit", {"MFTX_RAFT_NOPRESPLIT": "1"}), ("nofuse", {"MFTX_RAFT_NOFUSE": "1"})):
-        f = tmp_path / f"{tag}.npy"
-        res = subprocess.run([sys.executable, str(worker), str(f)], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
-        assert res.returncode == 0, res.stderr[-2000:]
-        outs[tag] = np.load(f)
+    their producers) to the last digits; with the flow branch in order on one stream (fork = 0) and with the grouped
+    launches kept apart (group = 0) bit for bit.  Options are per handle (mftx_raft_set_option), not process state."""
+    base = {"fuse_lookup": 0}
+    outs = {tag: _engine_outputs(dict(base, **extra)) for tag, extra in
+            (("default", {}), ("nopresplit", {"presplit": 0}), ("nofork", {"fork": 0}), ("nogroup", {"group": 0, "fork": 0}))}
     assert np.isfinite(outs["default"]).all()
-    assert np.array_equal(outs["nofuse"], outs["default"])
+    assert np.array_equal(outs["nofork"], outs["default"])
+    assert np.array_equal(outs["nogroup"], outs["default"])
     # (not bit for bit: the OU heads' gather reads h back from its split form, hi + lo / 2048, which re-splits to another
     # pair of halves in rare rounding ties -- differences of an ulp in their inputs)
     assert np.abs(outs["nopresplit"] - outs["default"]).max() < 2e-5
 
 
-def test_conv_tile_shapes_bitwise(tmp_path):
+def test_engine_fused_lookup_matches_unfused():
+    """The engine with lookup + convc1 as ONE kernel (the default) against the same engine with the two kept apart: the
+    fused kernel sums convc1's 324 products in another order (level by level, 16 at a time), so the iterations drift
+    apart by fp32 rounding only."""
+    fused, apart = _engine_outputs({}), _engine_outputs({"fuse_lookup": 0})
+    assert np.isfinite(fused).all()
+    n = 3 * 2 * 192 * 320
+    d = (fused[:n] - apart[:n]).reshape(3, 2, -1)
+    epe = np.sqrt((d ** 2).sum(1)).mean()
+    assert epe < 1e-4, epe
+    assert np.abs(fused[n:] - apart[n:]).max() < 1e-3
+
+
+def _tile_layers(arith, tile, ref=False):
+    """A few conv GEMMs with the tile shape forced (mftx_conv2d_tile), outputs concatenated."""
+    from mft_amd import ops
+    g = torch.Generator().manual_seed(5)
+    outs = []
+    layers = [(256, 128, 1, 5, 1, 64, 64, "tanh"), (256, 126, 3, 3, 2, 33, 47, "relu"),
+              (128, 64, 3, 3, 1, 64, 64, "relu"), (324, 256, 1, 1, 1, 17, 23, None)]
+    if arith == 2:      # channel counts in whole 8-channel groups; N = 256 wide, two input segments, M not a multiple of any tile
+        layers = [(256, 128, 1, 5, 1, 64, 64, "tanh"), (256, 126, 3, 3, 2, 33, 47, "relu"),
+                  (384, 256, 5, 1, 2, 40, 56, "relu"), (328, 256, 1, 1, 1, 17, 23, None), (192, 384, 3, 3, 1, 24, 31, "relu")]
+    for (cin, cout, kh, kw, P, h, w, act) in layers:
+        x = torch.randn(P * h * w, cin, generator=g).cuda()
+        wt = ops.pack_conv_weight((torch.randn(cout, cin, kh, kw, generator=g) * 0.05).cuda())
+        b = torch.randn(cout, generator=g).cuda()
+        if arith:
+            wt = ops.split_weights(wt)
+        if arith == 2:
+            x2 = None
+            if cin == 384:                                   # as the GRU gates: [h | x] from two tensors
+                x, x2 = x[:, :128].contiguous(), x[:, 128:].contiguous()
+            y = ops.conv2d(ops.split_activations(x), wt, b, P, h, w, cout, kh, kw, act=act, arith=1, a_split=True,
+                           x2=None if x2 is None else ops.split_activations(x2), tile=tile)
+            if ref:                                          # the same layer with A split in registers: same bits
+                r = ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act=act, arith=1, x2=x2, tile=tile)
+                assert torch.equal(y, r), ((cin, cout, kh, kw), float((y - r).abs().max()))
+            outs.append(y.cpu().numpy().ravel())
+            continue
+        outs.append(ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act=act, arith=arith, tile=tile).cpu().numpy().ravel())
+    return np.concatenate(outs)
+
+
+def test_conv_tile_shapes_bitwise():
     """Every tile shape -- 128x128, 128x64, 64x64 on v_mfma_f32_32x32x2_f32 and the 32x32 tile of
     v_mfma_f32_16x16x4_f32 waves used for very small M x N -- gives the same bits: the reduction order
     is a property of the kernel, not of the tiling (the 1-vs-N GPU equality relies on it)."""
-    import os
-    import subprocess
-    import sys
-    from pathlib import Path
-    worker = Path(__file__).with_name("tile_worker.py")
-    outs = {}
-    for tile in (0, 1, 2, 5):
-        f = tmp_path / f"t{tile}.npy"
-        env = dict(os.environ, MFTX_CONV_TILE=str(tile))
-        res = subprocess.run([sys.executable, str(worker), str(f)], env=env, capture_output=True, text=True, timeout=300)
-        assert res.returncode == 0, res.stderr[-2000:]
-        outs[tile] = np.load(f)
+    outs = {tile: _tile_layers(0, tile) for tile in (0, 1, 2, 5)}
     for tile in (0, 1, 5):
         assert np.array_equal(outs[tile], outs[2]), tile
-    # the same for the split-arithmetic kernels: 128x128 (four and eight waves), 64x64, 128x256, 128x192, 224x128 (uneven
-    # wave rows), rings of two to four chunks
-    outs = {}
-    for tile in (0, 6, 9, 10, 14, 15):
-        f = tmp_path / f"s{tile}.npy"
-        env = dict(os.environ, MFTX_CONV_TILE=str(tile), MFTX_TILE_WORKER_ARITH="1")
-        res = subprocess.run([sys.executable, str(worker), str(f)], env=env, capture_output=True, text=True, timeout=300)
-        assert res.returncode == 0, res.stderr[-2000:]
-        outs[tile] = np.load(f)
-    for tile in (6, 9, 10, 14, 15):
+    # the same for the split-arithmetic kernels: 128x128 (four and eight waves), 64x64, 128x256, 128x192, rings of two to
+    # four chunks
+    outs = {tile: _tile_layers(1, tile) for tile in (0, 6, 9, 10, 14)}
+    for tile in (6, 9, 10, 14):
         assert np.array_equal(outs[tile], outs[0]), tile
-    # and for a pre-split A operand, including the 112 x 256 tile on 16x16x32 MFMAs (whose k slots are fed so that every
-    # accumulator sees the sequence of the 32x32x16 form)
-    outs = {}
-    for tile in (0, 6, 9, 10, 13, 14, 15):
-        f = tmp_path / f"p{tile}.npy"
-        env = dict(os.environ, MFTX_CONV_TILE=str(tile), MFTX_TILE_WORKER_ARITH="2")
-        if tile == 0:
-            env["MFTX_TILE_WORKER_REF"] = "1"
-        res = subprocess.run([sys.executable, str(worker), str(f)], env=env, capture_output=True, text=True, timeout=300)
-        assert res.returncode == 0, res.stderr[-2000:]
-        outs[tile] = np.load(f)
-    for tile in (6, 9, 10, 13, 14, 15):
+    # and for a pre-split A operand
+    outs = {tile: _tile_layers(2, tile, ref=(tile == 0)) for tile in (0, 6, 9, 10, 14)}
+    for tile in (6, 9, 10, 14):
         assert np.array_equal(outs[tile], outs[0]), tile
+    # the measurement-only shapes (224 x 128, 112 x 256 on 16-row MFMAs) are not part of the product build
+    from mft_amd.ops import MftxError
+    with pytest.raises(MftxError, match="measurement-only"):
+        _tile_layers(2, 13)
