@@ -96,6 +96,13 @@ def build_tracker(args, sharded):
     if getattr(args, "alternate_corr", False):
         conf.flow_config.raft_params.alternate_corr = True
     conf.flow_config.raft_params.arith = getattr(args, "arith", "split")
+    opts = {}
+    if getattr(args, "no_graphs", False):
+        opts["graph"] = 0                     # plain launches instead of hipGraph replays (A/B)
+    if getattr(args, "no_fused_lookup", False):
+        opts["fuse_lookup"] = 0               # lookup and convc1 as two kernels (A/B)
+    if opts:
+        conf.flow_config.raft_params.engine_options = opts
     conf.keep_result_on_device = True
     conf.delta_sharding = sharded
     return conf.tracker_class(conf), conf
@@ -305,6 +312,8 @@ def main():
     ap.add_argument("--arith", choices=("split", "fp32"), default="split",
                     help="raft_params.arith: split-fp16 products on the fp16 matrix cores (default) or fp32 MFMA")
     ap.add_argument("--no-alt-arith", action="store_true", help="skip the short pass in the other arithmetic")
+    ap.add_argument("--no-graphs", action="store_true", help="A/B: plain kernel launches instead of hipGraph replays")
+    ap.add_argument("--no-fused-lookup", action="store_true", help="A/B: correlation lookup and convc1 as two kernels")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="with --force-sharded on ONE GPU: behave like rank 0 of this many ranks (compute only that rank's "
                          "share of every window; the other ranks' slots of the all-gathers are filled with copies of the "
@@ -389,11 +398,27 @@ def main():
         raise SystemExit(f"timed region is not the 7-pair steady state: warm-up {warm_pairs}, timed {timed_pairs}")
 
     kernels, prof_pairs = {}, []
+    ranks_seen = 1
+    if sharded:
+        # what the collectives themselves say about the job: every rank contributes a one
+        ones = torch.ones(1, device="cuda", dtype=torch.float32)
+        dist.all_reduce(ones)
+        ranks_seen = int(round(float(ones.item())))
     if n_prof and not sharded:
         kernels, prof_pairs = profile_pass(tracker, frames, first + args.steps, n_prof, args.arith)
         torch.cuda.synchronize()
         if min(prof_pairs) != FULL_PAIRS:
             raise SystemExit(f"profile pass left the steady state: {prof_pairs}")
+    elif n_prof and rank == 0:
+        # N > 1 (or forced sharding): the per-kernel roofline of the same workload, measured on rank 0 with a local,
+        # unsharded tracker after the timed region (the other ranks wait at the final barrier) -- a rank of the sharded
+        # job runs the very same kernels on batches of 7 or 8 pairs
+        ptr, _ = build_tracker(args, sharded=False)
+        ptr.init(frames[0])
+        run_frames(ptr, frames, 1, preroll, 1)
+        kernels, prof_pairs = profile_pass(ptr, frames, 1 + preroll, min(n_prof, 10), args.arith)
+        torch.cuda.synchronize()
+        del ptr
 
     result = None
     if rank == 0:
@@ -417,6 +442,7 @@ def main():
                        "frames_resident_in_hbm": True, "preroll_frames": preroll,
                        "first_timed_frame": first},
             "emulated_world": (args.emulate_world or None),
+            "ranks_seen": ranks_seen,          # sum over ranks of 1, by all-reduce (1 without a process group)
             "host_enqueue_ms_per_step": (float(np.mean(host_ms)) if host_ms else None),
             "pairs_per_frame": {"warmup": warm_pairs, "timed_min": min(timed_pairs), "timed_max": max(timed_pairs),
                                 "timed_mean": float(np.mean(timed_pairs)), "profile_pass_min": min(prof_pairs, default=None)},

@@ -195,16 +195,27 @@ int mftx_raft_arith(const mftx_raft *r);
  * and the stored pyramid, every iteration then runs lookup + convc1 as the one fused kernel above; the 324 features are
  * materialised on the last iteration only, for the occlusion / uncertainty heads (core/raft.py:199-206).  NULL: off. */
 int mftx_raft_set_lookup_fused(mftx_raft *r, const void *wfused);
+/* Debug payload of RAFT.forward(vis_debug=True) (core/raft.py:159-176, 255-257): trace = (iters + 1) x [P*h*w][2] floats
+ * (device, kept) receives coords1 as every iteration finds it and, last, as the final iteration leaves it; NULL: off.  The
+ * cost-volume pyramid of the same call stays in the workspace (mftx_raft_workspace_layout_for: lvl0..3). */
+int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
 /* Per-handle scheduling options (no global state; defaults are the measured best):
  *   MFTX_RAFT_OPT_FORK      -1 default (flow branch of the motion encoder on a side stream with the split arithmetic), 0 never, 1 always
  *   MFTX_RAFT_OPT_PRESPLIT   1 default (GEMM inputs kept in split form in the workspace), 0 fp32 activations split in registers
  *   MFTX_RAFT_OPT_GROUP      1 default (fp32 MFMA: lookup + convf1 and convc2 + convf2 as grouped launches), 0 one launch per layer
- *   MFTX_RAFT_OPT_FUSE_LOOKUP 1 default (use the fused lookup + convc1 kernel when its weights are set), 0 keep them apart */
+ *   MFTX_RAFT_OPT_FUSE_LOOKUP 1 default (use the fused lookup + convc1 kernel when its weights are set), 0 keep them apart
+ *   MFTX_RAFT_OPT_GRAPH      1 default (the launch sequence between the first and the last kernel of mftx_raft_refine -- it
+ *                            touches the workspace only -- is captured per (shape, workspace, stream) on its second use and
+ *                            replayed as a hipGraph from then on: same kernels, same bits, ~170 launches less host work),
+ *                            0 plain launches */
 #define MFTX_RAFT_OPT_FORK 0
 #define MFTX_RAFT_OPT_PRESPLIT 1
 #define MFTX_RAFT_OPT_GROUP 2
 #define MFTX_RAFT_OPT_FUSE_LOOKUP 3
+#define MFTX_RAFT_OPT_GRAPH 4
 int mftx_raft_set_option(mftx_raft *r, int option, int value);
+/* graphs captured / graph launches so far (tests, bench) */
+int mftx_raft_graph_stats(const mftx_raft *r, unsigned long long *captures, unsigned long long *replays);
 size_t mftx_raft_workspace_bytes_for(const mftx_raft *r, int P, int h, int w);
 /* Byte offsets (19 of them) of the workspace regions lvl0..3, coords1, corr,
  * cor1, corflo, flo1, hx, z, rh, fh, delta, mask, ouin, ouh, ou, flow_lr: after
@@ -242,6 +253,9 @@ int mftx_encoder_create(const float *const *weights, int n_weights, int instance
  * n conv weights, in the order of mftx_encoder_create's (weight, bias) pairs -> MFTX_ARITH_SPLIT; NULL -> fp32 MFMA.
  * The pointers are kept, not copied. */
 int mftx_encoder_set_split_weights(mftx_encoder *e, const void *const *split, int n);
+/* on (default 1): the layers between the pre-processing kernel and the head -- workspace only -- are replayed as a hipGraph
+ * per (image size, workspace, stream) from their third use on (as MFTX_RAFT_OPT_GRAPH); 0: plain launches. */
+int mftx_encoder_set_graph(mftx_encoder *e, int on);
 void mftx_encoder_destroy(mftx_encoder *e);
 size_t mftx_encoder_workspace_bytes(int H0, int W0);
 int mftx_encoder_forward(mftx_encoder *e, const uint8_t *img, int H0, int W0, float *out0, float *out1,

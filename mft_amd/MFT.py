@@ -37,6 +37,12 @@ def is_packed(r):
     return isinstance(r, torch.Tensor)
 
 
+def pack_planes(planes):
+    """(flow[2,H,W], occl[1,H,W], sigma[1,H,W]) -> packed [H, W, 4] (one strided copy)."""
+    f, o, s_ = planes
+    return torch.cat([f.reshape(2, *f.shape[-2:]), o.reshape(1, *o.shape[-2:]), s_.reshape(1, *s_.shape[-2:])], 0).permute(1, 2, 0).contiguous()
+
+
 def unpack_planes(r):
     """packed [H, W, 4] -> (flow[2,H,W], occl[1,H,W], sigma[1,H,W]) (contiguous copies)."""
     p = r.permute(2, 0, 1)
@@ -82,13 +88,15 @@ class MFT():
         self.flow_cache = flow_cache
         if hasattr(self.flower, "reset_cache"):
             self.flower.reset_cache()
+        # a private copy: the caller may recycle its buffer (a pinned staging ring, mft_amd/video.py: FrameRing), and the
+        # template stays in memory for the whole sequence when inf is among the deltas
+        self.template_img = img.copy() if hasattr(img, "copy") else img.clone()
         self.memory = {
             self.start_frame_i: {
-                'img': img,
+                'img': self.template_img,
                 'result': FlowOUTrackingResult.identity((self.img_H, self.img_W), device=self.device)
             }
         }
-        self.template_img = img.copy() if hasattr(img, "copy") else img.clone()
         self.last_pairs = []
         self.last_chosen = None
         self._window_ids = set()
@@ -157,7 +165,17 @@ class MFT():
         """Chain every candidate onto its stored (template -> left) result, pick the best per pixel
         (MFT/MFT.py:104-143), store the frame and clean the ring."""
         meta = SimpleNamespace()
+        # C.timers_enabled (MFT/MFT.py:73, 104-113, 143): the reference times the chains and the selection with CUDA events
+        # and logs them at DEBUG level; here both are ONE kernel, timed and logged as such
+        timed = bool(self.C.timers_enabled) and torch.cuda.is_available()
+        if timed:
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
         flow, occl, sigma, chosen = self.backend.chain_select(lefts, rights, self.C.occlusion_threshold)
+        if timed:
+            t1.record()
+            torch.cuda.synchronize()
+            logger.debug("chain + selection (%d candidates, one kernel): %.2fms", len(lefts), t0.elapsed_time(t1))
         # invalid flows are already marked occluded inside the selection kernel
         result = FlowOUTrackingResult(flow, occl, sigma, validate=False)
         self.current_frame_i = frame_i
@@ -203,7 +221,9 @@ class MFT():
             if got is None:
                 missing.append(i)
             else:
-                out[i] = got
+                # (a cache hit next to fresh packed results: packed once here, so that the selection stays on the packed
+                # kernel instead of unpacking every fresh candidate)
+                out[i] = pack_planes(got) if getattr(self.flower, "has_packed_output", False) else got
         if missing:
             to_cache = self.flow_cache is not None and any(plan[i][2] for i in missing)
             res = self._flows_for_pairs([(plan[i][1], self.memory[plan[i][1]]['img'], right_id, input_img)

@@ -53,6 +53,8 @@ SIGNATURES = {
     "mftx_raft_arith": (C.c_int, [C.c_void_p]),
     "mftx_raft_set_lookup_fused": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mftx_raft_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "mftx_raft_set_coords_trace": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mftx_raft_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "mftx_pack_lookup_convc1_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mftx_corr_lookup_convc1": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p, C.c_void_p,
                                                                             C.c_int, C.c_int, C.c_void_p]),
@@ -70,6 +72,7 @@ SIGNATURES = {
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
     "mftx_encoder_create": (C.c_int, [_PP, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mftx_encoder_destroy": (None, [C.c_void_p]),
+    "mftx_encoder_set_graph": (C.c_int, [C.c_void_p, C.c_int]),
     "mftx_encoder_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mftx_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -114,6 +114,9 @@ __device__ __forceinline__ void store_split4v(float *row, int c, float4 v) {
     *reinterpret_cast<uint2 *>(dst + 16) = make_uint2((a >> 16) | (b & 0xffff0000u), (cc >> 16) | (d & 0xffff0000u));
 }
 #endif
+// ReLU that keeps a NaN (fmaxf(NaN, 0) is 0): an operand outside the split arithmetic's fp16 range turns into NaN
+// products, and that NaN must reach the outputs instead of being clipped to a finite wrong value by the next activation
+__host__ __device__ inline float relu_keep_nan(float v) { return v < 0.f ? 0.f : v; }
 int launch_conv(const mftx_conv_desc &d, hipStream_t s, int tile = -1);      // tile >= 0: forced tile shape (mftx_conv2d_tile)
 int launch_conv_pair(const mftx_conv_desc &a, const mftx_conv_desc &b, hipStream_t s);   // two independent ReLU convs, one launch
 // conv whose epilogue is a GRU gate (see conv_gemm.hip)

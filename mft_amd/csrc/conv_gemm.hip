@@ -206,7 +206,7 @@ __device__ __forceinline__ float gru_blend(float z, float h, float q) { return _
 
 __device__ __forceinline__ float act_fn(float v, int act) {
     switch (act) {
-        case 1: return fmaxf(v, 0.f);
+        case 1: return relu_keep_nan(v);
         case 2: return 1.f / (1.f + expf(-v));
         case 3: return tanhf(v);
         default: return v;
@@ -1152,7 +1152,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                             float sv = v[t][e] + bias4[e];
                             if (ADD && p.residual_mode == 0) sv += L.add[t][e];
                             if constexpr (EPI == EPI_RELU) {
-                                o[e] = fmaxf(sv, 0.f) * p.out_scale;
+                                o[e] = relu_keep_nan(sv) * p.out_scale;
                             } else if constexpr (EPI == EPI_GRU_ZR) {
                                 const float g = fast_sigmoid(sv);
                                 o[e] = nb < 128 ? g : g * L.a1[t][e];
@@ -1160,7 +1160,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                                 o[e] = gru_blend(L.a0[t][e], L.a1[t][e], fast_tanh(sv));
                             } else {
                                 float g = act_fn(sv, p.act) * p.out_scale;
-                                if (ADD && p.residual_mode == 1) g = fmaxf(g + L.add[t][e], 0.f);
+                                if (ADD && p.residual_mode == 1) g = relu_keep_nan(g + L.add[t][e]);
                                 o[e] = g;
                             }
                         }
@@ -1266,7 +1266,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                     float sv = v[t][e] + bias4[e];
                     if (pre_add) sv += L.add[t][e];
                     if constexpr (EPI == EPI_RELU) {
-                        o[e] = fmaxf(sv, 0.f) * p.out_scale;
+                        o[e] = relu_keep_nan(sv) * p.out_scale;
                     } else if constexpr (EPI == EPI_GRU_ZR) {   // [z | r] gates; r is folded into r*h
                         const float g = fast_sigmoid(sv);
                         o[e] = nb < 128 ? g : g * L.a1[t][e];
@@ -1274,7 +1274,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                         o[e] = gru_blend(L.a0[t][e], L.a1[t][e], fast_tanh(sv));
                     } else {
                         float g = act_fn(sv, p.act) * p.out_scale;
-                        if (p.residual_mode == 1) g = fmaxf(g + L.add[t][e], 0.f);
+                        if (p.residual_mode == 1) g = relu_keep_nan(g + L.add[t][e]);
                         o[e] = g;
                     }
                 }
@@ -1346,7 +1346,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                 float s = acc[i][j][r] + bias;
                 if (pre_add) s += add[r];
                 if constexpr (EPI == EPI_RELU) {
-                    out[m * p.ldo + n] = fmaxf(s, 0.f) * p.out_scale;
+                    out[m * p.ldo + n] = relu_keep_nan(s) * p.out_scale;
                 } else if constexpr (EPI == EPI_GRU_ZR) {   // [z | r] gates; r is folded into r*h
                     const float v = fast_sigmoid(s);
                     if (n < 128) p.z[m * 128 + n] = v;
@@ -1356,7 +1356,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
                     p.hx[m * p.ld_hx + n] = gru_blend(aux0[r], aux1[r], v);
                 } else {
                     float v = act_fn(s, p.act) * p.out_scale;
-                    if (p.residual_mode == 1) v = fmaxf(v + add[r], 0.f);
+                    if (p.residual_mode == 1) v = relu_keep_nan(v + add[r]);
                     out[m * p.ldo + n] = v;
                 }
             }

@@ -13,6 +13,7 @@
 // layer is a single GEMM launch with a fused ReLU or residual epilogue.
 #include "common.h"
 #include "profile.h"
+#include "graph_cache.h"
 #include <new>
 
 namespace mftx {
@@ -136,8 +137,8 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(float *__restrict__
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float t = (o[k] - mean_s[c + k]) * rstd_s[c + k];
-            if (mode != 2) t = fmaxf(t, 0.f);
-            if (mode == 1) t = fmaxf(rr[k] + t, 0.f);
+            if (mode != 2) t = relu_keep_nan(t);
+            if (mode == 1) t = relu_keep_nan(rr[k] + t);
             o[k] = t;
         }
         reinterpret_cast<float4 *>(x)[i] = make_float4(o[0], o[1], o[2], o[3]);
@@ -188,6 +189,8 @@ struct mftx_encoder {
     const float *w[EC_COUNT], *b[EC_COUNT];
     const float *wg[EC_COUNT];  // what the conv GEMMs stream: w, or its split form (arith = MFTX_ARITH_SPLIT)
     int arith;
+    int use_graph;              // replay the layers between the pre-processing kernel and the head as a hipGraph (graph_cache.h)
+    GraphCache *graphs;
 };
 static constexpr uint32_t ENC_MAGIC = 0x454e4358;
 
@@ -204,11 +207,14 @@ extern "C" int mftx_encoder_create(const float *const *weights, int n_weights, i
     for (int i = 0; i < EC_COUNT; ++i) { e->w[i] = e->wg[i] = nullptr; e->b[i] = nullptr; }
     for (int i = 0; i < n_conv; ++i) { e->w[i] = e->wg[i] = weights[2 * i]; e->b[i] = weights[2 * i + 1]; }
     e->arith = MFTX_ARITH_F32;
+    e->use_graph = 1;
+    e->graphs = new (std::nothrow) GraphCache;
     *out = e;
     return 0;
 }
 
 extern "C" int mftx_encoder_set_split_weights(mftx_encoder *e, const void *const *split, int n) {
+    if (e && e->magic == ENC_MAGIC && e->graphs) e->graphs->clear();
     if (!e || e->magic != ENC_MAGIC) return fail(MFTX_E_STATE, "encoder_set_split_weights: bad handle");
     const int n_conv = e->instance_norm ? EC_COUNT - 1 : EC_COUNT;
     if (!split) {                                    // back to fp32 MFMA
@@ -225,7 +231,13 @@ extern "C" int mftx_encoder_set_split_weights(mftx_encoder *e, const void *const
 }
 
 extern "C" void mftx_encoder_destroy(mftx_encoder *e) {
-    if (e && e->magic == ENC_MAGIC) { e->magic = 0; delete e; }
+    if (e && e->magic == ENC_MAGIC) { e->magic = 0; delete e->graphs; delete e; }
+}
+
+extern "C" int mftx_encoder_set_graph(mftx_encoder *e, int on) {
+    if (!e || e->magic != ENC_MAGIC) return fail(MFTX_E_STATE, "encoder_set_graph: bad handle");
+    e->use_graph = on ? 1 : 0;
+    return 0;
 }
 
 extern "C" size_t mftx_encoder_workspace_bytes(int H0, int W0) {
@@ -313,12 +325,24 @@ extern "C" int mftx_encoder_forward(mftx_encoder *e, const uint8_t *img, int H0,
     const int Hp = H0 + ph, Wp = W0 + pw, pl = pw / 2, pt = ph / 2;
     Enc E{e, enc_carve(workspace, Hp, Wp), (hipStream_t)stream};
     if (E.ws.bytes > workspace_bytes) return fail(MFTX_E_WORKSPACE, "encoder_forward: workspace %zu < %zu", workspace_bytes, E.ws.bytes);
+    const bool graphs_on = e->graphs && e->use_graph && !prof_enabled();
+    bool proxied = false;
+    if (graphs_on && E.s == nullptr) {               // the legacy stream (PyTorch's default) cannot be captured: graph_cache.h
+        hipStream_t own = e->graphs->proxy.enter(nullptr);
+        if (own) { E.s = own; proxied = true; }
+    }
+    struct Leave { GraphCache *g; bool on; ~Leave() { if (on) g->proxy.leave(nullptr); } } leave{e->graphs, proxied};
     hipStream_t s = E.s;
     {
         ProfScope prof(PC_GLUE, s, 0);
         hipLaunchKernelGGL(enc_prep_kernel, dim3(cdiv(Wp + 6, 256), Hp), dim3(256), 0, s, img, H0, W0, pl, pt, Hp, Wp, E.ws.img);
     }
     TRY(check_launch("enc_prep"));
+    // From the stem to the last residual block the layers touch the workspace only: one hipGraph per (size, workspace,
+    // stream), see graph_cache.h; the pre-processing kernel (reads the caller's image) and the head (writes the caller's
+    // maps) are launched plainly around it.
+    const int h3 = Hp / 8, w3 = Wp / 8;
+    auto body = [&]() -> int {
     // stem: 7 taps (rows) x 28-float windows starting at padded column 2x: kh = 7, kw = 1, no x padding
     const int h1 = Hp / 2, w1 = Wp / 2;
     {
@@ -340,10 +364,18 @@ extern "C" int mftx_encoder_forward(mftx_encoder *e, const uint8_t *img, int H0,
     TRY(E.block(EC_L2B0C1, EC_L2B0C2, EC_L2B0DS, E.ws.a, 64, h1, w1, E.ws.b, sc2, E.ws.c, 96, h2, w2, 2));
     TRY(E.block(EC_L2B1C1, EC_L2B1C2, -1, E.ws.c, 96, h2, w2, E.ws.b, nullptr, E.ws.a, 96, h2, w2, 1));
     // stage 3 (128, stride 2)
-    const int h3 = h2 / 2, w3 = w2 / 2;
     float *sc3 = E.ws.b + (size_t)h3 * w3 * 128;
     TRY(E.block(EC_L3B0C1, EC_L3B0C2, EC_L3B0DS, E.ws.a, 96, h2, w2, E.ws.b, sc3, E.ws.c, 128, h3, w3, 2));
-    TRY(E.block(EC_L3B1C1, EC_L3B1C2, -1, E.ws.c, 128, h3, w3, E.ws.b, nullptr, E.ws.a, 128, h3, w3, 1));
+    return E.block(EC_L3B1C1, EC_L3B1C2, -1, E.ws.c, 128, h3, w3, E.ws.b, nullptr, E.ws.a, 128, h3, w3, 1);
+    };   // body
+    if (graphs_on) {
+        GraphKey key{};
+        key.v[0] = (uintptr_t)H0; key.v[1] = (uintptr_t)W0; key.v[2] = reinterpret_cast<uintptr_t>(workspace);
+        key.v[3] = reinterpret_cast<uintptr_t>(s); key.v[4] = (uintptr_t)e->arith;
+        TRY(e->graphs->run(key, s, body));
+    } else {
+        TRY(body());
+    }
     // head
     if (e->instance_norm) return E.conv(EC_HEAD, E.ws.a, 128, 128, h3, w3, out0, 256, 256, h3, w3, 1, 1, 0);
     TRY(E.conv(EC_HEAD, E.ws.a, 128, 128, h3, w3, out0, 128, 128, h3, w3, 1, 1, 3));   // net = tanh(first 128)

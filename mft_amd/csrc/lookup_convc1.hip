@@ -37,14 +37,29 @@ constexpr int LF_GROUPS = 24;                       // 16-wide k groups: 4 level
 constexpr int LF_AROW = 400;                        // bytes per A row of a unit: 96 x 4 + 16 (rows r, r + 1 start 25 sixteen-byte slots apart: conflict-free ds_read_b128)
 constexpr int LF_AUNIT = 64 * LF_AROW;              // 25 600
 constexpr int LF_PATCH = 432;                       // bytes per window patch: 100 taps + 8 pad floats (finite: the dummy samples read them)
-constexpr int LF_NP = 3;                            // units of gathers in flight per producer wave
+constexpr int LF_NP = 3;                            // patch ring (units) per producer wave
+#ifndef MFTX_LF_LA
+#define MFTX_LF_LA 2
+#endif
+constexpr int LF_LA = MFTX_LF_LA;                            // a unit's gather is issued LF_LA + 1 steps before its conversion (<= LF_NP - 1)
 constexpr int LF_CPP = 16;                          // cells per producer wave and unit (at most)
 constexpr unsigned LF_WBYTES = LF_GROUPS * 4 * 4 * 1024;     // fused weights: [group][wave][fragment][lane] x 16 bytes
 constexpr unsigned LF_OOB = 0x80000000u;
 constexpr int LF_OFF_PATCH = 2 * LF_AUNIT;                                   // 51 200
 constexpr int LF_OFF_STAGE = LF_OFF_PATCH + 4 * LF_NP * LF_CPP * LF_PATCH;   // + 82 944
 constexpr int LF_OFF_COORD = LF_OFF_STAGE + 4 * 4096;                        // + 16 384
-constexpr int LF_LDS = LF_OFF_COORD + 4 * 3 * 128;                           // 152 064 bytes
+constexpr int LF_OFF_TAB = LF_OFF_COORD + 4 * 3 * 128;                       // + 1 536
+constexpr int LF_LDS = LF_OFF_TAB + 4 * LF_CPP * 32 * 4;                     // + 8 192 = 160 256 bytes
+
+// Tuning builds only (-DMFTX_LF_TRACE): s_memtime stamps of workgroup 0's waves at the pipeline's events, read back with
+// mftx_debug_lf_trace (tools/lf_trace.py): [wave][event] = (code << 56) | ticks
+#ifdef MFTX_LF_TRACE
+__device__ unsigned long long lf_trace_buf[8][128];
+#define LF_T(code) do { if (blockIdx.x == 0 && tcount < 128) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                        if ((threadIdx.x & 63) == 0) lf_trace_buf[threadIdx.x >> 6][tcount] = ((unsigned long long)(code) << 56) | (t_ & 0x00ffffffffffffffull); ++tcount; } } while (0)
+#else
+#define LF_T(code) do { } while (0)
+#endif
 
 struct LookupConvArgs {
     const float *lvl[4];
@@ -59,6 +74,7 @@ struct LookupConvArgs {
     int ld_out, out_split;
     int rpw;                    // cells per producer wave and tile: a tile is 4 rpw cells
     int n_tiles;
+    int ablate;                 // tuning builds only (MFTX_LF_ABLATE): 1 no window gathers, 2 no MFMAs, 4 no conversion, 8 no weight loads, 16 no stores
 };
 
 __device__ __forceinline__ void lf_barrier() {
@@ -67,15 +83,14 @@ __device__ __forceinline__ void lf_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate).  Waiting for a smaller count than
+// necessary is always safe, so n is rounded DOWN to a multiple of 8 (a gather is 8, 16, 24 or 32 operations: the exact
+// counts are the ones that matter) -- nine cases instead of 64
 #define LF_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
 __device__ __forceinline__ void lf_wait_vmcnt(int n) {
-    switch (n < 63 ? n : 63) {
-        LF_W(0) LF_W(1) LF_W(2) LF_W(3) LF_W(4) LF_W(5) LF_W(6) LF_W(7) LF_W(8) LF_W(9) LF_W(10) LF_W(11) LF_W(12) LF_W(13) LF_W(14) LF_W(15)
-        LF_W(16) LF_W(17) LF_W(18) LF_W(19) LF_W(20) LF_W(21) LF_W(22) LF_W(23) LF_W(24) LF_W(25) LF_W(26) LF_W(27) LF_W(28) LF_W(29) LF_W(30) LF_W(31)
-        LF_W(32) LF_W(33) LF_W(34) LF_W(35) LF_W(36) LF_W(37) LF_W(38) LF_W(39) LF_W(40) LF_W(41) LF_W(42) LF_W(43) LF_W(44) LF_W(45) LF_W(46) LF_W(47)
-        LF_W(48) LF_W(49) LF_W(50) LF_W(51) LF_W(52) LF_W(53) LF_W(54) LF_W(55) LF_W(56) LF_W(57) LF_W(58) LF_W(59) LF_W(60) LF_W(61) LF_W(62)
-        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    switch (n < 63 ? (n & ~7) : 56) {
+        LF_W(0) LF_W(8) LF_W(16) LF_W(24) LF_W(32) LF_W(40) LF_W(48)
+        default: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
     }
 }
 #undef LF_W
@@ -107,11 +122,16 @@ struct LfProducer {
     int c16, q, trA, tcA, trB, tcB;
     unsigned char *patches;
     float *cslots;
+    unsigned *tab;               // row / column offsets of the windows being gathered: [cell][row 0..15 | column 0..15]
 
     __device__ __forceinline__ int tile_of(int k) const { return (int)blockIdx.x + k * (int)gridDim.x; }
 
     // VMEM operations of unit v's gather, and of the coordinate prefetch that follows a level-0 unit
-    __device__ __forceinline__ int n_gather(int v) const { return v < U ? 2 * rpw : 0; }
+#ifdef MFTX_TUNING
+    __device__ __forceinline__ int n_gather(int v) const { return (v < U && !(p.ablate & 1)) ? 2 * ((rpw + 3) & ~3) : 0; }
+#else
+    __device__ __forceinline__ int n_gather(int v) const { return v < U ? 2 * ((rpw + 3) & ~3) : 0; }
+#endif
     __device__ __forceinline__ int n_coord(int v) const { return (v < U && (v & 3) == 0 && (v >> 2) + 1 < my_tiles) ? 1 : 0; }
 
     // coordinates of tile k's cells of this wave -> slot k % 3 (32 dwords: 16 cells x (x, y))
@@ -131,42 +151,74 @@ struct LfProducer {
         sy = c.y * inv;
     }
 
-    // gather of unit v: two DMA instructions per cell (taps 0..63, 64..99) into patch slot v % 3
+    // gather of unit v: two DMA instructions per cell (taps 0..63, 64..99) into patch slot v % 3.
+    //   The VALU pipe of a SIMD is all a producer wave has (one instruction per four cycles), so the address arithmetic is
+    // done ONCE per row and column of a window instead of once per tap: phase 1 forms, two cells per pass -- lane =
+    // (cell & 1, row | column, j) --, the byte offset of window row j (or column j) inside the query's level slice, or a
+    // large value where the row / column lies outside the level (any sum with it is out of range = a zero, as
+    // grid_sample pads), into a small LDS table; phase 2 adds one row and one column entry per tap.
     __device__ __forceinline__ void gather(int v) {
         const int k = v >> 2, l = v & 3;
-        float sx, sy;
-        level_coords(v, sx, sy);
-        // clamp so that the int conversion is defined for wild coordinates
-        const int x0v = (int)fminf(fmaxf(floorf(sx), -1.0e6f), 1.0e6f) - 4;
-        const int y0v = (int)fminf(fmaxf(floorf(sy), -1.0e6f), 1.0e6f) - 4;
+        const float inv = l == 0 ? 1.f : l == 1 ? 0.5f : l == 2 ? 0.25f : 0.125f;     // (x / 2^l, exactly)
         const float *base = l == 0 ? p.lvl[0] : l == 1 ? p.lvl[1] : l == 2 ? p.lvl[2] : p.lvl[3];
         const long long stride = l == 0 ? p.stride[0] : l == 1 ? p.stride[1] : l == 2 ? p.stride[2] : p.stride[3];
         const unsigned H = (unsigned)(l == 0 ? p.hl[0] : l == 1 ? p.hl[1] : l == 2 ? p.hl[2] : p.hl[3]);
         const unsigned W = (unsigned)(l == 0 ? p.wl[0] : l == 1 ? p.wl[1] : l == 2 ? p.wl[2] : p.wl[3]);
         const unsigned wb = (unsigned)(l == 0 ? p.wb0 : p.wb1);
         const bool blocked = l < 2;
-        unsigned char *pdst = patches + (v % 3) * (LF_CPP * LF_PATCH);
         const int cell0 = tile_of(k) * TR + pw * rpw;
-        for (int i = 0; i < rpw; ++i) {
-            const int x0 = __builtin_amdgcn_readlane(x0v, i), y0 = __builtin_amdgcn_readlane(y0v, i);
-            // (provably wave-uniform: the buffer descriptor must live in SGPRs, or every DMA becomes a waterfall loop)
-            const int cell = __builtin_amdgcn_readfirstlane(cell0 + i);
-            const bool cv = cell < p.cells;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float *>(base + (long long)(cv ? cell : 0) * stride), 0, (unsigned)stride * 4u, 0x00020000);
-            unsigned offA, offB;
-            {   // unsigned compares fold the lower bounds in
-                const unsigned yy = (unsigned)(y0 + trA), xx = (unsigned)(x0 + tcA);
-                const unsigned o = blocked ? (((yy >> 2) * wb + (xx >> 3)) * 32u + (yy & 3u) * 8u + (xx & 7u)) : yy * W + xx;
-                offA = (cv & (yy < H) & (xx < W)) ? o * 4u : LF_OOB;
+        const float2 *cs = reinterpret_cast<const float2 *>(cslots + (k % 3) * 32);
+        {
+            const int kind = (lane >> 4) & 1, j = lane & 15;
+            const unsigned lim = kind ? W : H;
+            const unsigned rowmul = blocked ? wb * 128u : W * 4u;
+            const unsigned stride4 = (unsigned)stride * 4u;
+            for (int pass = 0; 2 * pass < ((rpw + 3) & ~3); ++pass) {
+                const int ci = 2 * pass + (lane >> 5);
+                const float2 c = cs[ci];
+                const float sv = (kind ? c.x : c.y) * inv;
+                // clamp so that the int conversion is defined for wild coordinates
+                const unsigned vv = (unsigned)((int)fminf(fmaxf(floorf(sv), -1.0e6f), 1.0e6f) - 4 + j);
+                unsigned val;
+                if (blocked) val = kind ? (vv >> 3) * 128u + (vv & 7u) * 4u : (vv >> 2) * rowmul + (vv & 3u) * 32u;
+                else val = kind ? vv * 4u : vv * rowmul;
+                if (!kind) val += (unsigned)ci * stride4;        // this cell's slice inside the unit's buffer
+                const bool ok = (ci < rpw) & (cell0 + ci < p.cells) & (j < 10) & (vv < lim);
+                tab[pass * 64 + lane] = ok ? val : 0x40000000u;
             }
-            {
-                const unsigned yy = (unsigned)(y0 + trB), xx = (unsigned)(x0 + tcB);
-                const unsigned o = blocked ? (((yy >> 2) * wb + (xx >> 3)) * 32u + (yy & 3u) * 8u + (xx & 7u)) : yy * W + xx;
-                offB = (cv & (yy < H) & (xx < W)) ? o * 4u : LF_OOB;
+        }
+        unsigned char *pdst = patches + (v % 3) * (LF_CPP * LF_PATCH);
+        // ONE buffer descriptor per unit: this wave's cells are consecutive, their level slices lie `stride` floats apart --
+        // phase 1 has folded cell * stride into the row entries, so a tap's offset is still one addition
+        const int c0 = __builtin_amdgcn_readfirstlane(cell0 < p.cells ? cell0 : 0);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(base + (long long)c0 * stride), 0, (unsigned)rpw * (unsigned)stride * 4u, 0x00020000);
+#ifdef MFTX_TUNING
+        if (p.ablate & 1) { if (n_coord(v)) coords_issue(k + 1); return; }
+#endif
+        // taps 0..63 of every cell, then (lanes 0..35 only: a DMA stores for every enabled lane) taps 64..99; four cells at a
+        // time -- their table entries are read together, so the LDS latency shows once per four DMAs (cells past rpw in the
+        // last group carry out-of-range entries: zeros into patches nobody reads)
+        const int ng = (rpw + 3) & ~3;
+        {
+            const unsigned *tr_ = tab + trA, *tc_ = tab + 16 + tcA;
+            for (int i = 0; i < ng; i += 4) {
+                unsigned o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = tr_[(i + e) * 32] + tc_[(i + e) * 32];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lf_dma4(rs, pdst + (i + e) * LF_PATCH, o[e]);
             }
-            lf_dma4(rs, pdst + i * LF_PATCH, offA);
-            if (lane < 36) lf_dma4(rs, pdst + i * LF_PATCH + 256, offB);
+        }
+        if (lane < 36) {
+            const unsigned *tr_ = tab + trB, *tc_ = tab + 16 + tcB;
+            for (int i = 0; i < ng; i += 4) {
+                unsigned o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = tr_[(i + e) * 32] + tc_[(i + e) * 32];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lf_dma4(rs, pdst + (i + e) * LF_PATCH + 256, o[e]);
+            }
         }
         if (n_coord(v)) coords_issue(k + 1);
     }
@@ -174,6 +226,9 @@ struct LfProducer {
     // conversion of unit v: lane (cell c16, quarter q) blends samples k'' = 24 q .. 24 q + 23 of its cell and stores
     // their halves into the A slot v & 1
     __device__ __forceinline__ void convert(int v) {
+#ifdef MFTX_TUNING
+        if (p.ablate & 4) return;
+#endif
         float sx, sy;
         level_coords(v, sx, sy);
         const float fx = sx - floorf(sx), fy = sy - floorf(sy);
@@ -206,12 +261,17 @@ struct LfProducer {
     }
 
     // operations issued after unit v's gather at the moment unit v is converted: the coordinate prefetch behind it
-    // and the gathers of units v + 1, v + 2 with theirs (unit v + 3 follows the conversion)
+    // and the gathers of units v + 1 .. v + LF_LA with theirs (unit v + LF_LA + 1 follows the conversion)
     __device__ __forceinline__ int younger(int v) const {
-        return n_coord(v) + n_gather(v + 1) + n_coord(v + 1) + n_gather(v + 2) + n_coord(v + 2);
+        int n = n_coord(v);
+#pragma unroll
+        for (int a = 1; a <= LF_LA; ++a) n += n_gather(v + a) + n_coord(v + a);
+        return n;
     }
 
     __device__ __forceinline__ void run() {
+        int tcount = 0; (void)tcount;
+        LF_T(1);
         // pad floats of my patches: finite for ever (no DMA reaches them)
         if (lane < LF_NP * LF_CPP) {
             lf_f32x4 *pad = reinterpret_cast<lf_f32x4 *>(patches + lane * LF_PATCH + 400);
@@ -220,22 +280,30 @@ struct LfProducer {
         }
         coords_issue(0);
         lf_wait_vmcnt(0);
-        gather(0);
-        if (1 < U) gather(1);
-        if (2 < U) gather(2);
+        LF_T(2);
+        for (int a = 0; a <= LF_LA; ++a)
+            if (a < U) { gather(a); LF_T(3); }
         lf_wait_vmcnt(younger(0));
+        LF_T(4);
         convert(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (3 < U) gather(3);
+        LF_T(5);
+        if (LF_LA + 1 < U) gather(LF_LA + 1);
+        LF_T(3);
         for (int u = 0; u < U; ++u) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            LF_T(6);
             lf_barrier();                    // unit u is complete in its slot; the consumers are done with unit u - 1
+            LF_T(7);
             if (u + 1 < U) {
                 lf_wait_vmcnt(younger(u + 1));
+                LF_T(4);
                 convert(u + 1);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the conversion's patch reads are complete)
-            if (u + 4 < U) gather(u + 4);    // into the patch slot unit u + 1 has just left
+            LF_T(5);
+            if (u + LF_LA + 2 < U) gather(u + LF_LA + 2);    // (LF_LA = 2: into the patch slot unit u + 1 has just left)
+            LF_T(3);
         }
     }
 };
@@ -251,6 +319,9 @@ __device__ __forceinline__ void lf_consumer(const LookupConvArgs &p, unsigned ch
     const unsigned w_lane = (unsigned)(j * 4096 + lane * 16);          // + 16384 group + 1024 fragment
     lf_f16x8 wq[3][4];                    // weight fragments of three k groups: [jt = 0 hi, lo | jt = 1 hi, lo]
     auto wload = [&](int wg, lf_f16x8 (&d)[4]) {
+#ifdef MFTX_TUNING
+        if (p.ablate & 8) return;
+#endif
 #pragma unroll
         for (int x = 0; x < 4; ++x)
             d[x] = __builtin_bit_cast(lf_f16x8, __builtin_amdgcn_raw_buffer_load_b128(rW, (unsigned)wg * 16384u + (unsigned)x * 1024u + w_lane, 0, 0));
@@ -272,9 +343,13 @@ __device__ __forceinline__ void lf_consumer(const LookupConvArgs &p, unsigned ch
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[it][jt][r] = 0.f; accx[it][jt][r] = 0.f; }
 
+    int tcount = 0; (void)tcount;
+    LF_T(1);
     for (int u = 0; u < U; ++u) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        LF_T(6);
         lf_barrier();
+        LF_T(7);
         const unsigned char *A = a_lane + (u & 1) * LF_AUNIT;
         lf_f16x8 ah[2][2], al[2][2];      // [register set][row tile]
         auto read_a = [&](int g, int set) {
@@ -291,6 +366,10 @@ __device__ __forceinline__ void lf_consumer(const LookupConvArgs &p, unsigned ch
             if (g < 5) read_a(g + 1, set ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             lf_f16x8 (&w)[4] = wq[g % 3];
+#ifdef MFTX_TUNING
+            if (!(p.ablate & 2))
+#endif
+            {
             // product by product: consecutive MFMAs never wait for each other's accumulator
 #pragma unroll
             for (int it = 0; it < 2; ++it)
@@ -304,11 +383,13 @@ __device__ __forceinline__ void lf_consumer(const LookupConvArgs &p, unsigned ch
             for (int it = 0; it < 2; ++it)
 #pragma unroll
                 for (int jt = 0; jt < 2; ++jt) accx[it][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set][it], w[2 * jt], accx[it][jt], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             wload(wg_next, wq[g % 3]);          // three k groups ahead of its use
             wg_next = wg_next == LF_GROUPS - 1 ? 0 : wg_next + 1;
             __builtin_amdgcn_sched_barrier(0);
         }
+        LF_T(8);
         if ((u & 3) != 3) continue;
         // ---- the tile is complete: out = relu(acc + accx / 2048 + bias), through 4 KiB of the wave's own LDS so that a
         // lane holds 4 consecutive channels of a row (16-byte accesses; conv_gemm.hip's vectorised epilogue)
@@ -332,10 +413,14 @@ __device__ __forceinline__ void lf_consumer(const LookupConvArgs &p, unsigned ch
                 for (int t = 0; t < 4; ++t) {
                     const int row = 32 * it + 8 * t + (lane >> 3);
                     const long long m = m_base + row;
+#ifdef MFTX_TUNING
+                    const bool ok = row < TR && m < p.cells && !(p.ablate & 16);
+#else
                     const bool ok = row < TR && m < p.cells;
+#endif
                     lf_f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = fmaxf(v[t][e] + bias4[jt][e], 0.f);
+                    for (int e = 0; e < 4; ++e) o[e] = relu_keep_nan(v[t][e] + bias4[jt][e]);
                     if constexpr (OS) {
                         unsigned h0, h1, l0, l1;
                         const float k2048 = 2048.f;
@@ -349,6 +434,7 @@ __device__ __forceinline__ void lf_consumer(const LookupConvArgs &p, unsigned ch
                     }
                 }
             }
+        LF_T(9);
     }
 }
 
@@ -365,7 +451,8 @@ __global__ __launch_bounds__(512, 2) void lookup_convc1_kernel(LookupConvArgs p)
         LfProducer P{p, lf_lds, pw, lane, p.rpw, TR, my_tiles, U,
                      lane & 15, lane >> 4, lane / 10, lane % 10, (lane + 64) / 10, (lane + 64) % 10,
                      lf_lds + LF_OFF_PATCH + pw * (LF_NP * LF_CPP * LF_PATCH),
-                     reinterpret_cast<float *>(lf_lds + LF_OFF_COORD + pw * (3 * 128))};
+                     reinterpret_cast<float *>(lf_lds + LF_OFF_COORD + pw * (3 * 128)),
+                     reinterpret_cast<unsigned *>(lf_lds + LF_OFF_TAB + pw * (LF_CPP * 32 * 4))};
         P.run();
     } else {
         lf_consumer<OS>(p, lf_lds, wid, lane, U, TR);
@@ -395,6 +482,14 @@ __global__ void pack_lookup_convc1_kernel(const float *__restrict__ w, int ld_w,
     __builtin_memcpy(&r, o, 16);
     out[d] = r;
 }
+
+#ifdef MFTX_LF_TRACE
+extern "C" int mftx_debug_lf_trace(unsigned long long *out) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lf_trace_buf), sizeof(unsigned long long) * 8 * 128) != hipSuccess) return -1;
+    unsigned long long z[8 * 128] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(lf_trace_buf), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
 
 static int lf_num_cus() {
     static const int n = [] {
@@ -434,6 +529,8 @@ int launch_lookup_convc1(const float *const lvl[4], const float *coords, int P, 
     const int tr0 = cdiv(a.cells, (int)(rounds * cus));
     a.rpw = cdiv(tr0, 4) < 1 ? 1 : cdiv(tr0, 4) > LF_CPP ? LF_CPP : cdiv(tr0, 4);
     a.n_tiles = cdiv(a.cells, 4 * a.rpw);
+    static const int ablate = tune_env("MFTX_LF_ABLATE", 0);
+    a.ablate = ablate;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(lookup_convc1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LF_LDS);

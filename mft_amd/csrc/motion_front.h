@@ -257,10 +257,10 @@ __device__ __forceinline__ void convf1_strip(const ConvF1Args &q, int strip_id, 
         const bool st = x < w && live;                       // (uniform per block)
         const long long cell = st ? img_base + (long long)y * w + x : 0;
         if (q.out_split) {                                   // every lane takes part in the pair exchange
-            store_split_pairwise(flo1 + cell * 128, co, fmaxf(acc[t], 0.f), st);
+            store_split_pairwise(flo1 + cell * 128, co, relu_keep_nan(acc[t]), st);
             store_split_pairwise(hx + cell * 384, 382 + (co & 1), patch[3][2 * (t + 3) + (co & 1)], st && co < 2);
         } else if (st) {
-            flo1[cell * 128 + co] = fmaxf(acc[t], 0.f);
+            flo1[cell * 128 + co] = relu_keep_nan(acc[t]);
             if (co < 2) hx[cell * 384 + 382 + co] = patch[3][2 * (t + 3) + co];
         }
     }

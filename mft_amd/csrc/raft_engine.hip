@@ -5,6 +5,7 @@
 #include "common.h"
 #include "profile.h"
 #include "motion_front.h"
+#include "graph_cache.h"
 #include <cstdlib>
 #include <new>
 
@@ -178,8 +179,10 @@ struct mftx_raft {
     // the motion encoder's flow branch (convf1 -> convf2) runs on a stream of its own, beside lookup -> convc1 -> convc2
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
+    float *coords_trace;           // debug payload (mftx_raft_set_coords_trace): coords1 before every iteration and after the last, or null
+    GraphCache *graphs;            // the refinement's launch sequence between its first and last kernels, captured per (shape, workspace, mode)
     const void *wfused;            // convc1's weights for the fused lookup + convc1 kernel (csrc/lookup_convc1.hip), or null
-    int opt[4];                    // MFTX_RAFT_OPT_*
+    int opt[5];                    // MFTX_RAFT_OPT_*
 };
 // weights that go through the conv GEMM (the others feed VALU kernels and stay fp32)
 static constexpr int GEMM_SLOTS[] = {W_CONVC1, W_CONVC2, W_CONVF2, W_CONV, W_ZR1_DYN, W_ZR1_INP, W_Q1_DYN, W_Q1_INP,
@@ -200,7 +203,9 @@ extern "C" int mftx_raft_create(const float *const *weights, int n_weights, mftx
     r->arith = MFTX_ARITH_F32;
     r->side = nullptr; r->ev_fork = nullptr; r->ev_join = nullptr;
     r->wfused = nullptr;
-    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1;
+    r->coords_trace = nullptr;
+    r->graphs = new (std::nothrow) GraphCache;
+    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1;
     for (int i = 0; i < W_COUNT; ++i) r->w[i] = r->wg[i] = weights[i];
     *out = r;
     return 0;
@@ -212,6 +217,7 @@ extern "C" void mftx_raft_destroy(mftx_raft *r) {
         if (r->ev_fork) (void)hipEventDestroy(r->ev_fork);
         if (r->ev_join) (void)hipEventDestroy(r->ev_join);
         if (r->side) (void)hipStreamDestroy(r->side);
+        delete r->graphs;
         delete r;
     }
 }
@@ -234,11 +240,13 @@ extern "C" size_t mftx_raft_workspace_bytes(int P, int h, int w) {
 extern "C" int mftx_raft_set_ondemand(mftx_raft *r, int on) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_ondemand: bad handle");
     r->ondemand = on ? 1 : 0;
+    if (r->graphs) r->graphs->clear();
     return 0;
 }
 
 extern "C" int mftx_raft_set_split_weights(mftx_raft *r, const void *const *split, int n) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_split_weights: bad handle");
+    if (r->graphs) r->graphs->clear();
     if (!split) {                                    // back to fp32 MFMA
         for (int i = 0; i < W_COUNT; ++i) r->wg[i] = r->w[i];
         r->arith = MFTX_ARITH_F32;
@@ -258,13 +266,21 @@ extern "C" int mftx_raft_set_lookup_fused(mftx_raft *r, const void *wfused) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_lookup_fused: bad handle");
     if (wfused && !aligned16(wfused)) return fail(MFTX_E_ALIGN, "raft_set_lookup_fused: weights not 16-byte aligned");
     r->wfused = wfused;
+    if (r->graphs) r->graphs->clear();
+    return 0;
+}
+
+extern "C" int mftx_raft_set_coords_trace(mftx_raft *r, float *trace) {
+    if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_coords_trace: bad handle");
+    r->coords_trace = trace;
     return 0;
 }
 
 extern "C" int mftx_raft_set_option(mftx_raft *r, int option, int value) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_option: bad handle");
-    if (option < 0 || option > MFTX_RAFT_OPT_FUSE_LOOKUP) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
+    if (option < 0 || option > MFTX_RAFT_OPT_GRAPH) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
     r->opt[option] = value;
+    if (r->graphs) r->graphs->clear();
     return 0;
 }
 
@@ -342,6 +358,14 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     if (ws.bytes > workspace_bytes)
         return fail(MFTX_E_WORKSPACE, "raft_refine: workspace %zu < %zu bytes", workspace_bytes, ws.bytes);
     hipStream_t s = (hipStream_t)stream;
+    const bool use_graph = r->graphs && r->opt[MFTX_RAFT_OPT_GRAPH] != 0 && !prof_enabled() && !r->coords_trace && !ondemand;
+    hipStream_t caller = s;
+    bool proxied = false;
+    if (use_graph && s == nullptr) {                 // the legacy stream (PyTorch's default) cannot be captured: graph_cache.h
+        hipStream_t own = r->graphs->proxy.enter(s);
+        if (own) { s = own; proxied = true; }
+    }
+    struct Leave { GraphCache *g; hipStream_t caller; bool on; ~Leave() { if (on) g->proxy.leave(caller); } } leave{r->graphs, caller, proxied};
     const int N = h * w, M = P * N;
     const float *const *W = r->w;
     const float *const *G = r->wg;          // GEMM layers: fp32 or split weights, by the handle's arithmetic
@@ -360,6 +384,11 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
                            flow_init, ws.hx, SP ? ws.hf : nullptr, ws.coords1, M, h, w);
         TRY(check_launch("init_state"));
     }
+    float *flow_lr = flow_lr_out ? flow_lr_out : ws.flow_lr;
+    // Everything between the first kernels (which read the caller's feature maps) and the last (which writes the caller's
+    // outputs) touches the workspace only: one launch sequence per (shape, workspace, mode), replayed as a hipGraph from
+    // its third use on (graph_cache.h).  The forked side stream joins the capture through its events.
+    auto core = [&]() -> int {
     // The gate convolutions are linear in their input [h | inp | motion] and `inp` does not change
     // over the iterations (core/raft.py:146-149): its third of every gate sum (+ bias) is computed
     // once here and enters the per-iteration GEMMs as an epilogue addend.  Same terms, summed once.
@@ -372,6 +401,9 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     const int strips = cdiv(w, F1_CELLS);
     for (int it = 0; it < iters; ++it) {
         const bool last = (it == iters - 1);
+        if (r->coords_trace &&       // RAFT.forward(vis_debug=True): the coordinates every iteration starts from (core/raft.py:175-176)
+            hipMemcpyAsync(r->coords_trace + (size_t)it * M * 2, ws.coords1, (size_t)M * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return fail(MFTX_E_STATE, "raft_refine: coords trace copy failed");
         // The motion encoder has two independent branches (core/update.py:152-158): correlation lookup -> convc1 -> convc2
         // and convf1 -> convf2 on the flow.  Both need only coords1.  Split arithmetic, small batches (up to four
         // 512 x 512 pairs: the kernels leave CUs idle): the flow branch runs on the handle's SIDE STREAM beside the
@@ -453,12 +485,14 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
             TRY(launch_conv_small(fh2, s, ws.coords1, 2));
         }
         if (!last) continue;
+        if (r->coords_trace &&       // ... and the final ones (core/raft.py:255-256)
+            hipMemcpyAsync(r->coords_trace + (size_t)iters * M * 2, ws.coords1, (size_t)M * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return fail(MFTX_E_STATE, "raft_refine: coords trace copy failed");
         // The upsampling mask is consumed only after the last iteration in test
         // mode (core/raft.py:190-196,234-239), so it is computed once.
         TRY(launch_conv(gemm(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, G[W_MASK0], W[B_MASK0], ws.fh, 256, P, h, w, 256, 3, 3, 1), true, false), s));
         TRY(launch_conv(gemm(conv_desc(ws.fh, 256, 256, nullptr, 0, 0, G[W_MASK2], W[B_MASK2], ws.mask, 576, P, h, w, 576, 1, 1, 0, 0.25f), false, false), s));
         // occlusion + uncertainty heads (core/update.py:196-214)
-        float *flow_lr = flow_lr_out ? flow_lr_out : ws.flow_lr;
         {
             const long long slots = (long long)M * 178;
             ProfScope prof(PC_GLUE, s, 0);
@@ -468,9 +502,27 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         }
         TRY(launch_conv(gemm(conv_desc(ws.ouin, 712, 712, nullptr, 0, 0, G[W_OU1], W[B_OU1], ws.ouh, 256, P, h, w, 256, 3, 3, 1), true, false), s));
         TRY(launch_conv(conv_desc(ws.ouh, 256, 256, nullptr, 0, 0, W[W_OU2], W[B_OU2], ws.ou, 4, P, h, w, 3, 3, 3, 0), s));
-        TRY(launch_convex_upsample(flow_lr, ws.ou, 4, ws.mask, P, h, w, pad_left, pad_right, pad_top, pad_bottom,
-                                   flow, occl, sigma, packed, s));
     }
+    return 0;
+    };   // core
+    if (use_graph) {
+        if (AR == MFTX_ARITH_SPLIT && r->opt[MFTX_RAFT_OPT_FORK] != 0) TRY(ensure_side_stream(r));      // (not while capturing)
+        GraphKey key{};
+        key.v[0] = (uintptr_t)P; key.v[1] = (uintptr_t)h; key.v[2] = (uintptr_t)w; key.v[3] = (uintptr_t)iters;
+        key.v[4] = reinterpret_cast<uintptr_t>(workspace); key.v[5] = reinterpret_cast<uintptr_t>(flow_lr_out);
+        key.v[6] = (uintptr_t)AR; key.v[7] = reinterpret_cast<uintptr_t>(r->wfused); key.v[8] = reinterpret_cast<uintptr_t>(s);
+        TRY(r->graphs->run(key, s, core));
+    } else {
+        TRY(core());
+    }
+    return launch_convex_upsample(flow_lr, ws.ou, 4, ws.mask, P, h, w, pad_left, pad_right, pad_top, pad_bottom,
+                                  flow, occl, sigma, packed, s);
+}
+
+extern "C" int mftx_raft_graph_stats(const mftx_raft *r, unsigned long long *captures, unsigned long long *replays) {
+    if (!r || r->magic != RAFT_MAGIC || !captures || !replays) return fail(MFTX_E_STATE, "raft_graph_stats: bad arguments");
+    *captures = r->graphs ? r->graphs->captures : 0;
+    *replays = r->graphs ? r->graphs->replays : 0;
     return 0;
 }
 

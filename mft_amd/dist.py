@@ -148,9 +148,11 @@ class WindowSharder:
         deferred by the PREVIOUS call ([] the first time), ``flush`` hands back the last one.  The all-gather and the
         replicated selections of window w then overlap the RAFT batches of window w + 1 instead of standing between
         two windows' batches.  Same results, one window later."""
+        if not defer and self._pending is not None:
+            # (checked BEFORE anything is enqueued: a rank that raised after issuing collectives would leave its peers hanging)
+            raise RuntimeError("flush() the deferred window before switching to undeferred calls")
         cur = self._start_window(tracker, imgs, next_imgs, async_gather=defer)
         if not defer:
-            assert self._pending is None, "flush() the deferred window before switching to undeferred calls"
             return self._finish_window(tracker, cur)
         prev, self._pending = self._pending, cur
         return self._finish_window(tracker, prev) if prev is not None else []
@@ -202,18 +204,50 @@ class WindowSharder:
         send = torch.empty(max(slots, 1), H, W, 4, dtype=torch.float32, device=dev)
         mine = units[off: off + cnt]
         max_batch = self.MAX_BATCH_SPLIT if getattr(tracker.flower, "_arith", 0) == 1 else self.MAX_BATCH
-        n_batches = -(-cnt // max_batch) if cnt else 0
-        bounds = [(cnt * i) // n_batches for i in range(n_batches + 1)] if cnt else [0]
+        # Flow cache (MFT/MFT.py:96-102, 214-219): a unit is looked up -- and, when computed, written back -- by its OWNER
+        # rank only, so hit or miss cannot differ between ranks: whatever the owner puts into its send slot (the cached,
+        # quantised FlowOU or the fresh one) is what every rank chains.  Any read error means recompute.
+        cache = getattr(tracker, "flow_cache", None)
+        todo = list(range(cnt))                     # positions in `mine` that go through the engine
+        if cache is not None:
+            todo = []
+            for i, (j, k) in enumerate(mine):
+                _, left_id, use_cache = plans[j][k]
+                hit = None
+                if use_cache:
+                    try:
+                        f, o, s_ = cache.read(left_id, frame_ids[j])
+                        assert f is not None
+                        hit = (torch.as_tensor(f).to(dev), torch.as_tensor(o).to(dev), torch.as_tensor(s_).to(dev))
+                    except Exception:
+                        hit = None
+                if hit is None:
+                    todo.append(i)
+                else:
+                    send[i].copy_(torch.cat([hit[0].reshape(2, H, W), hit[1].reshape(1, H, W), hit[2].reshape(1, H, W)], 0).permute(1, 2, 0))
+                    self.stats["cache_hits"] = self.stats.get("cache_hits", 0) + 1
+        n_todo = len(todo)
+        n_batches = -(-n_todo // max_batch) if n_todo else 0
+        bounds = [(n_todo * i) // n_batches for i in range(n_batches + 1)] if n_todo else [0]
+        contiguous = todo == list(range(cnt))       # (no cache, or nothing found: the engine writes into the send buffer itself)
         for b0, b1 in zip(bounds[:-1], bounds[1:]):
-            batch = mine[b0: b1]
+            batch = [mine[i] for i in todo[b0: b1]]
             pairs = []
             for j, k in batch:
                 left_id = plans[j][k][1]
                 pairs.append((left_id, img_of(left_id), frame_ids[j], imgs[j]))
-            res = tracker._flows_for_pairs(pairs, packed_out=send[b0: b0 + len(batch)], planar=False)
+            want_planes = cache is not None and any(plans[j][k][2] for j, k in batch)
+            res = tracker._flows_for_pairs(pairs, packed_out=send[b0: b0 + len(batch)] if contiguous else True,
+                                           planar=want_planes)
             for s_, out in enumerate(res):
+                i = todo[b0 + s_]
                 if len(out) < 4:                      # a plugin without packed output: interleave here
-                    send[b0 + s_].copy_(torch.cat([out[0], out[1], out[2]], 0).permute(1, 2, 0))
+                    send[i].copy_(torch.cat([out[0], out[1], out[2]], 0).permute(1, 2, 0))
+                elif not contiguous:
+                    send[i].copy_(out[3])
+                j, k = mine[i]
+                if cache is not None and plans[j][k][2]:
+                    cache.write(plans[j][k][1], frame_ids[j], out[0], out[1], out[2])
         recv = torch.empty((G,) + tuple(send.shape), dtype=send.dtype, device=send.device)     # [G, slots, H, W, 4]
         work = dist.all_gather_into_tensor(recv.view(G * send.shape[0], *send.shape[1:]), send, group=self.group,
                                            async_op=async_gather)

@@ -198,7 +198,8 @@ def pack_encoder_weights(sd: dict, prefix: str, batch_norm: bool, device) -> lis
 class EncoderEngine:
     """Handle on the native encoder runtime (``mftx_encoder_*``): fnet or cnet."""
 
-    def __init__(self, state_dict: dict, prefix: str, instance_norm: bool, device, arith=None):
+    def __init__(self, state_dict: dict, prefix: str, instance_norm: bool, device, arith=None, graph=True):
+        """graph: replay the layers between pre-processing and head as a hipGraph (``mftx_encoder_set_graph``)."""
         lib = _lib.load()
         self.device = torch.device(device)
         self.instance_norm = instance_norm
@@ -209,6 +210,8 @@ class EncoderEngine:
               "mftx_encoder_create")
         self._h = handle
         self._ws = None
+        if not graph:
+            check(lib.mftx_encoder_set_graph(self._h, 0), "mftx_encoder_set_graph")
         self.arith = ARITH_SPLIT if arith is None else int(arith)
         if self.arith == ARITH_SPLIT:           # split-fp16 products: the convolutions stream split weights
             self.split = [split_weights(t) for t in self.weights[0::2]]
@@ -554,7 +557,7 @@ class RaftEngine:
     # WeightSlot indices (csrc/raft_engine.hip) of the weights that feed GEMM layers
     GEMM_SLOTS = (0, 2, 6, 8, 10, 11, 13, 14, 16, 17, 19, 20, 22, 26, 28, 30)
 
-    OPTIONS = {"fork": 0, "presplit": 1, "group": 2, "fuse_lookup": 3}      # MFTX_RAFT_OPT_*
+    OPTIONS = {"fork": 0, "presplit": 1, "group": 2, "fuse_lookup": 3, "graph": 4}      # MFTX_RAFT_OPT_*
 
     def __init__(self, state_dict: dict, device, ondemand_corr=False, arith=ARITH_SPLIT, options=None):
         """options: {"fork" | "presplit" | "group" | "fuse_lookup": int} scheduling options of this handle
@@ -590,6 +593,40 @@ class RaftEngine:
                 self._h = None
         except Exception:
             pass
+
+    def debug_refine(self, fmap1, fmap2, net, inp, h, w, iters, pads=(0, 0, 0, 0), flow_init=None):
+        """``refine`` with the debug payload of ``RAFT.forward(vis_debug=True)`` (core/raft.py:159-176, 255-257):
+        -> (flow, occl, sigma), {'costvolume_pyramid': 4 x [P*h*w, 1, h_l, w_l], 'coords_left': [P, 2, h, w],
+        'iterations': (iters + 1) x {'coords': [P, 2, h, w]}}, everything on the CPU like the reference's."""
+        lib = _lib.load()
+        P = fmap1.shape[0]
+        M = P * h * w
+        trace = torch.empty(iters + 1, M, 2, dtype=torch.float32, device=self.device)
+        check(lib.mftx_raft_set_coords_trace(self._h, trace.data_ptr()), "mftx_raft_set_coords_trace")
+        try:
+            out = self.refine(fmap1, fmap2, net, inp, h, w, iters, pads=pads, flow_init=flow_init)
+        finally:
+            check(lib.mftx_raft_set_coords_trace(self._h, None), "mftx_raft_set_coords_trace")
+        if self.ondemand_corr:
+            pyramid = None                      # (alternate_corr keeps no volume, as in the reference)
+        else:
+            stride, _ = pyramid_layout(h, w)
+            pyramid = []
+            for l in range(4):
+                lvl = self.region(f"lvl{l}", P, h, w, stride[l]).reshape(P, h * w, stride[l])
+                pyramid.append(unblock_level(lvl, l, h, w).reshape(M, 1, h >> l, w >> l).cpu())
+        to_map = lambda t: t.reshape(P, h, w, 2).permute(0, 3, 1, 2).contiguous().cpu()      # noqa: E731
+        ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+        debug = {"costvolume_pyramid": pyramid,
+                 "coords_left": torch.stack([xs, ys])[None].repeat(P, 1, 1, 1),
+                 "iterations": [{"coords": to_map(trace[i])} for i in range(iters + 1)]}
+        return out, debug
+
+    def graph_stats(self):
+        """(graphs captured, graph launches) of this handle (``mftx_raft_graph_stats``)."""
+        c, r = C.c_ulonglong(), C.c_ulonglong()
+        check(_lib.load().mftx_raft_graph_stats(self._h, C.byref(c), C.byref(r)), "mftx_raft_graph_stats")
+        return int(c.value), int(r.value)
 
     def set_option(self, name, value):
         check(_lib.load().mftx_raft_set_option(self._h, self.OPTIONS[name], int(value)), "mftx_raft_set_option")

@@ -93,8 +93,9 @@ class RAFTWrapper:
         self._enc_stream = torch.cuda.Stream(device=self.device) if getattr(config, "async_encode", False) else None
 
     def _build_engines(self):
-        self.fnet_engine = ops.EncoderEngine(self.sd, "fnet", True, self.device, arith=self._arith)
-        self.cnet_engine = ops.EncoderEngine(self.sd, "cnet", False, self.device, arith=self._arith)
+        graph = bool(self._engine_options.get("graph", 1))
+        self.fnet_engine = ops.EncoderEngine(self.sd, "fnet", True, self.device, arith=self._arith, graph=graph)
+        self.cnet_engine = ops.EncoderEngine(self.sd, "cnet", False, self.device, arith=self._arith, graph=graph)
         self.engine = ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand, arith=self._arith,
                                      options=self._engine_options)
 
@@ -336,16 +337,27 @@ class RAFTWrapper:
         """(H,W,3) uint8 BGR images -> flow (2,H,W) + {'occlusion','sigma','debug'}
         (mode='flow'), or (src_coords, dst_coords, extra) (mode='TC')."""
         H, W = src_img.shape[:2]
-        (flow, occl, sigma), = self.compute_pairs([(None, src_img, None, dst_img)], init_flow=init_flow)
+        debug = None
+        if vis_debug:
+            # the reference's debug payload (core/raft.py:159-176, 255-257): cost-volume pyramid, start grid and the
+            # coordinates of every iteration, on the CPU
+            fl, fr = self._features(None, src_img), self._features(None, dst_img)
+            flow_init = self._init_flow_lr(init_flow, fl) if init_flow is not None else None
+            (flow, occl, sigma), debug = self.engine.debug_refine(fl.fmap[None], fr.fmap[None], fl.net[None], fl.inp[None],
+                                                                   fl.h, fl.w, int(self.C.flow_iters), pads=fl.pads,
+                                                                   flow_init=flow_init)
+            flow, occl, sigma = flow[0], occl[0], sigma[0]
+        else:
+            (flow, occl, sigma), = self.compute_pairs([(None, src_img, None, dst_img)], init_flow=init_flow)
         assert flow.shape == (2, H, W)
         conv = (lambda t: t.detach().cpu().numpy()) if numpy_out else (lambda t: t)
         if mode == "flow":
-            return conv(flow), {"occlusion": conv(occl), "sigma": conv(sigma), "debug": None}
+            return conv(flow), {"occlusion": conv(occl), "sigma": conv(sigma), "debug": debug}
         if mode == "TC":
             idx = torch.arange(H * W, device=flow.device)
             src = torch.stack([idx % W, torch.div(idx, W, rounding_mode="floor")]).to(torch.float32)
             dst = src + flow.reshape(2, H * W)
             return conv(src), conv(dst), {"occlusion": conv(occl.reshape(-1)) if numpy_out else occl,
                                           "sigma": conv(sigma.reshape(-1)) if numpy_out else sigma,
-                                          "debug": None}
+                                          "debug": debug}
         raise ValueError(f"unknown mode {mode!r}")

@@ -52,9 +52,27 @@ class ExchangingFlower:
         return out
 
 
-def run(sharded, window, flower, prefetch=False, defer=False):
+class RoundingCache:
+    """Flow cache whose entries come back QUANTISED (like the reference's .flowouX16 entries, MFT/utils/io.py:495-563):
+    a run that reads an entry chains other values than the run that computed it."""
+
+    def __init__(self):
+        self.store, self.hits, self.writes = {}, 0, 0
+
+    def read(self, left_id, right_id):
+        if (left_id, right_id) not in self.store:
+            return None, None, None
+        self.hits += 1
+        return tuple(torch.round(t * 64) / 64 for t in self.store[(left_id, right_id)])
+
+    def write(self, left_id, right_id, flow, occl, sigma):
+        self.writes += 1
+        self.store[(left_id, right_id)] = (flow.clone(), occl.clone(), sigma.clone())
+
+
+def run(sharded, window, flower, prefetch=False, defer=False, flow_cache=None):
     tr = make_tracker(flower, delta_sharding=sharded)
-    tr.init(gi.id_image(0))
+    tr.init(gi.id_image(0), flow_cache=flow_cache)
     out, i, done = {}, 1, 1            # done: index of the next frame whose meta has not come back yet
 
     def record(metas):
@@ -102,9 +120,22 @@ if __name__ == "__main__":
             res.update(_encoded=np.array(fl.encoded), _local=np.array(fl.local), _frames=np.array(N_FRAMES - 1), _my_units=np.array(st["my_units"]),
                        _windows=np.array(st["windows"]))
         np.savez(outdir / f"rank{rank}_{mode}.npz", **res)
+    # flow cache in the sharded path: a unit is read / written by its owner rank only; a second run over the same
+    # frames is served from the owners' caches and chains the QUANTISED entries, exactly like the single-rank tracker
+    cache = RoundingCache()
+    cold, _ = run(True, 8, StubFlower(), flow_cache=cache)
+    fl2 = StubFlower()
+    warm, tr2 = run(True, 8, fl2, flow_cache=cache)
+    np.savez(outdir / f"rank{rank}_cache.npz", _hits=np.array(cache.hits), _writes=np.array(cache.writes),
+             _recomputed=np.array(len([c for c in fl2.calls if c[0] != 0])),
+             **{"cold_" + k: v for k, v in cold.items()}, **{"warm_" + k: v for k, v in warm.items()})
     if rank == 0:
         # single-rank reference: per-frame track(); chosen / keys recorded at the same frames as L = 8
         ref, _ = run(False, 1, StubFlower())
         np.savez(outdir / "single.npz", **{k: v for k, v in ref.items() if not k.startswith(("chosen", "keys"))})
+        c1 = RoundingCache()
+        run(False, 1, StubFlower(), flow_cache=c1)
+        ref_warm, _ = run(False, 1, StubFlower(), flow_cache=c1)
+        np.savez(outdir / "single_warm.npz", **{k: v for k, v in ref_warm.items() if not k.startswith(("chosen", "keys"))})
     dist.barrier()
     dist.destroy_process_group()

@@ -428,3 +428,60 @@ def test_tapvid_runner_vs_oracle_tracker():
     d = np.abs(out_hip["tracks"] - out_cpu["tracks"]).max(-1)
     assert (d < 1e-3 * 256 / min(H, W)).mean() > 0.99, float((d < 1e-3).mean())
     assert (np.abs(out_hip["occluded"] - out_cpu["occluded"]) < 1e-4).mean() > 0.99
+
+
+def test_compute_flow_vis_debug_payload(flower, weights_cpu):
+    """compute_flow(vis_debug=True) returns the reference's debug payload (core/raft.py:159-176, 255-257): the cost-volume
+    pyramid [N, 1, h_l, w_l] per level, the start grid and iters + 1 coordinate maps, all on the CPU -- and the same flow
+    as without it."""
+    vid = SyntheticVideo(125, 187, n_frames=4, seed=31)          # ragged: 16 x 24 cells after padding
+    flower.C.flow_iters = 3
+    try:
+        f0, e0 = flower.compute_flow(vid[0], vid[2], mode="flow")
+        f1, e1 = flower.compute_flow(vid[0], vid[2], mode="flow", vis_debug=True)
+    finally:
+        flower.C.flow_iters = 12
+    assert e0["debug"] is None
+    assert torch.equal(f0, f1) and torch.equal(e0["sigma"], e1["sigma"])
+    dbg = e1["debug"]
+    h, w = 16, 24
+    assert sorted(dbg) == ["coords_left", "costvolume_pyramid", "iterations"]
+    assert [tuple(t.shape) for t in dbg["costvolume_pyramid"]] == [(h * w, 1, h >> l, w >> l) for l in range(4)]
+    assert all(not t.is_cuda for t in dbg["costvolume_pyramid"])
+    assert tuple(dbg["coords_left"].shape) == (1, 2, h, w) and torch.equal(dbg["coords_left"], O.pixel_grid(h, w)[None])
+    its = dbg["iterations"]
+    assert len(its) == 4 and all(tuple(i["coords"].shape) == (1, 2, h, w) for i in its)
+    assert torch.equal(its[0]["coords"], dbg["coords_left"])          # no init_flow: the first iteration starts on the grid
+    assert not torch.equal(its[1]["coords"], its[0]["coords"])
+    # the pyramid is the reference's: all-pairs correlation of the feature maps, average-pooled over the target dims
+    im1, im2 = O.preprocess(vid[0]), O.preprocess(vid[2])
+    pyr = O.corr_pyramid(O.corr_volume(O.features(weights_cpu, im1), O.features(weights_cpu, im2)))
+    for l in range(4):
+        assert (dbg["costvolume_pyramid"][l] - pyr[l]).abs().max() < 2e-3, l
+    # the last coordinates are the low-resolution flow that gets upsampled: 8 x (coords - grid) ~ the flow's local mean
+    lr = 8 * (its[-1]["coords"] - dbg["coords_left"])[0]
+    assert (torch.nn.functional.avg_pool2d(f1.cpu()[None, :, :120, :184], 8)[0] - lr[:, :15, :23]).abs().mean() < 1.0
+
+
+def test_checkpoint_with_module_prefix_loads_through_config(tmp_path, weights_np):
+    """torch.load(C.model) of a DataParallel checkpoint -- every key prefixed with 'module.' (MFT/raft.py:20-23) -- gives
+    the same plugin as handing the state dict over; a configured but missing checkpoint raises like the reference."""
+    from mft_amd.config import Config
+    from mft_amd.raft import RAFTWrapper
+    path = tmp_path / "raft-things-sintel-kubric-splitted-occlusion-uncertainty-non-occluded-base-sintel.pth"
+    torch.save({"module." + k: torch.from_numpy(v) for k, v in weights_np.items()}, path)
+    c = Config()
+    c.flow_iters = 2
+    c.model = str(path)
+    loaded = RAFTWrapper(c)
+    c2 = Config()
+    c2.flow_iters = 2
+    direct = RAFTWrapper(c2, state_dict=weights_np)
+    vid = SyntheticVideo(128, 160, n_frames=3, seed=3)
+    fa, ea = loaded.compute_flow(vid[0], vid[1], mode="flow")
+    fb, eb = direct.compute_flow(vid[0], vid[1], mode="flow")
+    assert torch.equal(fa, fb) and torch.equal(ea["occlusion"], eb["occlusion"]) and torch.equal(ea["sigma"], eb["sigma"])
+    c3 = Config()
+    c3.model = str(tmp_path / "missing.pth")
+    with pytest.raises(FileNotFoundError):
+        RAFTWrapper(c3)

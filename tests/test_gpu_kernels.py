@@ -296,9 +296,9 @@ def test_split_weights_range_guard(ops_mod, weights_np):
     fc = _flow_config()
     wrapper = RAFTWrapper(fc, state_dict=sd)
     assert wrapper.arith == "fp32"                            # refused the split arithmetic, kept working
-    img = np.random.default_rng(0).integers(0, 255, (64, 96, 3), dtype=np.uint8)
+    img = np.random.default_rng(0).integers(0, 255, (128, 192, 3), dtype=np.uint8)
     flow, extra = wrapper.compute_flow(img, img, mode="flow")
-    assert flow.shape == (2, 64, 96)
+    assert flow.shape == (2, 128, 192)
     assert RAFTWrapper(fc, state_dict={k: torch.from_numpy(v) for k, v in weights_np.items()}).arith == "split"
 
 
@@ -1012,3 +1012,55 @@ def test_conv_tile_shapes_bitwise():
     from mft_amd.ops import MftxError
     with pytest.raises(MftxError, match="measurement-only"):
         _tile_layers(2, 13)
+
+
+def test_engine_graph_replay_bitwise():
+    """mftx_raft_refine replays its workspace-only launch sequence as a hipGraph from the third call with a (shape,
+    workspace) key on (option graph, default on): first call plain, second captured, later ones replayed -- same bits as
+    plain launches every time, with fresh inputs each call (the graph holds addresses, not values)."""
+    from mft_amd import ops
+    from mft_amd.weights import make_weights
+    sd = {k: torch.from_numpy(v).cuda() for k, v in make_weights(7).items()}
+    plain, graphed = ops.RaftEngine(sd, "cuda", options={"graph": 0}), ops.RaftEngine(sd, "cuda")
+    g = torch.Generator().manual_seed(21)
+    P, h, w = 2, 24, 40
+    for stream in (torch.cuda.Stream(), torch.cuda.default_stream()):
+      # (the legacy default stream cannot be captured: the engine moves such calls onto a private stream, ordered by events)
+      graphed = ops.RaftEngine(sd, "cuda")
+      s = stream
+      with torch.cuda.stream(s):
+        for call in range(5):
+            f1 = torch.randn(P, h * w, 256, generator=g).cuda()
+            f2 = (f1.cpu() + 0.3 * torch.randn(P, h * w, 256, generator=g)).cuda()
+            net = torch.tanh(torch.randn(P, h * w, 128, generator=g)).cuda()
+            inp = torch.relu(torch.randn(P, h * w, 128, generator=g)).cuda()
+            a = plain.refine(f1, f2, net, inp, h, w, 3)
+            b = graphed.refine(f1, f2, net, inp, h, w, 3)
+            for x, y in zip(a, b):
+                assert torch.equal(x, y), call
+        # another shape gets its own graph; the first one stays valid
+        f = torch.randn(1, 16 * 24, 256, generator=g).cuda()
+        n = torch.zeros(1, 16 * 24, 128).cuda()
+        for call in range(3):
+            assert all(torch.equal(x, y) for x, y in zip(plain.refine(f, f, n, n, 16, 24, 2), graphed.refine(f, f, n, n, 16, 24, 2)))
+      s.synchronize()
+      captures, replays = graphed.graph_stats()
+      assert captures == 2 and replays == 4, (captures, replays)
+    assert plain.graph_stats() == (0, 0)
+
+
+def test_encoder_graph_replay_bitwise(weights_np):
+    from mft_amd import ops
+    sd = {k: torch.from_numpy(v).cuda() for k, v in weights_np.items()}
+    rng = np.random.default_rng(3)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for prefix, inorm in (("fnet", True), ("cnet", False)):
+            plain = ops.EncoderEngine(sd, prefix, inorm, "cuda", graph=False)
+            graphed = ops.EncoderEngine(sd, prefix, inorm, "cuda")
+            for call in range(4):
+                img = torch.from_numpy(rng.integers(0, 255, (125, 187, 3), dtype=np.uint8)).cuda()
+                a, b = plain.forward(img), graphed.forward(img)
+                for x, y in zip(a, b):
+                    assert (x is None and y is None) or torch.equal(x, y), (prefix, call)
+    s.synchronize()
