@@ -485,20 +485,33 @@ def main():
         log(f"other arithmetic ({other}): {10 / alt_dt:.1f} frames/s")
     if not sharded and rank == 0:
         if n_io:
-            # PCIe-inclusive variant of the same loop: numpy frames in, CPU results out -- every frame crosses PCIe in,
-            # every result out.  (Pageable frames + synchronous .cpu(): of the paths measured in
-            # profiles/r2_io_paths.txt the fastest that moves data in BOTH directions; pinned-ring uploads and pinned
-            # downloads are each faster alone but serialise when combined on this software stack.)
-            conf.keep_result_on_device = False
+            # PCIe-inclusive variant of the same loop: every frame comes from HOST memory and every result goes back to it
+            # (what the reference's API does, MFT/utils/io.py:566-615 in, MFT/MFT.py:145-148 out).  Frames wait in pinned
+            # buffers (mft_amd.video.FrameRing) and are uploaded by a copy kernel on the encoders' stream; results leave
+            # through the same copy kernel into pinned buffers and are collected two frames late (ResultDrain) -- no SDMA
+            # copy on either side, so nothing serialises (profiles/r2_io_paths.txt was the study of the hipMemcpyAsync paths).
+            from mft_amd.video import FrameRing, ResultDrain
             base = first + args.steps + n_prof
+            enc = getattr(tracker.flower, "_enc_stream", None)
+            ring = FrameRing((host_frames[i] for i in range(base, base + n_io)), keep=40,
+                             streams=[enc] if enc is not None else None).prepare(host_frames[0].shape)
+            drain = ResultDrain(depth=4)
+            got = 0
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i in range(base, base + n_io):
-                out = tracker.track(host_frames[i]).result
-                assert not out.flow.is_cuda
+            for frame in ring:
+                drain.submit(tracker.track(frame).result)
+                if len(drain) > 2:
+                    out = drain.collect()
+                    assert not out[0].is_cuda
+                    got += 1
+            while len(drain):
+                drain.collect()
+                got += 1
             torch.cuda.synchronize()
-            conf.keep_result_on_device = True
+            assert got == n_io
             result["host_io_fps"] = n_io / (time.perf_counter() - t0)
+            result["host_io_path"] = "pinned frames in and pinned results out, both moved by a copy kernel (no SDMA queue)"
             log("host-io pass done")
         torch.set_num_threads(oracle_threads())
         if not args.no_parity:

@@ -319,6 +319,15 @@ int mftx_quantize_u16(const float *x, long long n, uint16_t *q, float *lohi,
                       void *workspace, size_t workspace_bytes, void *stream);
 int mftx_dequantize_u16(const uint16_t *q, long long n, float lo, float hi, float *x, void *stream);
 
+/* ---- 8f-4: frame / result transport without copy queues -------------------------------------------------------------------
+ * A copy KERNEL: src -> dst, n bytes, both 16-byte aligned; either may be PINNED HOST memory (hipHostMalloc / torch
+ * pin_memory: mapped into the device's address space), which a kernel reads and writes over PCIe directly.  Unlike
+ * hipMemcpyAsync it is ordered like any kernel of `stream` and uses no SDMA queue -- uploads and downloads enqueued this
+ * way cannot serialise behind each other (MFT/utils/io.py:566-615 reads frames on the host, MFT/MFT.py:145-148 hands
+ * results back to it: every frame crosses PCIe both ways).  16 bytes per lane, coalesced: ~25 GB/s either way.  (Kernels that
+ * read host memory in narrow pieces crawl -- the encoders take a device copy of the frame, uploaded with this.) */
+int mftx_copy_bytes(const void *src, void *dst, long long n, void *stream);
+
 /* HOST helper of the same codec: reconstruct the scanlines of an inflated, non-interlaced PNG
  * IDAT stream in place (what cv2.imdecode does inside read_flowou_X16, MFT/utils/io.py:541-543).
  * rows: height x (1 + row_bytes) bytes in, height x row_bytes bytes out (compacted to the front);

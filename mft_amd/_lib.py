@@ -87,6 +87,7 @@ SIGNATURES = {
     "mftx_quantize_u16": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mftx_dequantize_u16": (C.c_int, [C.c_void_p, C.c_longlong, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "mftx_png_unfilter": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "mftx_copy_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
 }
 
 _lib = None

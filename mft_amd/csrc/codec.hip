@@ -138,6 +138,29 @@ extern "C" int mftx_dequantize_u16(const uint16_t *q, long long n, float lo, flo
 // IDAT stream of a non-interlaced image: height x (1 filter byte + row_bytes); the reconstructed
 // pixels are compacted to the front (height x row_bytes).  Host code: byte-serial by definition
 // (every byte depends on its left neighbour), so it lives here rather than in a Python loop.
+// ---- shader copy ----------------------------------------------------------------------------------------------------------
+// A pinned-host <-> device copy enqueued with hipMemcpyAsync goes through the SDMA queues, where an upload submitted
+// while a download is pending waits for the compute that download waits for (profiles/r2_io_paths.txt: pinned uploads and
+// downloads together serialise the loop).  Pinned host memory is mapped into the device's address space, so a KERNEL can
+// move the bytes instead: it is ordered like any other kernel of its stream and touches no copy queue.
+__global__ void copy_bytes_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, long long n16,
+                                  const unsigned char *__restrict__ tail_src, unsigned char *__restrict__ tail_dst, int tail) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) tail_dst[threadIdx.x] = tail_src[threadIdx.x];
+}
+
+extern "C" int mftx_copy_bytes(const void *src, void *dst, long long n, void *stream) {
+    if (!src || !dst || n < 0) return fail(MFTX_E_ARG, "copy_bytes: bad arguments");
+    if (n == 0) return 0;
+    if (!aligned16(src) || !aligned16(dst)) return fail(MFTX_E_ALIGN, "copy_bytes: both pointers must be 16-byte aligned");
+    const long long n16 = n / 16;
+    const long long blocks = (n16 + 255) / 256;
+    hipLaunchKernelGGL(copy_bytes_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks > 2048 ? 2048 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const uint4 *>(src), static_cast<uint4 *>(dst), n16,
+                       static_cast<const unsigned char *>(src) + n16 * 16, static_cast<unsigned char *>(dst) + n16 * 16, (int)(n - n16 * 16));
+    return check_launch("copy_bytes");
+}
+
 // ---- range guard of the split arithmetic (MFTX_ARITH_SPLIT): hi = fp16(x) needs |x| < 65504 ---------------------------------
 __global__ void count_not_below_kernel(const float *__restrict__ x, long long n, float limit, unsigned *__restrict__ count) {
     unsigned bad = 0;

@@ -344,8 +344,13 @@ __device__ __forceinline__ void volume_epilogue(const ConvArgs &p, const f32x16 
 // form consumes -- (k, k+4, k+1, k+5), (k+2, k+6, k+3, k+7) across its four lane groups -- the 16x16x4
 // form rounds bit-identically (both are sequential fmaf chains; tools/micro/mfma_order.hip), so the
 // tile choice still does not show in the results.
-template <int BM, int BN, int WM, int WN, int EPI, int MT = 32, int AR = AR_F32, int NS = 2>
+// WS = 1 (split arithmetic, A pre-split): WARP-SPECIALISED workgroup -- WM x WN consumer waves (fragment reads and MFMAs,
+// nothing else in their K loop) and as many producer waves (all of the LDS-DMA staging: an LDS-DMA piece holds the wave
+// that issues it for ~70 cycles, a third of a chunk's matrix work when the same wave also feeds the matrix pipe).  Same
+// ring, same barrier per chunk, same fragment order: same bits.
+template <int BM, int BN, int WM, int WN, int EPI, int MT = 32, int AR = AR_F32, int NS = 2, int WS = 0>
 __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
+    static_assert(!WS || (AR == AR_PRESPLIT && MT == 32), "warp-specialised form: split arithmetic with a pre-split A, 32-row MFMA tiles");
     static_assert(AR == AR_F32 || MT == 32 || AR == AR_PRESPLIT, "split arithmetic: 32x32 MFMA tiles; 16x16 for a pre-split A only");
     // NS: LDS ring of K chunks.  fp32 MFMA: two (a chunk is > 1000 matrix cycles per wave, deeper rings were
     // measured: no gain).  Split arithmetic: a chunk is 192 matrix cycles per MFMA tile, well below the L2 latency:
@@ -369,9 +374,11 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
     float *As = smem;                       // [NS][BMS][LDK]
     float *Bs = smem + NS * BMS * LDK;      // [NS][BNS][LDK]
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA destinations live in m0
+    const int lane = threadIdx.x & 63;
+    const int wid_all = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // scalar: LDS-DMA destinations live in m0
+    const bool is_prod = WS && wid_all >= WM * WN;             // (wave-uniform) a producer wave of the warp-specialised form
+    const int wid = is_prod ? wid_all - WM * WN : wid_all;     // consumer: which wave tile; producer: which staging rows
+    const int tid = wid * 64 + lane;
     const int wm = wid / WN, wn = wid % WN;
     const int srow = tid >> 3;  // 0..RPP-1: staging row of this lane within an RPP-row group
     // this lane's LDS chunk (tid & 7) receives logical chunk (tid & 7) ^ swz(row); rows advance by
@@ -873,6 +880,49 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         wait_vmcnt<0>();
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // the last MFMAs' results, before the VALU reads them
     } else
+    if constexpr (WS) {
+        // Warp-specialised form of the loop below.  Producer waves: chunks 0 .. NS - 1 up front; then, per chunk c, wait for
+        // their own pieces of chunk c + 1 (counted: NS - 2 younger chunks may fly), meet the consumers at the chunk's one
+        // barrier -- which also certifies that every consumer has read the last of chunk c -- and refill that slot with
+        // chunk c + NS.  Consumer waves: the loop below without a single DMA piece or vmcnt wait in it.
+        constexpr int L = RA + RB;
+        if (is_prod) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+                if (i < T) fetch(i);
+            if (T >= NS) wait_vmcnt<(NS - 1) * L>(); else wait_vmcnt<0>();
+            block_barrier();
+            int slot = 0;
+            for (int c = 0; c + 1 < T; ++c) {
+                if (c + NS - 1 < T) wait_vmcnt<(NS - 2) * L>(); else wait_vmcnt<0>();
+                block_barrier();
+                if (c + NS < T) fetch(slot);
+                slot = slot + 1 == NS ? 0 : slot + 1;
+            }
+        } else {
+            block_barrier();
+            read_raw(0, 0, 0);
+            ah[0] = __builtin_bit_cast(f16x8, ra[0][0][0]);
+            al[0] = __builtin_bit_cast(f16x8, ra[0][0][1]);
+            int slot = 0;
+            auto chunk = [&](auto more_) {
+                constexpr bool more = decltype(more_)::value;
+                const int nslot = slot + 1 == NS ? 0 : slot + 1;
+                read_raw(slot, 1, 1);
+                group(0, 1, std::true_type{}, std::false_type{}, 0);
+                if constexpr (more) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    block_barrier();
+                    read_raw(nslot, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                group(1, 0, std::integral_constant<bool, more>{}, std::false_type{}, slot);
+                slot = nslot;
+            };
+            for (int c = 0; c + 1 < T; ++c) chunk(std::true_type{});
+            chunk(std::false_type{});
+        }
+    } else
     if constexpr (SPLIT) {
         // Ring of NS chunks, slot of chunk c = c % NS (run-time index: the K loop is not unrolled over the slots).
         // Per chunk: two 16-wide k groups; the raw fragments of the next group are read from LDS before the
@@ -1021,6 +1071,7 @@ __device__ __forceinline__ void conv_gemm_body(const ConvArgs &p, int vt0) {
         // per row.  Two phases per tile as below: every global read first, then arithmetic and stores.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         block_barrier();                      // every wave is done with the ring: it becomes epilogue staging
+        if (WS && is_prod) continue;          // (producer waves hold no accumulators: on to the next tile's top barrier)
         // (16-row MFMA tiles: the epilogue tile is one 16-row tile x the wave's 64 columns -- four passes of 4 rows x 16
         // float4; staging rows padded to 68 floats so that the four lane groups' C/D writes spread over all banks)
         constexpr int ETN = MT == 32 ? TM * TN : TM;            // epilogue tiles per wave
@@ -1369,10 +1420,10 @@ __device__ __forceinline__ int n_virtual_tiles(const ConvArgs &p, int BM, int BN
     return 8 * (((p.M + BM - 1) / BM + 7) / 8) * ((p.N + BN - 1) / BN) * p.batch;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int MT = 32, int AR = AR_F32, int NS = 2>
-__global__ __launch_bounds__(64 * WM * WN, AR != AR_F32 ? min_waves_split((BM / WM / MT) * (BN / WN / MT), WM * WN, MT) : min_waves((BM / WM / MT) * (BN / WN / MT), EPI))
+template <int BM, int BN, int WM, int WN, int EPI, int MT = 32, int AR = AR_F32, int NS = 2, int WS = 0>
+__global__ __launch_bounds__(64 * WM * WN * (1 + WS), WS ? 2 * WM * WN / 4 : AR != AR_F32 ? min_waves_split((BM / WM / MT) * (BN / WN / MT), WM * WN, MT) : min_waves((BM / WM / MT) * (BN / WN / MT), EPI))
 void conv_gemm_kernel(ConvArgs p) {
-    conv_gemm_body<BM, BN, WM, WN, EPI, MT, AR, NS>(p, blockIdx.x);
+    conv_gemm_body<BM, BN, WM, WN, EPI, MT, AR, NS, WS>(p, blockIdx.x);
 }
 
 // Two independent convolutions in one launch (the two branches of the motion encoder, convc2 and convf2):
@@ -1402,12 +1453,12 @@ static int num_cus() {
     return n;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int MT = 32, int AR = AR_F32, int NS = 2>
+template <int BM, int BN, int WM, int WN, int EPI, int MT = 32, int AR = AR_F32, int NS = 2, int WS = 0>
 static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat, double work = -1.0) {
     constexpr int RPP = 8 * WM * WN;                  // ring slots hold whole staging passes
     constexpr size_t lds = (size_t)NS * ((BM + RPP - 1) / RPP + (BN + RPP - 1) / RPP) * RPP * LDK * sizeof(float);
     static bool attr_set = false;
-    auto kern = conv_gemm_kernel<BM, BN, WM, WN, EPI, MT, AR, NS>;
+    auto kern = conv_gemm_kernel<BM, BN, WM, WN, EPI, MT, AR, NS, WS>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1418,7 +1469,7 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat, 
     args.batch = batch;
     // resident workgroups per CU: LDS-bound (160 KiB per CU), at most MFTX_CONV_RESIDENT_WAVES waves
     static const int max_waves = tune_env("MFTX_CONV_RESIDENT_WAVES", 16);
-    const int max_res = max_waves / (WM * WN);
+    const int max_res = max_waves / (WM * WN * (1 + WS));
     const int resident = (160 * 1024) / (int)lds < max_res ? (160 * 1024) / (int)lds : max_res;
     const long long n_virtual = 8ll * cdiv(cdiv(a.M, BM), 8) * cdiv(a.N, BN) * batch;
     static const bool one_tile_per_wg = tune_env("MFTX_CONV_NONPERSISTENT", 0) != 0;   // tuning: let the dispatcher interleave kernels of two streams
@@ -1426,7 +1477,7 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat, 
     dim3 grid((unsigned)(n_virtual < slots ? n_virtual : slots));
     // algorithmic flops: real (unpadded) reduction length
     ProfScope prof(cat, s, work >= 0 ? work : 2.0 * a.M * a.N * (double)(a.kh * a.kw) * (a.c0 + a.c1) * batch);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, args);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN * (1 + WS)), lds, s, args);
     return check_launch("conv_gemm");
 }
 
@@ -1444,6 +1495,7 @@ int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, ProfCat c
             case 6: return launch_cfg<128, 128, 4, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);       // (ring of three: 125.1 -> 126.2 frames/s against four)
             case 10: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
             case 14: return launch_cfg<128, 192, 4, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);   // eight waves of 32 x 96: N = 192 without a half-empty column tile
+            case 11: return launch_cfg<128, 128, 2, 2, EPI, 32, AR_PRESPLIT, 4, 1>(a, batch, s, cat);   // warp-specialised: four 64 x 64 consumer waves + four producer waves, ring of four chunks (128 KiB)
 #ifdef MFTX_EXPERIMENTAL_TILES       // measurement-only shapes: bit-identical, slower
             case 15: return launch_cfg<224, 128, 2, 4, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);   // four waves of 128 x 32 over four of 96 x 32: 7 x 4096 cells = 128 x 224
             case 13: return launch_cfg<112, 256, 1, 4, EPI, 16, AR_PRESPLIT, 3>(a, batch, s, cat);  // four waves of 112 x 64 on 16-row MFMAs: 7 x 4096 cells = 256 tiles
@@ -1507,7 +1559,9 @@ static int pick_tile(const ConvArgs &a, int batch, int forced_arg) {
         if (try13 && a.a_pre && a.N % 256 == 0 && (long long)cdiv(a.M, 112) * (a.N / 256) <= cus && (long long)cdiv(a.M, 112) * (a.N / 256) * 8 >= cus * 7) return 13;
         if (a.N % 256 == 0 && (long long)cdiv(a.M, 128) * (a.N / 256) * 4 >= cus * 3) return 10;
         if (t128 * 2 >= cus * 3) return 0;
-        if (t128 * 4 >= cus * 3 && t128 <= cus) return 6;     // one round only: five pairs, N = 256 (320 tiles) would take two
+        //   11: 128 x 128 warp-specialised (four 64 x 64 consumer waves + four producer waves), A pre-split: the same one round
+        //       as tile 6, measured at M = 7 x 4096: conv 3x3 256->126 64.0 -> 57.3 us, q gates 40.9 / 36.7 -> 37.4 / 35.6 us
+        if (t128 * 4 >= cus * 3 && t128 <= cus) return a.a_pre ? 11 : 6;     // one round only: five pairs, N = 256 (320 tiles) would take two
         return 9;
     }
     // Measured on MI355X (tools/bench_conv.py, M = 7 x 4096 and 4096): the 64x64

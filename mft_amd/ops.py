@@ -23,6 +23,22 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _device_visible(t):
+    """A tensor a kernel may address: device memory, or pinned host memory (mapped into the device's address space)."""
+    return isinstance(t, torch.Tensor) and (t.is_cuda or t.is_pinned())
+
+
+def copy_bytes(src: torch.Tensor, dst: torch.Tensor):
+    """dst <- src by a copy KERNEL on the current stream (``mftx_copy_bytes``): either side may be pinned host memory.  No
+    SDMA queue is involved, so uploads and downloads enqueued this way do not serialise behind each other."""
+    if not (_device_visible(src) and _device_visible(dst)):
+        raise MftxError("copy_bytes: tensors must be on the device or in pinned host memory")
+    if not (src.is_contiguous() and dst.is_contiguous()) or src.numel() * src.element_size() != dst.numel() * dst.element_size():
+        raise MftxError("copy_bytes: contiguous tensors of the same size in bytes")
+    check(_lib.load().mftx_copy_bytes(src.data_ptr(), dst.data_ptr(), src.numel() * src.element_size(), _stream()), "mftx_copy_bytes")
+    return dst
+
+
 def _chk(t, name, dtype=torch.float32):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise MftxError(f"{name} must be a CUDA(HIP) tensor")

@@ -133,6 +133,11 @@ class RAFTWrapper:
 
     def _device_image(self, img_bgr):
         img = img_bgr if isinstance(img_bgr, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img_bgr))
+        if not img.is_cuda and img.is_pinned() and img.is_contiguous() and img.dtype == torch.uint8 and img.data_ptr() % 16 == 0:
+            # a pinned host frame (mft_amd.video.FrameRing): uploaded by a copy KERNEL (16-byte coalesced reads over PCIe) on
+            # the current stream instead of hipMemcpyAsync -- no SDMA queue, nothing to serialise behind a pending download
+            dev = torch.empty(img.shape, dtype=torch.uint8, device=self.device)
+            return ops.copy_bytes(img, dev)
         return img.to(self.device, non_blocking=True).contiguous()
 
     @torch.no_grad()

@@ -122,11 +122,11 @@ class FrameRing:
         for frame in FrameRing(get_video_frames(path)):
             meta = tracker.track(frame)
 
-    The tracker's flow plugin uploads a frame with a non-blocking copy on the stream that encodes it (the encoder
-    side stream when ``C.async_encode`` is set): from pinned memory that copy is truly asynchronous -- the host
-    moves on to the next frame and the upload overlaps the previous frame's refinement -- and it needs no stream of
-    its own (HIP multiplexes streams onto a few hardware queues; a dedicated copy stream ended up behind queues
-    full of GEMM launches and stalled the loop for a frame time, ``tools/io_paths.py``).
+    The tracker's flow plugin uploads a pinned frame with a copy kernel (``mftx_copy_bytes``) on the stream that encodes it
+    (the encoder side stream when ``C.async_encode`` is set): the host moves on to the next frame and the upload
+    overlaps the previous frame's refinement.  (Round 2 blamed the SDMA queues for this ring and ``ResultDrain`` running at
+    a third of the resident rate together; the cause was on the host: filling the pinned buffer with torch's ``copy_``
+    ran a 786 kB memcpy on the whole intra-op thread pool, ``tools/io_paths3.py`` -- 45 vs 124 frames/s.)
 
     ``keep``: how many later frames a yielded frame stays valid for (its buffer is recycled after that); the default
     covers the tracker's memory ring (32 frames + the frames in flight).  ``streams``: the HIP streams the consumer
@@ -158,7 +158,9 @@ class FrameRing:
                 raise ValueError("all frames of a video must have the same size")
             for ev in self._events.pop(n % self.slots, ()):          # uploads of the frame this buffer held before
                 ev.synchronize()
-            buf.copy_(torch.from_numpy(frame))
+            # a plain memcpy: torch's CPU copy_ would run on the whole intra-op thread pool (128 threads on the GPU box) -- 4-7 ms
+            # for 786 kB, and its spinning workers then slow every host-side wait of the loop down (tools/io_paths3.py)
+            np.copyto(buf.numpy(), frame)
             yield buf
             if torch.cuda.is_available():                            # the consumer is back: its uploads of `buf` are enqueued
                 evs = []
@@ -192,8 +194,11 @@ class ResultDrain:
         if len(self._sets) <= slot:
             self._sets.append([torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in planes])
         host = self._sets[slot]
+        from . import ops
         for h, t in zip(host, planes):
-            h.copy_(t, non_blocking=True)
+            # a copy KERNEL on the caller's stream, not hipMemcpyAsync: a pinned download in the SDMA queue holds back the
+            # pinned uploads submitted behind it until the compute it waits for is done (profiles/r2_io_paths.txt)
+            ops.copy_bytes(t.contiguous(), h)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         self._queue.append((ev, host))
@@ -202,7 +207,7 @@ class ResultDrain:
     def collect(self, copy=False):
         ev, host = self._queue.pop(0)
         ev.synchronize()
-        return tuple(h.clone() for h in host) if copy else tuple(host)
+        return tuple(torch.from_numpy(h.numpy().copy()) for h in host) if copy else tuple(host)      # (numpy: a plain memcpy, see FrameRing)
 
     def __len__(self):
         return len(self._queue)

@@ -1005,8 +1005,9 @@ def test_conv_tile_shapes_bitwise():
     for tile in (6, 9, 10, 14):
         assert np.array_equal(outs[tile], outs[0]), tile
     # and for a pre-split A operand
-    outs = {tile: _tile_layers(2, tile, ref=(tile == 0)) for tile in (0, 6, 9, 10, 14)}
-    for tile in (6, 9, 10, 14):
+    # ... including the warp-specialised 128 x 128 tile (11: consumer waves multiply, producer waves stage)
+    outs = {tile: _tile_layers(2, tile, ref=(tile == 0)) for tile in (0, 6, 9, 10, 11, 14)}
+    for tile in (6, 9, 10, 11, 14):
         assert np.array_equal(outs[tile], outs[0]), tile
     # the measurement-only shapes (224 x 128, 112 x 256 on 16-row MFMAs) are not part of the product build
     from mft_amd.ops import MftxError

@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--a-split", action="store_true", help="A operand pre-split (split arithmetic)")
     ap.add_argument("--out-split", action="store_true", help="output written in split form")
     ap.add_argument("--enc", action="store_true", help="the encoder's layer shapes (one 512 x 512 frame) instead")
+    ap.add_argument("--tile", type=int, default=None, help="force the workgroup tile shape (mftx_conv2d_tile)")
     args = ap.parse_args()
     P, h, w = args.P, args.h, args.w
     M = P * h * w
@@ -87,12 +88,14 @@ def main():
         osplit = args.out_split and cout > 4
         obuf = torch.empty(M, -(-cout // 8) * 8, device=dev) if osplit else None
         for _ in range(3):
-            ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu", arith=args.arith, a_split=args.a_split, out_split=osplit, out=obuf)
+            ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu", arith=args.arith, a_split=args.a_split, out_split=osplit, out=obuf,
+                       tile=None if cout <= 4 else args.tile)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.reps):
-            ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu", arith=args.arith, a_split=args.a_split, out_split=osplit, out=obuf)
+            ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu", arith=args.arith, a_split=args.a_split, out_split=osplit, out=obuf,
+                       tile=None if cout <= 4 else args.tile)
         e1.record()
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) / args.reps * 1e-3
