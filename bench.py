@@ -495,8 +495,11 @@ def main():
             enc = getattr(tracker.flower, "_enc_stream", None)
             ring = FrameRing((host_frames[i] for i in range(base, base + n_io)), keep=40,
                              streams=[enc] if enc is not None else None).prepare(host_frames[0].shape)
-            drain = ResultDrain(depth=4)
+            drain = ResultDrain(depth=4).prepare(tracker.memory[tracker.current_frame_i]['result'])
             got = 0
+            # (the loop issues no CPU tensor math; torch's intra-op pool -- 128 threads on this host -- only adds wake-up and
+            # spin noise to the host-side waits: tools/io_paths3.py, 101 vs 124 frames/s)
+            torch.set_num_threads(1)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for frame in ring:

@@ -36,17 +36,14 @@ typedef _Float16 lf_f16x8 __attribute__((ext_vector_type(8)));
 constexpr int LF_GROUPS = 24;                       // 16-wide k groups: 4 levels x 6
 constexpr int LF_AROW = 400;                        // bytes per A row of a unit: 96 x 4 + 16 (rows r, r + 1 start 25 sixteen-byte slots apart: conflict-free ds_read_b128)
 constexpr int LF_AUNIT = 64 * LF_AROW;              // 25 600
-constexpr int LF_PATCH = 432;                       // bytes per window patch: 100 taps + 8 pad floats (finite: the dummy samples read them)
-constexpr int LF_NP = 3;                            // patch ring (units) per producer wave
-#ifndef MFTX_LF_LA
-#define MFTX_LF_LA 2
-#endif
-constexpr int LF_LA = MFTX_LF_LA;                            // a unit's gather is issued LF_LA + 1 steps before its conversion (<= LF_NP - 1)
+constexpr int LF_PATCH = 400;                       // bytes per window patch: the 100 taps of a cell and level, patches of a unit back to back
+constexpr int LF_PSLOT = 16 * LF_PATCH + 32;        // a unit's patches + 8 floats that stay zero (the last cell's dummy samples read them)
+constexpr int LF_NP = 3;                            // patch ring (units) per producer wave: a unit's gather is issued two steps before its conversion
 constexpr int LF_CPP = 16;                          // cells per producer wave and unit (at most)
 constexpr unsigned LF_WBYTES = LF_GROUPS * 4 * 4 * 1024;     // fused weights: [group][wave][fragment][lane] x 16 bytes
 constexpr unsigned LF_OOB = 0x80000000u;
 constexpr int LF_OFF_PATCH = 2 * LF_AUNIT;                                   // 51 200
-constexpr int LF_OFF_STAGE = LF_OFF_PATCH + 4 * LF_NP * LF_CPP * LF_PATCH;   // + 82 944
+constexpr int LF_OFF_STAGE = LF_OFF_PATCH + 4 * LF_NP * LF_PSLOT;            // + 77 184
 constexpr int LF_OFF_COORD = LF_OFF_STAGE + 4 * 4096;                        // + 16 384
 constexpr int LF_OFF_TAB = LF_OFF_COORD + 4 * 3 * 128;                       // + 1 536
 constexpr int LF_LDS = LF_OFF_TAB + 4 * LF_CPP * 32 * 4;                     // + 8 192 = 160 256 bytes
@@ -119,7 +116,8 @@ struct LfProducer {
     const LookupConvArgs &p;
     unsigned char *lds;
     int pw, lane, rpw, TR, my_tiles, U;
-    int c16, q, trA, tcA, trB, tcB;
+    int c16, q;
+    unsigned tap_rc[7][4];       // table indices (row entry | column entry << 16) of this lane's tap in DMA 4 i + e of a unit
     unsigned char *patches;
     float *cslots;
     unsigned *tab;               // row / column offsets of the windows being gathered: [cell][row 0..15 | column 0..15]
@@ -128,9 +126,9 @@ struct LfProducer {
 
     // VMEM operations of unit v's gather, and of the coordinate prefetch that follows a level-0 unit
 #ifdef MFTX_TUNING
-    __device__ __forceinline__ int n_gather(int v) const { return (v < U && !(p.ablate & 1)) ? 2 * ((rpw + 3) & ~3) : 0; }
+    __device__ __forceinline__ int n_gather(int v) const { return (v < U && !(p.ablate & 1)) ? ((p.ablate & 512) ? 10 : ((((rpw + 3) & ~3) * 100 + 63) >> 6)) : 0; }
 #else
-    __device__ __forceinline__ int n_gather(int v) const { return v < U ? 2 * ((rpw + 3) & ~3) : 0; }
+    __device__ __forceinline__ int n_gather(int v) const { return v < U ? ((((rpw + 3) & ~3) * 100 + 63) >> 6) : 0; }
 #endif
     __device__ __forceinline__ int n_coord(int v) const { return (v < U && (v & 3) == 0 && (v >> 2) + 1 < my_tiles) ? 1 : 0; }
 
@@ -173,7 +171,10 @@ struct LfProducer {
             const unsigned lim = kind ? W : H;
             const unsigned rowmul = blocked ? wb * 128u : W * 4u;
             const unsigned stride4 = (unsigned)stride * 4u;
-            for (int pass = 0; 2 * pass < ((rpw + 3) & ~3); ++pass) {
+            // (all 16 cells, used or not: the last DMA of a short unit runs a few taps into the next cell's table entries, which
+            // must say "outside" -- a stale entry could be a misaligned offset, and a misaligned dword of finite floats can be a
+            // NaN that the next cell's zero-weight dummy samples would spread over a whole row)
+            for (int pass = 0; pass < LF_CPP / 2; ++pass) {
                 const int ci = 2 * pass + (lane >> 5);
                 const float2 c = cs[ci];
                 const float sv = (kind ? c.x : c.y) * inv;
@@ -187,7 +188,7 @@ struct LfProducer {
                 tab[pass * 64 + lane] = ok ? val : 0x40000000u;
             }
         }
-        unsigned char *pdst = patches + (v % 3) * (LF_CPP * LF_PATCH);
+        unsigned char *pdst = patches + (v % 3) * LF_PSLOT;
         // ONE buffer descriptor per unit: this wave's cells are consecutive, their level slices lie `stride` floats apart --
         // phase 1 has folded cell * stride into the row entries, so a tap's offset is still one addition
         const int c0 = __builtin_amdgcn_readfirstlane(cell0 < p.cells ? cell0 : 0);
@@ -196,29 +197,36 @@ struct LfProducer {
 #ifdef MFTX_TUNING
         if (p.ablate & 1) { if (n_coord(v)) coords_issue(k + 1); return; }
 #endif
-        // taps 0..63 of every cell, then (lanes 0..35 only: a DMA stores for every enabled lane) taps 64..99; four cells at a
-        // time -- their table entries are read together, so the LDS latency shows once per four DMAs (cells past rpw in the
-        // last group carry out-of-range entries: zeros into patches nobody reads)
-        const int ng = (rpw + 3) & ~3;
-        {
-            const unsigned *tr_ = tab + trA, *tc_ = tab + 16 + tcA;
-            for (int i = 0; i < ng; i += 4) {
+        // The unit's taps form ONE array -- cell after cell, 100 each -- and a DMA instruction fetches 64 consecutive ones:
+        // 25 full instructions for 16 cells (two per cell would be 32, the second with 36 of 64 lanes: the texture unit
+        // charges a gather by the lane).  A lane's (cell, row, column) in DMA d never changes: their table addresses were
+        // worked out once (tap_r / tap_c).  Four DMAs at a time: their table entries are read together, so the LDS latency
+        // shows once per four.  (Taps past the last cell: table entries of unused cells -- anything goes, the patch is not read.)
+        const int nd = (((rpw + 3) & ~3) * 100 + 63) >> 6;
+#ifdef MFTX_TUNING
+        if (p.ablate & 512) {       // experiment (results are garbage): the unit's windows as 640 sixteen-byte pieces = 10 full x4 DMAs
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
                 unsigned o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = tr_[(i + e) * 32] + tc_[(i + e) * 32];
+                for (int e = 0; e < 4; ++e) o[e] = (tab[tap_rc[i][e] & 0xffffu] + tab[tap_rc[i][e] >> 16]) & ~15u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) lf_dma4(rs, pdst + (i + e) * LF_PATCH, o[e]);
+                for (int e = 0; e < 4; ++e)
+                    if (4 * i + e < 10) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(pdst + (4 * i + e) * 512), 16, o[e], 0, 0, 0);
             }
+            if (n_coord(v)) coords_issue(k + 1);
+            return;
         }
-        if (lane < 36) {
-            const unsigned *tr_ = tab + trB, *tc_ = tab + 16 + tcB;
-            for (int i = 0; i < ng; i += 4) {
-                unsigned o[4];
+#endif
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = tr_[(i + e) * 32] + tc_[(i + e) * 32];
+        for (int i = 0; i < 7; ++i) {            // (unrolled: tap_rc stays in registers)
+            if (4 * i >= nd) break;
+            unsigned o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) lf_dma4(rs, pdst + (i + e) * LF_PATCH + 256, o[e]);
-            }
+            for (int e = 0; e < 4; ++e) o[e] = tab[tap_rc[i][e] & 0xffffu] + tab[tap_rc[i][e] >> 16];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * i + e < nd) lf_dma4(rs, pdst + (4 * i + e) * 256, o[e]);
         }
         if (n_coord(v)) coords_issue(k + 1);
     }
@@ -233,7 +241,7 @@ struct LfProducer {
         level_coords(v, sx, sy);
         const float fx = sx - floorf(sx), fy = sy - floorf(sy);
         const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
-        const lf_f32x4 *src = reinterpret_cast<const lf_f32x4 *>(patches + (v % 3) * (LF_CPP * LF_PATCH) + c16 * LF_PATCH + q * 96);
+        const lf_f32x4 *src = reinterpret_cast<const lf_f32x4 *>(patches + (v % 3) * LF_PSLOT + c16 * LF_PATCH + q * 96);
         float T[36];
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
@@ -260,50 +268,60 @@ struct LfProducer {
         }
     }
 
-    // operations issued after unit v's gather at the moment unit v is converted: the coordinate prefetch behind it
-    // and the gathers of units v + 1 .. v + LF_LA with theirs (unit v + LF_LA + 1 follows the conversion)
-    __device__ __forceinline__ int younger(int v) const {
+    // operations issued after unit v's gather at the moment unit v is converted: the coordinate prefetch behind it and the
+    // gathers of the `ahead` units issued since, with theirs
+    __device__ __forceinline__ int younger(int v, int ahead) const {
         int n = n_coord(v);
-#pragma unroll
-        for (int a = 1; a <= LF_LA; ++a) n += n_gather(v + a) + n_coord(v + a);
+        for (int a = 1; a <= ahead; ++a) n += n_gather(v + a) + n_coord(v + a);
         return n;
     }
 
+    // Per step u (the consumers multiply unit u) every producer converts its cells of unit u + 1 and issues the gather of unit
+    // u + 3.  A gather keeps the texture unit busy and the wave's VALU idle, a conversion the other way round -- and the four
+    // producer waves would all do the one and then all the other.  So they are STAGGERED: waves 0, 1 convert first and
+    // gather second, waves 2, 3 gather first (into the patch slot unit u left a step ago) and convert second: at any time
+    // two waves feed the texture unit while two convert.
     __device__ __forceinline__ void run() {
         int tcount = 0; (void)tcount;
         LF_T(1);
-        // pad floats of my patches: finite for ever (no DMA reaches them)
-        if (lane < LF_NP * LF_CPP) {
-            lf_f32x4 *pad = reinterpret_cast<lf_f32x4 *>(patches + lane * LF_PATCH + 400);
-            pad[0] = lf_f32x4{0.f, 0.f, 0.f, 0.f};
-            pad[1] = lf_f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        const bool gather_first = pw >= 2;                       // (wave-uniform)
+        const int ahead = gather_first ? 2 : 1;                  // gathers younger than the unit being converted
+        // my patch slots start out as zeros: the dummy samples of a cell (k'' = 10 b + 9, k'' >= 90: zero weights) read up to 8
+        // taps past its 100 -- the next cell's, or the slot's pad, which no DMA reaches -- and must find finite values there
+        for (int i = lane; i < LF_NP * LF_PSLOT / 16; i += 64) reinterpret_cast<lf_f32x4 *>(patches)[i] = lf_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int g = 64 * (4 * i + e) + lane;                    // this lane's tap in the unit's array
+                const int cell = g / 100, t = g - 100 * cell, r = t / 10;
+                tap_rc[i][e] = cell < LF_CPP ? (unsigned)(cell * 32 + r) | ((unsigned)(cell * 32 + 16 + (t - 10 * r)) << 16) : 0u;
+            }
         coords_issue(0);
         lf_wait_vmcnt(0);
         LF_T(2);
-        for (int a = 0; a <= LF_LA; ++a)
+        for (int a = 0; a <= ahead; ++a)
             if (a < U) { gather(a); LF_T(3); }
-        lf_wait_vmcnt(younger(0));
+        lf_wait_vmcnt(younger(0, ahead));
         LF_T(4);
         convert(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         LF_T(5);
-        if (LF_LA + 1 < U) gather(LF_LA + 1);
-        LF_T(3);
+        if (!gather_first) { if (2 < U) gather(2); LF_T(3); }
         for (int u = 0; u < U; ++u) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             LF_T(6);
             lf_barrier();                    // unit u is complete in its slot; the consumers are done with unit u - 1
             LF_T(7);
+            if (gather_first) { if (u + 3 < U) gather(u + 3); LF_T(3); }
             if (u + 1 < U) {
-                lf_wait_vmcnt(younger(u + 1));
+                lf_wait_vmcnt(younger(u + 1, ahead));
                 LF_T(4);
                 convert(u + 1);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the conversion's patch reads are complete)
             LF_T(5);
-            if (u + LF_LA + 2 < U) gather(u + LF_LA + 2);    // (LF_LA = 2: into the patch slot unit u + 1 has just left)
-            LF_T(3);
+            if (!gather_first) { if (u + 3 < U) gather(u + 3); LF_T(3); }      // into the patch slot unit u + 1 has just left
         }
     }
 };
@@ -443,14 +461,20 @@ __global__ __launch_bounds__(512, 2) void lookup_convc1_kernel(LookupConvArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char lf_lds[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#ifdef MFTX_TUNING
+    if (p.ablate & 1024) {          // robustness check (tools/lf_stress.py): start from LDS full of NaNs -- nothing may depend on what it held
+        for (int i = threadIdx.x; i < LF_LDS / 4; i += blockDim.x) reinterpret_cast<unsigned *>(lf_lds)[i] = 0x7fc0beefu;
+        __syncthreads();
+    }
+#endif
     const int TR = 4 * p.rpw;
     const int my_tiles = (p.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;    // >= 1: the grid never exceeds n_tiles
     const int U = 4 * my_tiles;
     if (wid >= 4) {
         const int pw = wid - 4;
         LfProducer P{p, lf_lds, pw, lane, p.rpw, TR, my_tiles, U,
-                     lane & 15, lane >> 4, lane / 10, lane % 10, (lane + 64) / 10, (lane + 64) % 10,
-                     lf_lds + LF_OFF_PATCH + pw * (LF_NP * LF_CPP * LF_PATCH),
+                     lane & 15, lane >> 4, {},
+                     lf_lds + LF_OFF_PATCH + pw * (LF_NP * LF_PSLOT),
                      reinterpret_cast<float *>(lf_lds + LF_OFF_COORD + pw * (3 * 128)),
                      reinterpret_cast<unsigned *>(lf_lds + LF_OFF_TAB + pw * (LF_CPP * 32 * 4))};
         P.run();

@@ -186,6 +186,14 @@ class ResultDrain:
         self.depth = depth
         self._sets, self._queue, self._n = [], [], 0
 
+    def prepare(self, result):
+        """Pin all `depth` buffer sets now, for results shaped like `result` (pinning is slow -- milliseconds per buffer --
+        and otherwise happens inside the loop, during the first `depth` submits)."""
+        planes = result.planes() if hasattr(result, "planes") else tuple(result)
+        while len(self._sets) < self.depth:
+            self._sets.append([torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in planes])
+        return self
+
     def submit(self, result):
         planes = result.planes() if hasattr(result, "planes") else tuple(result)
         if len(self._queue) >= self.depth:

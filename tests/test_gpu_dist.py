@@ -36,3 +36,26 @@ def test_window_sharding_rccl_bitwise(tmp_path):
             # every exchanged frame is encoded exactly once across the ranks (the ragged last window of one
             # frame is shorter than the world size when n > 1: every rank encodes it itself)
             assert enc == (13 if n == 1 else 12), enc
+
+
+def test_bench_sharded_line_carries_roofline_and_ranks_seen():
+    """The N > 1 form of bench.py (forced here with the one visible GPU: RCCL process group of one rank, window-sharded
+    tracker, pipelined windows): its JSON line must carry what the N = 1 line carries -- `roofline`, `kernels` -- plus
+    `ranks_seen`, the sum over ranks of 1 by all-reduce, which the driver can hold against --gpus."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, str(repo / "bench.py"), "--gpus", "1", "--force-sharded", "--steps", "4", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-parity", "--no-alt-arith"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["steps"] == 4
+    assert "sharded" in d["config"]["parallelism"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and 0.05 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert "lookup_convc1_fused" in d["kernels"] and "conv_gemm" in d["kernels"]
+    assert d["pairs_per_frame"]["timed_min"] == 7

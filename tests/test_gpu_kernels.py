@@ -900,6 +900,32 @@ def test_lookup_convc1_fused_batch_and_tile_invariance(ops_mod):
         assert torch.equal(one.reshape(N, 256), whole[i])
 
 
+def test_lookup_convc1_independent_of_stale_lds(ops_mod):
+    """The fused kernel must not depend on what LDS held before it ran (it once did: a stale address-table entry of an
+    unused cell could be a misaligned offset, a misaligned dword of finite floats can be a NaN, and a zero-weight dummy
+    sample spread it over a row -- on the first launches of a fresh process only).  Here a GEMM over NaN operands leaves
+    every CU's LDS full of NaNs right before each launch; tools/lf_stress.py does the same with an in-kernel poison."""
+    g = torch.Generator().manual_seed(77)
+    nan_x = torch.full((7 * 64 * 64, 256), float("nan"), device=DEV)
+    nan_w = ops_mod.split_weights(ops_mod.pack_conv_weight(torch.zeros(256, 256, 3, 3, device=DEV)), check_range=False)
+    for P, h, w in ((2, 33, 50), (1, 16, 24), (7, 64, 64)):
+        N = h * w
+        f1 = torch.randn(P, N, 256, generator=g).to(DEV)
+        f2 = torch.randn(P, N, 256, generator=g).to(DEV)
+        lv = ops_mod.corr_pyramid(f1, f2, h, w, arith=ops_mod.ARITH_SPLIT)
+        coords = (torch.stack([pm(O.pixel_grid(h, w)[None])] * P).cpu() + 8 * torch.randn(P, N, 2, generator=g)).to(DEV).contiguous()
+        wpk = ops_mod.pack_conv_weight((torch.randn(256, 324, 1, 1, generator=g) * 0.05).to(DEV))
+        bias = torch.randn(256, generator=g).to(DEV)
+        wf = ops_mod.pack_lookup_convc1_weights(wpk)
+        ref = None
+        for rep in range(4):
+            ops_mod.conv2d(nan_x, nan_w, None, 7, 64, 64, 256, 3, 3, arith=ops_mod.ARITH_SPLIT)      # NaNs into every LDS
+            out = ops_mod.corr_lookup_convc1(lv, coords, h, w, wf, bias)
+            assert bool(torch.isfinite(out).all())
+            ref = out.clone() if ref is None else ref
+            assert torch.equal(out, ref), (P, h, w, rep)
+
+
 def test_lookup_convc1_argument_errors(ops_mod):
     h, w = 16, 16
     stride, _ = ops_mod.pyramid_layout(h, w)
