@@ -46,7 +46,7 @@ constexpr int LF_OFF_PATCH = 2 * LF_AUNIT;                                   // 
 constexpr int LF_OFF_STAGE = LF_OFF_PATCH + 4 * LF_NP * LF_PSLOT;            // + 77 184
 constexpr int LF_OFF_COORD = LF_OFF_STAGE + 4 * 4096;                        // + 16 384
 constexpr int LF_OFF_TAB = LF_OFF_COORD + 4 * 3 * 128;                       // + 1 536
-constexpr int LF_LDS = LF_OFF_TAB + 4 * LF_CPP * 32 * 4;                     // + 8 192 = 160 256 bytes
+constexpr int LF_LDS = LF_OFF_TAB + 4 * LF_CPP * 32 * 4;                     // + 8 192 = 154 496 bytes
 
 // Tuning builds only (-DMFTX_LF_TRACE): s_memtime stamps of workgroup 0's waves at the pipeline's events, read back with
 // mftx_debug_lf_trace (tools/lf_trace.py): [wave][event] = (code << 56) | ticks
@@ -71,7 +71,7 @@ struct LookupConvArgs {
     int ld_out, out_split;
     int rpw;                    // cells per producer wave and tile: a tile is 4 rpw cells
     int n_tiles;
-    int ablate;                 // tuning builds only (MFTX_LF_ABLATE): 1 no window gathers, 2 no MFMAs, 4 no conversion, 8 no weight loads, 16 no stores
+    int ablate;                 // tuning builds only (MFTX_LF_ABLATE): 1 no window gathers, 2 no MFMAs, 4 no conversion, 8 no weight loads, 16 no stores, 1024 LDS poisoned with NaNs first
 };
 
 __device__ __forceinline__ void lf_barrier() {
@@ -126,7 +126,7 @@ struct LfProducer {
 
     // VMEM operations of unit v's gather, and of the coordinate prefetch that follows a level-0 unit
 #ifdef MFTX_TUNING
-    __device__ __forceinline__ int n_gather(int v) const { return (v < U && !(p.ablate & 1)) ? ((p.ablate & 512) ? 10 : ((((rpw + 3) & ~3) * 100 + 63) >> 6)) : 0; }
+    __device__ __forceinline__ int n_gather(int v) const { return (v < U && !(p.ablate & 1)) ? ((((rpw + 3) & ~3) * 100 + 63) >> 6) : 0; }
 #else
     __device__ __forceinline__ int n_gather(int v) const { return v < U ? ((((rpw + 3) & ~3) * 100 + 63) >> 6) : 0; }
 #endif
@@ -149,123 +149,160 @@ struct LfProducer {
         sy = c.y * inv;
     }
 
-    // gather of unit v: two DMA instructions per cell (taps 0..63, 64..99) into patch slot v % 3.
+    // gather of unit v into patch slot v % 3.
     //   The VALU pipe of a SIMD is all a producer wave has (one instruction per four cycles), so the address arithmetic is
     // done ONCE per row and column of a window instead of once per tap: phase 1 forms, two cells per pass -- lane =
     // (cell & 1, row | column, j) --, the byte offset of window row j (or column j) inside the query's level slice, or a
     // large value where the row / column lies outside the level (any sum with it is out of range = a zero, as
     // grid_sample pads), into a small LDS table; phase 2 adds one row and one column entry per tap.
-    __device__ __forceinline__ void gather(int v) {
+    struct GatherCtx { __amdgpu_buffer_rsrc_t rs; unsigned char *pdst; const unsigned *tb; int nd; };
+    struct ConvCtx { float T[36]; float w00, w01, w10, w11; unsigned char *dst; bool live; };
+    // what a unit's address-table passes need: level geometry, this lane's (cell of a pass, row | column, j) and the
+    // coordinates of its six cells (read together: one LDS round trip)
+    struct TableCtx {
+        float inv; unsigned H, W, rowmul, stride4, lim; bool blocked; int cell0, cl, kind, j;
+        float2 cv[6]; unsigned *tb;
+    };
+
+    __device__ __forceinline__ void level_geometry(int v, const float *&base, long long &stride, unsigned &H, unsigned &W, unsigned &wb) const {
+        const int l = v & 3;
+        base = l == 0 ? p.lvl[0] : l == 1 ? p.lvl[1] : l == 2 ? p.lvl[2] : p.lvl[3];
+        stride = l == 0 ? p.stride[0] : l == 1 ? p.stride[1] : l == 2 ? p.stride[2] : p.stride[3];
+        H = (unsigned)(l == 0 ? p.hl[0] : l == 1 ? p.hl[1] : l == 2 ? p.hl[2] : p.hl[3]);
+        W = (unsigned)(l == 0 ? p.wl[0] : l == 1 ? p.wl[1] : l == 2 ? p.wl[2] : p.wl[3]);
+        wb = (unsigned)(l == 0 ? p.wb0 : p.wb1);
+    }
+
+    // The address table of unit v, three cells per pass.
+    __device__ __forceinline__ void table_begin(int v, TableCtx &t) {
         const int k = v >> 2, l = v & 3;
-        const float inv = l == 0 ? 1.f : l == 1 ? 0.5f : l == 2 ? 0.25f : 0.125f;     // (x / 2^l, exactly)
-        const float *base = l == 0 ? p.lvl[0] : l == 1 ? p.lvl[1] : l == 2 ? p.lvl[2] : p.lvl[3];
-        const long long stride = l == 0 ? p.stride[0] : l == 1 ? p.stride[1] : l == 2 ? p.stride[2] : p.stride[3];
-        const unsigned H = (unsigned)(l == 0 ? p.hl[0] : l == 1 ? p.hl[1] : l == 2 ? p.hl[2] : p.hl[3]);
-        const unsigned W = (unsigned)(l == 0 ? p.wl[0] : l == 1 ? p.wl[1] : l == 2 ? p.wl[2] : p.wl[3]);
-        const unsigned wb = (unsigned)(l == 0 ? p.wb0 : p.wb1);
-        const bool blocked = l < 2;
-        const int cell0 = tile_of(k) * TR + pw * rpw;
+        const float *base; long long stride; unsigned wb;
+        level_geometry(v, base, stride, t.H, t.W, wb);
+        t.inv = l == 0 ? 1.f : l == 1 ? 0.5f : l == 2 ? 0.25f : 0.125f;     // (x / 2^l, exactly)
+        t.blocked = l < 2;
+        t.rowmul = t.blocked ? wb * 128u : t.W * 4u;
+        t.stride4 = (unsigned)stride * 4u;
+        t.cell0 = tile_of(k) * TR + pw * rpw;
+        // three cells per pass: lane = (cell of the pass, row | column, j < 10)
+        t.cl = lane / 20;
+        const int rem = lane - 20 * t.cl;
+        t.kind = rem >= 10 ? 1 : 0;
+        t.j = rem - 10 * t.kind;
+        t.lim = t.kind ? t.W : t.H;
+        t.tb = tab;
         const float2 *cs = reinterpret_cast<const float2 *>(cslots + (k % 3) * 32);
-        {
-            const int kind = (lane >> 4) & 1, j = lane & 15;
-            const unsigned lim = kind ? W : H;
-            const unsigned rowmul = blocked ? wb * 128u : W * 4u;
-            const unsigned stride4 = (unsigned)stride * 4u;
-            // (all 16 cells, used or not: the last DMA of a short unit runs a few taps into the next cell's table entries, which
-            // must say "outside" -- a stale entry could be a misaligned offset, and a misaligned dword of finite floats can be a
-            // NaN that the next cell's zero-weight dummy samples would spread over a whole row)
-            for (int pass = 0; pass < LF_CPP / 2; ++pass) {
-                const int ci = 2 * pass + (lane >> 5);
-                const float2 c = cs[ci];
-                const float sv = (kind ? c.x : c.y) * inv;
-                // clamp so that the int conversion is defined for wild coordinates
-                const unsigned vv = (unsigned)((int)fminf(fmaxf(floorf(sv), -1.0e6f), 1.0e6f) - 4 + j);
-                unsigned val;
-                if (blocked) val = kind ? (vv >> 3) * 128u + (vv & 7u) * 4u : (vv >> 2) * rowmul + (vv & 3u) * 32u;
-                else val = kind ? vv * 4u : vv * rowmul;
-                if (!kind) val += (unsigned)ci * stride4;        // this cell's slice inside the unit's buffer
-                const bool ok = (ci < rpw) & (cell0 + ci < p.cells) & (j < 10) & (vv < lim);
-                tab[pass * 64 + lane] = ok ? val : 0x40000000u;
-            }
-        }
-        unsigned char *pdst = patches + (v % 3) * LF_PSLOT;
+#pragma unroll
+        for (int pass = 0; pass < 6; ++pass) t.cv[pass] = cs[min(3 * pass + t.cl, LF_CPP - 1)];
+    }
+    // (all 16 cells, used or not: the last DMA of a short unit runs a few taps into the next cell's table entries, which must say
+    // "outside" -- a stale entry could be a misaligned offset, and a misaligned dword of finite floats can be a NaN that the
+    // next cell's zero-weight dummy samples would spread over a whole row)
+    __device__ __forceinline__ void table_pass(const TableCtx &t, int pass) {
+        const int ci = 3 * pass + t.cl;
+        const float sv = (t.kind ? t.cv[pass].x : t.cv[pass].y) * t.inv;
+        // clamp so that the int conversion is defined for wild coordinates
+        const unsigned vv = (unsigned)((int)fminf(fmaxf(floorf(sv), -1.0e6f), 1.0e6f) - 4 + t.j);
+        unsigned val;
+        if (t.blocked) val = t.kind ? (vv >> 3) * 128u + (vv & 7u) * 4u : (vv >> 2) * t.rowmul + (vv & 3u) * 32u;
+        else val = t.kind ? vv * 4u : vv * t.rowmul;
+        if (!t.kind) val += (unsigned)ci * t.stride4;        // this cell's slice inside the unit's buffer
+        const bool ok = (ci < rpw) & (t.cell0 + ci < p.cells) & (vv < t.lim);
+        if (lane < 60 && ci < LF_CPP) t.tb[ci * 32 + t.kind * 16 + t.j] = ok ? val : 0x40000000u;
+    }
+
+    // what unit v's DMA groups need
+    __device__ __forceinline__ GatherCtx gather_begin(int v) {
+        GatherCtx G;
+        const float *base; long long stride; unsigned H, W, wb;
+        level_geometry(v, base, stride, H, W, wb);
+        const int cell0 = tile_of(v >> 2) * TR + pw * rpw;
+        G.pdst = patches + (v % 3) * LF_PSLOT;
+        G.tb = tab;
         // ONE buffer descriptor per unit: this wave's cells are consecutive, their level slices lie `stride` floats apart --
-        // phase 1 has folded cell * stride into the row entries, so a tap's offset is still one addition
+        // the table has cell * stride folded into its row entries, so a tap's offset is still one addition
         const int c0 = __builtin_amdgcn_readfirstlane(cell0 < p.cells ? cell0 : 0);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float *>(base + (long long)c0 * stride), 0, (unsigned)rpw * (unsigned)stride * 4u, 0x00020000);
-#ifdef MFTX_TUNING
-        if (p.ablate & 1) { if (n_coord(v)) coords_issue(k + 1); return; }
-#endif
+        G.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base + (long long)c0 * stride), 0, (unsigned)rpw * (unsigned)stride * 4u, 0x00020000);
         // The unit's taps form ONE array -- cell after cell, 100 each -- and a DMA instruction fetches 64 consecutive ones:
-        // 25 full instructions for 16 cells (two per cell would be 32, the second with 36 of 64 lanes: the texture unit
-        // charges a gather by the lane).  A lane's (cell, row, column) in DMA d never changes: their table addresses were
-        // worked out once (tap_r / tap_c).  Four DMAs at a time: their table entries are read together, so the LDS latency
-        // shows once per four.  (Taps past the last cell: table entries of unused cells -- anything goes, the patch is not read.)
-        const int nd = (((rpw + 3) & ~3) * 100 + 63) >> 6;
-#ifdef MFTX_TUNING
-        if (p.ablate & 512) {       // experiment (results are garbage): the unit's windows as 640 sixteen-byte pieces = 10 full x4 DMAs
+        // 25 full instructions for 16 cells.  A lane's (cell, row, column) in DMA d never changes: their table addresses were
+        // worked out once (tap_rc).  (Taps past the last cell: table entries that say "outside" -- zeros into a patch nobody reads.)
+        G.nd = n_gather(v);
+        return G;
+    }
+
+    // DMAs 4 i .. 4 i + 3 of a unit's gather: their table entries are read together, so the LDS latency shows once per four
+    __device__ __forceinline__ void dma_group(const GatherCtx &G, int i) {
+        unsigned o[4];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                unsigned o[4];
+        for (int e = 0; e < 4; ++e) o[e] = G.tb[tap_rc[i][e] & 0xffffu] + G.tb[tap_rc[i][e] >> 16];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (tab[tap_rc[i][e] & 0xffffu] + tab[tap_rc[i][e] >> 16]) & ~15u;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * i + e < 10) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(pdst + (4 * i + e) * 512), 16, o[e], 0, 0, 0);
-            }
-            if (n_coord(v)) coords_issue(k + 1);
-            return;
-        }
-#endif
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {            // (unrolled: tap_rc stays in registers)
-            if (4 * i >= nd) break;
-            unsigned o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = tab[tap_rc[i][e] & 0xffffu] + tab[tap_rc[i][e] >> 16];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (4 * i + e < nd) lf_dma4(rs, pdst + (4 * i + e) * 256, o[e]);
-        }
-        if (n_coord(v)) coords_issue(k + 1);
+        for (int e = 0; e < 4; ++e)
+            if (4 * i + e < G.nd) lf_dma4(G.rs, G.pdst + (4 * i + e) * 256, o[e]);
     }
 
     // conversion of unit v: lane (cell c16, quarter q) blends samples k'' = 24 q .. 24 q + 23 of its cell and stores
-    // their halves into the A slot v & 1
-    __device__ __forceinline__ void convert(int v) {
-#ifdef MFTX_TUNING
-        if (p.ablate & 4) return;
-#endif
+    // their halves into the A slot v & 1 -- in three chunks of eight samples, so that the DMAs of the next gather can be issued
+    // between them (a DMA holds the wave that issues the NEXT one; VALU work slotted in between is free)
+    __device__ __forceinline__ void conv_load(int v, ConvCtx &C) {
         float sx, sy;
         level_coords(v, sx, sy);
         const float fx = sx - floorf(sx), fy = sy - floorf(sy);
-        const float w00 = (1.f - fx) * (1.f - fy), w01 = fx * (1.f - fy), w10 = (1.f - fx) * fy, w11 = fx * fy;
+        C.w00 = (1.f - fx) * (1.f - fy); C.w01 = fx * (1.f - fy); C.w10 = (1.f - fx) * fy; C.w11 = fx * fy;
         const lf_f32x4 *src = reinterpret_cast<const lf_f32x4 *>(patches + (v % 3) * LF_PSLOT + c16 * LF_PATCH + q * 96);
-        float T[36];
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const lf_f32x4 t = src[i];
-            T[4 * i] = t[0]; T[4 * i + 1] = t[1]; T[4 * i + 2] = t[2]; T[4 * i + 3] = t[3];
+            C.T[4 * i] = t[0]; C.T[4 * i + 1] = t[1]; C.T[4 * i + 2] = t[2]; C.T[4 * i + 3] = t[3];
         }
+        C.dst = lds + (v & 1) * LF_AUNIT + (pw * rpw + c16) * LF_AROW + q * 96;
+        C.live = c16 < rpw;
+    }
+    __device__ __forceinline__ void conv_chunk(const ConvCtx &C, int g8) {
         const float k2048 = 2048.f;
-        unsigned char *dst = lds + (v & 1) * LF_AUNIT + (pw * rpw + c16) * LF_AROW + q * 96;
-        const bool live = c16 < rpw;
+        unsigned h[4], l[4];
 #pragma unroll
-        for (int g8 = 0; g8 < 3; ++g8) {
-            unsigned h[4], l[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int j = 8 * g8 + 2 * e;
-                const float v0 = T[j] * w00 + T[j + 1] * w01 + T[j + 10] * w10 + T[j + 11] * w11;
-                const float v1 = T[j + 1] * w00 + T[j + 2] * w01 + T[j + 11] * w10 + T[j + 12] * w11;
-                lf_split_pair(v0, v1, k2048, h[e], l[e]);
-            }
-            if (live) {
-                *reinterpret_cast<lf_u32x4 *>(dst + g8 * 32) = lf_u32x4{h[0], h[1], h[2], h[3]};
-                *reinterpret_cast<lf_u32x4 *>(dst + g8 * 32 + 16) = lf_u32x4{l[0], l[1], l[2], l[3]};
-            }
+        for (int e = 0; e < 4; ++e) {
+            const int j = 8 * g8 + 2 * e;
+            const float v0 = C.T[j] * C.w00 + C.T[j + 1] * C.w01 + C.T[j + 10] * C.w10 + C.T[j + 11] * C.w11;
+            const float v1 = C.T[j + 1] * C.w00 + C.T[j + 2] * C.w01 + C.T[j + 11] * C.w10 + C.T[j + 12] * C.w11;
+            lf_split_pair(v0, v1, k2048, h[e], l[e]);
         }
+        if (C.live) {
+            *reinterpret_cast<lf_u32x4 *>(C.dst + g8 * 32) = lf_u32x4{h[0], h[1], h[2], h[3]};
+            *reinterpret_cast<lf_u32x4 *>(C.dst + g8 * 32 + 16) = lf_u32x4{l[0], l[1], l[2], l[3]};
+        }
+    }
+
+    // One step of a producer: the gather of unit vg (-1: none) and the conversion of unit vc (-1: none).  vg's address table
+    // first (VALU + LDS), then the wait for vc's patches (nothing of vg is in flight yet: only unit vc + 1's gather is
+    // younger), vc's patch reads, and then vg's DMA groups with a chunk of vc's conversion behind each of the first three.
+    // (A producer wave is one in-order instruction stream: measured, its step is the SUM of table, DMA issue and conversion
+    // whatever the interleaving -- working the table out a step ahead, pass by pass between the DMAs, was 5 % slower.)
+    __device__ __forceinline__ void work(int vg, int vc) {
+        GatherCtx G{};
+        ConvCtx C;
+        if (vg >= 0) {
+            TableCtx t;
+            table_begin(vg, t);
+#pragma unroll
+            for (int pass = 0; pass < 6; ++pass) table_pass(t, pass);
+            G = gather_begin(vg);
+        }
+#ifdef MFTX_TUNING
+        if (p.ablate & 1) G.nd = 0;
+        if (p.ablate & 4) vc = -1;
+#endif
+        if (vc >= 0) {
+            lf_wait_vmcnt(younger(vc, 1));
+            conv_load(vc, C);
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {            // (unrolled: tap_rc stays in registers)
+            if (vg >= 0 && 4 * i < G.nd) dma_group(G, i);
+            __builtin_amdgcn_sched_barrier(0);
+            if (vc >= 0 && i < 3) conv_chunk(C, i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (vg >= 0 && n_coord(vg)) coords_issue((vg >> 2) + 1);
     }
 
     // operations issued after unit v's gather at the moment unit v is converted: the coordinate prefetch behind it and the
@@ -276,16 +313,11 @@ struct LfProducer {
         return n;
     }
 
-    // Per step u (the consumers multiply unit u) every producer converts its cells of unit u + 1 and issues the gather of unit
-    // u + 3.  A gather keeps the texture unit busy and the wave's VALU idle, a conversion the other way round -- and the four
-    // producer waves would all do the one and then all the other.  So they are STAGGERED: waves 0, 1 convert first and
-    // gather second, waves 2, 3 gather first (into the patch slot unit u left a step ago) and convert second: at any time
-    // two waves feed the texture unit while two convert.
+    // Per step u (the consumers multiply unit u) every producer converts its cells of unit u + 1 and issues the gather of
+    // unit u + 3 (into the patch slot unit u left a step ago), interleaved (work()).
     __device__ __forceinline__ void run() {
         int tcount = 0; (void)tcount;
         LF_T(1);
-        const bool gather_first = pw >= 2;                       // (wave-uniform)
-        const int ahead = gather_first ? 2 : 1;                  // gathers younger than the unit being converted
         // my patch slots start out as zeros: the dummy samples of a cell (k'' = 10 b + 9, k'' >= 90: zero weights) read up to 8
         // taps past its 100 -- the next cell's, or the slot's pad, which no DMA reaches -- and must find finite values there
         for (int i = lane; i < LF_NP * LF_PSLOT / 16; i += 64) reinterpret_cast<lf_f32x4 *>(patches)[i] = lf_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -300,28 +332,21 @@ struct LfProducer {
         coords_issue(0);
         lf_wait_vmcnt(0);
         LF_T(2);
-        for (int a = 0; a <= ahead; ++a)
-            if (a < U) { gather(a); LF_T(3); }
-        lf_wait_vmcnt(younger(0, ahead));
-        LF_T(4);
-        convert(0);
+        work(0, -1);
+        LF_T(3);
+        work(1 < U ? 1 : -1, -1);
+        LF_T(3);
+        work(2 < U ? 2 : -1, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         LF_T(5);
-        if (!gather_first) { if (2 < U) gather(2); LF_T(3); }
         for (int u = 0; u < U; ++u) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             LF_T(6);
             lf_barrier();                    // unit u is complete in its slot; the consumers are done with unit u - 1
             LF_T(7);
-            if (gather_first) { if (u + 3 < U) gather(u + 3); LF_T(3); }
-            if (u + 1 < U) {
-                lf_wait_vmcnt(younger(u + 1, ahead));
-                LF_T(4);
-                convert(u + 1);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the conversion's patch reads are complete)
+            work(u + 3 < U ? u + 3 : -1, u + 1 < U ? u + 1 : -1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the conversion's patch reads and A stores are complete)
             LF_T(5);
-            if (!gather_first) { if (u + 3 < U) gather(u + 3); LF_T(3); }      // into the patch slot unit u + 1 has just left
         }
     }
 };

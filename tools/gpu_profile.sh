@@ -3,22 +3,38 @@
 #   bash tools/gpu_profile.sh <tag>          -> gpurun_out/<tag>/...  (copy what is to be judged into profiles/)
 # PMC passes run with --kernel-trace only (no other trace domains), one counter set per pass.
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python bench.py --steps 20 --warmup 5"
 # per-kernel passes: one batch, one stream, encoders on the main stream -> every kernel runs alone, like bench.py's own
 # HIP-event pass (the timed region of the default run overlaps two half-batches and the next frame's encoders)
-QUIET="--no-cpu-baseline --no-profile --no-parity --no-host-io --sync-encode --no-alt-arith"
+QUIET="--no-cpu-baseline --no-profile --no-parity --no-host-io --sync-encode --no-alt-arith --no-graphs"
 
 $BENCH > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
+# A/B of the round's two structural changes, same box, same run
+$BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-graphs > $OUT/bench_no_graphs.json 2>/dev/null; echo "bench no-graphs rc=$?"
+$BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-fused-lookup > $OUT/bench_no_fused_lookup.json 2>/dev/null; echo "bench no-fused-lookup rc=$?"
+python bench.py --steps 20 --warmup 5 --height 256 --width 256 --no-cpu-baseline --no-parity --no-alt-arith > $OUT/bench_256.json 2>/dev/null
+python bench.py --steps 5 --warmup 2 --height 1080 --width 1920 --no-cpu-baseline --no-parity --no-alt-arith --no-host-io > $OUT/bench_1080p.json 2>/dev/null
+python bench.py --steps 20 --warmup 5 --force-sharded --no-cpu-baseline --no-parity --no-alt-arith > $OUT/bench_forced_sharded_x1.json 2>/dev/null
+(for g in 2 4 8; do python bench.py --steps 20 --warmup 5 --force-sharded --emulate-world $g --no-cpu-baseline --no-parity --no-alt-arith --no-profile 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('emulated world $g (driver flags):', round(d['value'],1), 'frames/s')"; done; python bench.py --steps 80 --warmup 5 --force-sharded --emulate-world 8 --no-cpu-baseline --no-parity --no-alt-arith --no-profile 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('emulated world 8 (80 steps):', round(d['value'],1), 'frames/s')") > $OUT/emulated_world.txt
+IO_ALL=1 timeout 300 python tools/io_paths3.py 2>&1 | grep -v amdgpu.ids > $OUT/io_paths.txt; IO_ALL=1 IO_THREADS=1 timeout 300 python tools/io_paths3.py 2>&1 | grep -v amdgpu.ids >> $OUT/io_paths.txt
+timeout 100 python tools/io_kernel_copy.py 2>&1 | grep -v amdgpu.ids >> $OUT/io_paths.txt
+timeout 300 python tools/lf_stress.py 2>&1 | grep -v amdgpu.ids > $OUT/lf_stress.txt
+(for s in "7 64 64" "1 64 64" "7 136 240"; do timeout 200 python tools/bench_lookup_fused.py $s 2>&1 | tail -1; done) > $OUT/lookup_fused_micro.txt
+if [ -f build_tune/libmftx_tune.so ]; then
+  (echo "# tools/lf_trace.py on a -DMFTX_TUNING -DMFTX_LF_TRACE build (tools/build_tuning.sh): s_memtime stamps of workgroup 0, P = 7, 64 x 64"
+   MFTX_LIB=$PWD/build_tune/libmftx_tune.so timeout 200 python tools/lf_trace.py 2>&1 | grep -v amdgpu.ids
+   for a in 1 2 8 10 32 64 128 512 1024; do echo "== MFTX_LF_ABLATE=$a"; MFTX_LIB=$PWD/build_tune/libmftx_tune.so MFTX_LF_ABLATE=$a timeout 200 python tools/lf_trace.py 2>&1 | tail -4; done) > $OUT/lf_trace.txt
+fi
 $BENCH --arith fp32 --no-cpu-baseline --no-host-io --no-alt-arith > $OUT/bench_fp32_arith.json 2> $OUT/bench_fp32.err; echo "bench fp32 rc=$?"
 for a in 0 1; do echo "== arithmetic $a (0 fp32 MFMA, 1 split fp16): error against an fp64 convolution"; timeout 200 python tools/conv_arith_error.py $a 2>&1 | grep -v amdgpu.ids; done > $OUT/conv_arith_error.txt
 (timeout 100 tools/micro/mfma_shadow; timeout 100 tools/micro/lds_fill) > $OUT/micro_mfma_shadow_lds_fill.txt 2>&1
 for t in bench_lookup bench_small bench_corr; do timeout 120 python tools/$t.py 2>&1 | grep -v amdgpu.ids; done > $OUT/micro.txt
 timeout 300 python tools/bench_pairs.py > $OUT/bench_pairs.txt 2>/dev/null
-(echo "== split fp16 arithmetic"; timeout 300 python tools/bench_conv.py --P 7 --arith 1; echo "== fp32 MFMA"; timeout 300 python tools/bench_conv.py --P 7 --arith 0; echo "== encoder layers, split"; timeout 100 python tools/bench_conv.py --enc --arith 1) 2>/dev/null | grep -v amdgpu.ids > $OUT/bench_conv_P7.txt
+(echo "== split fp16 arithmetic, A and outputs in split form (what the engine runs)"; timeout 300 python tools/bench_conv.py --P 7 --arith 1 --a-split --out-split; echo "== the same on the warp-specialised 128 x 128 tile (11)"; timeout 300 python tools/bench_conv.py --P 7 --arith 1 --a-split --out-split --tile 11; echo "== split fp16 arithmetic, fp32 operands"; timeout 300 python tools/bench_conv.py --P 7 --arith 1; echo "== fp32 MFMA"; timeout 300 python tools/bench_conv.py --P 7 --arith 0; echo "== encoder layers, split"; timeout 100 python tools/bench_conv.py --enc --arith 1) 2>/dev/null | grep -v amdgpu.ids > $OUT/bench_conv_P7.txt
 
 MFTX_SPLIT_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof/trace -o bench -- $BENCH $QUIET > /dev/null 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -34,5 +50,11 @@ for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_E
   timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/prof/lk_$n -o lk -- python tools/bench_lookup.py > /dev/null 2>&1
 done
 python tools/pmc_kernel_table.py $OUT/prof corr_lookup > $OUT/pmc_lookup_requests_raw.txt 2>&1
+# the same memory-side counters, and the texture unit's, for the fused lookup + convc1 kernel
+for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum TCC_READ_sum" "TA_BUSY_avr TA_TA_BUSY_sum TA_BUFFER_LOAD_WAVEFRONTS_sum TA_BUFFER_WAVEFRONTS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS"; do
+  n=$(echo $set | md5sum | cut -c1-6)
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/prof/lf_$n -o lf -- python tools/bench_lookup_fused.py > /dev/null 2>&1
+done
+python tools/pmc_kernel_table.py $OUT/prof lookup_convc1 > $OUT/pmc_lookup_fused_raw.txt 2>&1
 rm -rf $OUT/prof/*/*/   # the per-host raw directories (large)
 du -sh $OUT
