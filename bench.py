@@ -57,8 +57,8 @@ F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16 /
 SPLIT_PRODUCTS = 3              # split arithmetic: fp16 MFMA products per fp32 product (hi hi + hi lo + lo hi)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak
 CATS = ["corr_volume_gemm", "corr_pool", "corr_lookup", "conv_gemm", "convf1", "glue", "convex_upsample",
-        "chain_select", "conv_small_n", "encoder_instnorm", "lookup_convc1_fused"]
-FLOP_CATS = {0, 3, 4, 8}
+        "chain_select", "conv_small_n", "encoder_instnorm", "lookup_convc1_fused", "flow_branch_fused"]
+FLOP_CATS = {0, 3, 4, 8, 11}
 VALU_CATS = {4, 8}
 FULL_PAIRS = 7                  # flow pairs per frame once every delta is live
 FIRST_FULL_FRAME = 33           # first frame index with FULL_PAIRS pairs (forward tracking from frame 0)
@@ -101,6 +101,9 @@ def build_tracker(args, sharded):
         opts["graph"] = 0                     # plain launches instead of hipGraph replays (A/B)
     if getattr(args, "no_fused_lookup", False):
         opts["fuse_lookup"] = 0               # lookup and convc1 as two kernels (A/B)
+    for kv in getattr(args, "engine_opt", None) or []:
+        k, _, v = kv.partition("=")
+        opts[k] = int(v)                      # A/B of a scheduling option of the refinement engine (mft_amd.ops.RaftEngine.OPTIONS)
     if opts:
         conf.flow_config.raft_params.engine_options = opts
     conf.keep_result_on_device = True
@@ -140,7 +143,7 @@ def profile_pass(tracker, frames, first, steps, arith="split"):
         if i in FLOP_CATS:
             d.update(unit="TFLOP/s", achieved=work[i] / t / 1e12, peak=FP32_MFMA_PEAK_TFLOPS,
                      bound="valu" if i in VALU_CATS else "mfma", work_per_launch=work[i] / cnt[i])
-            if name in ("conv_gemm", "corr_volume_gemm") and arith == "split":
+            if name in ("conv_gemm", "corr_volume_gemm", "flow_branch_fused") and arith == "split":
                 # the update block's GEMMs run every fp32 product as three fp16 MFMA products: the matrix work actually
                 # executed is 3 x the algorithmic flops, priced against the fp16 MFMA peak; the algorithmic rate is kept
                 # next to it (it may exceed the fp32 MFMA peak, which this path does not use)
@@ -314,6 +317,8 @@ def main():
     ap.add_argument("--no-alt-arith", action="store_true", help="skip the short pass in the other arithmetic")
     ap.add_argument("--no-graphs", action="store_true", help="A/B: plain kernel launches instead of hipGraph replays")
     ap.add_argument("--no-fused-lookup", action="store_true", help="A/B: correlation lookup and convc1 as two kernels")
+    ap.add_argument("--engine-opt", action="append", metavar="NAME=INT",
+                    help="A/B: a scheduling option of the refinement engine, e.g. fork=0 (results do not depend on it)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="with --force-sharded on ONE GPU: behave like rank 0 of this many ranks (compute only that rank's "
                          "share of every window; the other ranks' slots of the all-gathers are filled with copies of the "

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MFTX_VERSION 300
+#define MFTX_VERSION 301
 
 #define MFTX_E_ARG (-1)      /* null pointer / non-positive size / unsupported shape */
 #define MFTX_E_ALIGN (-2)    /* pointer or leading dimension not 16-byte aligned */
@@ -49,9 +49,10 @@ const char *mftx_last_error_string(void);
 /* Optional per-kernel timing (HIP events on the launch stream; bench.py's
  * roofline leg).  Categories: 0 corr volume GEMM, 1 pyramid pooling, 2 lookup,
  * 3 conv implicit GEMM, 4 convf1, 5 glue, 6 convex upsample, 7 chain/select,
- * 8 small-N conv, 9 encoder instance-norm passes, 10 lookup fused into convc1.
- * work[] = algorithmic flops (0, 3, 4, 8) or bytes (1, 2, 6, 7, 9, 10) booked per launch. */
-#define MFTX_PROFILE_CATEGORIES 11
+ * 8 small-N conv, 9 encoder instance-norm passes, 10 lookup fused into convc1,
+ * 11 convf1 + convf2 fused (the flow branch).
+ * work[] = algorithmic flops (0, 3, 4, 8, 11) or bytes (1, 2, 6, 7, 9, 10) booked per launch. */
+#define MFTX_PROFILE_CATEGORIES 12
 int mftx_profile_begin(void);
 int mftx_profile_end(double *ms, double *work, long long *count, int n);
 
@@ -100,6 +101,22 @@ int mftx_pack_lookup_convc1_weights(const float *wpk, int ld_w, void *wfused, vo
 int mftx_corr_lookup_convc1(const float *lvl0, const float *lvl1, const float *lvl2, const float *lvl3,
                             const float *coords, int P, int h, int w, const void *wfused, const float *bias,
                             float *out, int ld_out, int out_split, void *stream);
+
+/* ---- the motion encoder's flow branch, fused: convf1 -> convf2 without materialising the 128 features --------------
+ * Replaces flo = relu(convf1(flow)); flo = relu(convf2(flo)) (core/update.py:154-156; 7 x 7, 2 -> 128 and 3 x 3,
+ * 128 -> 64, both zero padded) on flow = coords - grid, in the split-fp16 arithmetic (MFTX_ARITH_SPLIT): the 128-channel
+ * features of a tile of 8 x 16 cells (and its one-cell halo) stay in the CU's LDS.
+ * coords: [P][h*w][2] (x, y) as mftx_corr_lookup.  wflow: MFTX_FLOW_BRANCH_WEIGHT_BYTES bytes (16-byte aligned) filled by
+ * mftx_pack_flow_branch_weights from w98 = convf1's weight as [98 = (ky, kx, c)][128] fp32 and w2pk = convf2's weight in the
+ * mftx_conv2d packing [>= 64 rows][9 taps][128] fp32.  b1: 128 floats, b2: 64 floats (16-byte aligned).
+ * out: the 64 output channels of cell m in SPLIT form (mftx_conv_desc.out_split) at out + m * ld_out floats (ld_out >= 64, a
+ * multiple of 8, 32-byte aligned rows).  hx (optional, may be NULL): rows of ld_hx >= 384 floats in split form; the flow
+ * itself is written to channels 382, 383 (the tail of the GRU input, core/update.py:160).
+ * |flow| must stay below MFTX_SPLIT_LIMIT px (beyond it the outputs of the cells that see it are NaN). */
+#define MFTX_FLOW_BRANCH_WEIGHT_BYTES 352256
+int mftx_pack_flow_branch_weights(const float *w98, const float *w2pk, void *wflow, void *stream);
+int mftx_flow_branch(const float *coords, int P, int h, int w, const void *wflow, const float *b1, const float *b2,
+                     float *out, int ld_out, float *hx, int ld_hx, void *stream);
 
 /* ---- a17: on-demand correlation lookup (no stored volume) ------------------------------------------------
  * Replaces AlternateCorrBlock + the optional CUDA op alt_cuda_corr (MFT/RAFT/core/corr.py:72-100,
@@ -195,6 +212,10 @@ int mftx_raft_arith(const mftx_raft *r);
  * and the stored pyramid, every iteration then runs lookup + convc1 as the one fused kernel above; the 324 features are
  * materialised on the last iteration only, for the occlusion / uncertainty heads (core/raft.py:199-206).  NULL: off. */
 int mftx_raft_set_lookup_fused(mftx_raft *r, const void *wfused);
+/* wflow (mftx_pack_flow_branch_weights of the engine's convf1 / convf2 weights; the pointer is kept): with the split
+ * arithmetic every iteration then runs the motion encoder's flow branch as the one fused kernel above, in order on the
+ * call's stream (no side stream).  NULL: off. */
+int mftx_raft_set_flow_fused(mftx_raft *r, const void *wflow);
 /* Debug payload of RAFT.forward(vis_debug=True) (core/raft.py:159-176, 255-257): trace = (iters + 1) x [P*h*w][2] floats
  * (device, kept) receives coords1 as every iteration finds it and, last, as the final iteration leaves it; NULL: off.  The
  * cost-volume pyramid of the same call stays in the workspace (mftx_raft_workspace_layout_for: lvl0..3). */
@@ -207,12 +228,14 @@ int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
  *   MFTX_RAFT_OPT_GRAPH      1 default (the launch sequence between the first and the last kernel of mftx_raft_refine -- it
  *                            touches the workspace only -- is captured per (shape, workspace, stream) on its second use and
  *                            replayed as a hipGraph from then on: same kernels, same bits, ~170 launches less host work),
- *                            0 plain launches */
+ *                            0 plain launches
+ *   MFTX_RAFT_OPT_FUSE_FLOW  1 default (use the fused convf1 + convf2 kernel when its weights are set), 0 keep them apart */
 #define MFTX_RAFT_OPT_FORK 0
 #define MFTX_RAFT_OPT_PRESPLIT 1
 #define MFTX_RAFT_OPT_GROUP 2
 #define MFTX_RAFT_OPT_FUSE_LOOKUP 3
 #define MFTX_RAFT_OPT_GRAPH 4
+#define MFTX_RAFT_OPT_FUSE_FLOW 5
 int mftx_raft_set_option(mftx_raft *r, int option, int value);
 /* graphs captured / graph launches so far (tests, bench) */
 int mftx_raft_graph_stats(const mftx_raft *r, unsigned long long *captures, unsigned long long *replays);

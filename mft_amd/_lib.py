@@ -12,6 +12,7 @@ LIB_PATH = _HERE / "libmftx.so"
 MAX_CANDIDATES = 16
 NUM_RAFT_WEIGHTS = 34
 LOOKUP_CONVC1_WEIGHT_BYTES = 393216
+FLOW_BRANCH_WEIGHT_BYTES = 352256
 SPLIT_LIMIT = 65504.0      # MFTX_SPLIT_LIMIT: operands of the split arithmetic must stay below it in magnitude
 
 
@@ -52,6 +53,10 @@ SIGNATURES = {
     "mftx_raft_set_split_weights": (C.c_int, [C.c_void_p, _PP, C.c_int]),
     "mftx_raft_arith": (C.c_int, [C.c_void_p]),
     "mftx_raft_set_lookup_fused": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mftx_raft_set_flow_fused": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mftx_pack_flow_branch_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mftx_flow_branch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mftx_raft_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mftx_raft_set_coords_trace": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mftx_raft_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),

@@ -145,6 +145,10 @@ int launch_pack_lookup_convc1(const float *w, int ld_w, void *out, hipStream_t s
 bool lookup_convc1_applicable(int P, int h, int w, int ld_out);
 int launch_lookup_convc1(const float *const lvl[4], const float *coords, int P, int h, int w, const void *wf,
                          const float *bias, float *out, int ld_out, int out_split, hipStream_t s);
+// the motion encoder's flow branch as one kernel (csrc/flow_branch.hip): out = relu(convf2(relu(convf1(coords - grid)))), split form
+int launch_pack_flow_branch(const float *w98, const float *w2pk, void *out, hipStream_t s);
+int launch_flow_branch(const float *coords, int P, int h, int w, const void *wf, const float *b1, const float *b2, float *out,
+                       int ld_out, float *hx, int ld_hx, hipStream_t s);
 // on-demand correlation (csrc/corr_ondemand.hip): pooled feature pyramid + lookup without a stored volume
 int launch_fmap_pyramid(const float *f2, int P, int C, int h, int w, float *const lvl[3], hipStream_t s);
 int launch_corr_ondemand(const float *f1, const float *const f2lvl[4], const float *coords, int P, int h, int w,

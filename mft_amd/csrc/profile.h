@@ -6,7 +6,7 @@
 namespace mftx {
 
 enum ProfCat { PC_CORR_VOLUME, PC_CORR_POOL, PC_LOOKUP, PC_CONV_GEMM, PC_CONVF1, PC_GLUE, PC_UPSAMPLE, PC_CHAIN,
-               PC_CONV_SMALL, PC_ENC_NORM, PC_LOOKUP_FUSED, PC_COUNT };
+               PC_CONV_SMALL, PC_ENC_NORM, PC_LOOKUP_FUSED, PC_FLOW_FUSED, PC_COUNT };
 
 bool prof_enabled();
 // bracket one launch: begin() records an event, end() records another and

@@ -182,7 +182,8 @@ struct mftx_raft {
     float *coords_trace;           // debug payload (mftx_raft_set_coords_trace): coords1 before every iteration and after the last, or null
     GraphCache *graphs;            // the refinement's launch sequence between its first and last kernels, captured per (shape, workspace, mode)
     const void *wfused;            // convc1's weights for the fused lookup + convc1 kernel (csrc/lookup_convc1.hip), or null
-    int opt[5];                    // MFTX_RAFT_OPT_*
+    const void *wflow;             // convf1's and convf2's weights for the fused flow-branch kernel (csrc/flow_branch.hip), or null
+    int opt[6];                    // MFTX_RAFT_OPT_*
 };
 // weights that go through the conv GEMM (the others feed VALU kernels and stay fp32)
 static constexpr int GEMM_SLOTS[] = {W_CONVC1, W_CONVC2, W_CONVF2, W_CONV, W_ZR1_DYN, W_ZR1_INP, W_Q1_DYN, W_Q1_INP,
@@ -203,9 +204,10 @@ extern "C" int mftx_raft_create(const float *const *weights, int n_weights, mftx
     r->arith = MFTX_ARITH_F32;
     r->side = nullptr; r->ev_fork = nullptr; r->ev_join = nullptr;
     r->wfused = nullptr;
+    r->wflow = nullptr;
     r->coords_trace = nullptr;
     r->graphs = new (std::nothrow) GraphCache;
-    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1;
+    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1; r->opt[MFTX_RAFT_OPT_FUSE_FLOW] = 1;
     for (int i = 0; i < W_COUNT; ++i) r->w[i] = r->wg[i] = weights[i];
     *out = r;
     return 0;
@@ -270,6 +272,14 @@ extern "C" int mftx_raft_set_lookup_fused(mftx_raft *r, const void *wfused) {
     return 0;
 }
 
+extern "C" int mftx_raft_set_flow_fused(mftx_raft *r, const void *wflow) {
+    if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_flow_fused: bad handle");
+    if (wflow && !aligned16(wflow)) return fail(MFTX_E_ALIGN, "raft_set_flow_fused: weights not 16-byte aligned");
+    r->wflow = wflow;
+    if (r->graphs) r->graphs->clear();
+    return 0;
+}
+
 extern "C" int mftx_raft_set_coords_trace(mftx_raft *r, float *trace) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_coords_trace: bad handle");
     r->coords_trace = trace;
@@ -278,7 +288,7 @@ extern "C" int mftx_raft_set_coords_trace(mftx_raft *r, float *trace) {
 
 extern "C" int mftx_raft_set_option(mftx_raft *r, int option, int value) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_option: bad handle");
-    if (option < 0 || option > MFTX_RAFT_OPT_GRAPH) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
+    if (option < 0 || option > MFTX_RAFT_OPT_FUSE_FLOW) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
     r->opt[option] = value;
     if (r->graphs) r->graphs->clear();
     return 0;
@@ -419,8 +429,17 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         const mftx_conv_desc c2 = gemm(conv_desc(ws.cor1, 256, 256, nullptr, 0, 0, G[W_CONVC2], W[B_CONVC2], ws.corflo, 256, P, h, w, 192, 3, 3, 1), true, true);
         const mftx_conv_desc f2 = gemm(conv_desc(ws.flo1, 128, 128, nullptr, 0, 0, G[W_CONVF2], W[B_CONVF2], ws.corflo + 192, 256, P, h, w, 64, 3, 3, 1), true, true);
         const int fork_env = r->opt[MFTX_RAFT_OPT_FORK];      // 0 never, -1 / 1 with the split arithmetic
-        const bool serial = prof_enabled() || nofuse || (AR == MFTX_ARITH_SPLIT && fork_env == 0);
+        // the flow branch as ONE kernel (csrc/flow_branch.hip), in order on this stream: no side stream, no join
+        const bool fuse_flow = SP && r->wflow != nullptr && r->opt[MFTX_RAFT_OPT_FUSE_FLOW] != 0 && !nofuse;
+        if (fuse_flow) TRY(launch_flow_branch(ws.coords1, P, h, w, r->wflow, W[B_CONVF1], W[B_CONVF2], ws.corflo + 192, 256, ws.hx, 384, s));
+        const bool serial = fuse_flow || prof_enabled() || nofuse || (AR == MFTX_ARITH_SPLIT && (fork_env == 0 || fork_env == 2));
         const bool forked = !serial && AR == MFTX_ARITH_SPLIT;
+        const bool flow_first = !fuse_flow && serial && fuse_lookup && fork_env == 2 && !prof_enabled() && !nofuse;    // convf1, convf2, then the correlation branch
+        if (flow_first) {
+            hipLaunchKernelGGL(convf1_kernel, dim3(f1_blocks), dim3(256), 0, s, f1);
+            TRY(check_launch("convf1"));
+            TRY(launch_conv(f2, s));
+        }
         if (forked) {
             TRY(ensure_side_stream(r));
             if (hipEventRecord(r->ev_fork, s) != hipSuccess || hipStreamWaitEvent(r->side, r->ev_fork, 0) != hipSuccess)
@@ -437,16 +456,16 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         if (fuse_lookup) {
             if (last && !forked) TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr, s));
             TRY(launch_lookup_convc1(lv, ws.coords1, P, h, w, r->wfused, W[B_CONVC1], ws.cor1, 256, 1, s));
-            if (!forked) {
+            if (!forked && !flow_first && !fuse_flow) {
                 ProfScope prof(PC_CONVF1, s, 2.0 * M * 128 * 98);
                 hipLaunchKernelGGL(convf1_kernel, dim3(f1_blocks), dim3(256), 0, s, f1);
             }
-        } else if (prof_enabled() || nofuse || forked || ondemand) {
+        } else if (prof_enabled() || nofuse || forked || ondemand || fuse_flow) {
             // (the 324 features stay fp32: written in split form the lookup takes 31 instead of 27 us, more than convc1
             // gains from a pre-split A -- and its HBM roofline is the one with a north-star target)
             if (ondemand) TRY(launch_corr_ondemand(fmap1, f2lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr, s));
             else TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr, s));
-            if (!forked) {
+            if (!forked && !fuse_flow) {
                 ProfScope prof(PC_CONVF1, s, 2.0 * M * 128 * 98);
                 hipLaunchKernelGGL(convf1_kernel, dim3(f1_blocks), dim3(256), 0, s, f1);
             }
@@ -463,7 +482,8 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
             TRY(launch_conv(c2, s));
             if (hipStreamWaitEvent(s, r->ev_join, 0) != hipSuccess) return fail(MFTX_E_STATE, "raft_refine: join failed");
         } else if (nopair || AR != MFTX_ARITH_F32) {
-            TRY(launch_conv(c2, s)); TRY(launch_conv(f2, s));
+            TRY(launch_conv(c2, s));
+            if (!flow_first && !fuse_flow) TRY(launch_conv(f2, s));
         } else {
             TRY(launch_conv_pair(c2, f2, s));      // second layers of the two branches in one launch
         }
@@ -511,6 +531,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         key.v[0] = (uintptr_t)P; key.v[1] = (uintptr_t)h; key.v[2] = (uintptr_t)w; key.v[3] = (uintptr_t)iters;
         key.v[4] = reinterpret_cast<uintptr_t>(workspace); key.v[5] = reinterpret_cast<uintptr_t>(flow_lr_out);
         key.v[6] = (uintptr_t)AR; key.v[7] = reinterpret_cast<uintptr_t>(r->wfused); key.v[8] = reinterpret_cast<uintptr_t>(s);
+        key.v[9] = reinterpret_cast<uintptr_t>(r->wflow);
         TRY(r->graphs->run(key, s, core));
     } else {
         TRY(core());
@@ -589,6 +610,17 @@ extern "C" int mftx_corr_lookup_convc1(const float *lvl0, const float *lvl1, con
         return fail(MFTX_E_ALIGN, "corr_lookup_convc1: operands must be 16-byte aligned (a split-form output: 32-byte rows)");
     const float *lv[4] = {lvl0, lvl1, lvl2, lvl3};
     return launch_lookup_convc1(lv, coords, P, h, w, wfused, bias, out, ld_out, out_split ? 1 : 0, (hipStream_t)stream);
+}
+
+extern "C" int mftx_pack_flow_branch_weights(const float *w98, const float *w2pk, void *wflow, void *stream) {
+    if (!w98 || !w2pk || !wflow) return fail(MFTX_E_ARG, "pack_flow_branch_weights: null pointer");
+    if (!aligned16(wflow)) return fail(MFTX_E_ALIGN, "pack_flow_branch_weights: output not 16-byte aligned");
+    return launch_pack_flow_branch(w98, w2pk, wflow, (hipStream_t)stream);
+}
+
+extern "C" int mftx_flow_branch(const float *coords, int P, int h, int w, const void *wflow, const float *b1, const float *b2,
+                                float *out, int ld_out, float *hx, int ld_hx, void *stream) {
+    return launch_flow_branch(coords, P, h, w, wflow, b1, b2, out, ld_out, hx, ld_hx, (hipStream_t)stream);
 }
 
 extern "C" int mftx_fmap_pyramid(const float *f2, int P, int C, int h, int w, float *lvl1, float *lvl2, float *lvl3,

@@ -357,6 +357,40 @@ def pack_lookup_convc1_weights(wpk: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_flow_branch_weights(w98: torch.Tensor, w2pk: torch.Tensor, check_range: bool = True) -> torch.Tensor:
+    """convf1's weight as [98 = (ky, kx, c), 128] and convf2's in the ``pack_conv_weight`` form [>= 64, 9, 128] -> the
+    fragment streams of the fused flow-branch kernel (``mftx_pack_flow_branch_weights``; opaque bytes).  The weights are
+    operands of the split arithmetic: with ``check_range`` a value not below 65504 raises ``SplitRangeError``."""
+    lib = _lib.load()
+    if tuple(w98.shape) != (98, 128) or w2pk.dim() != 3 or w2pk.shape[0] < 64 or tuple(w2pk.shape[1:]) != (9, 128):
+        raise MftxError("pack_flow_branch_weights: expected convf1 as [98, 128] and convf2 as [>= 64, 9, 128]")
+    if check_range:
+        bad = count_not_below(w98, _lib.SPLIT_LIMIT) + count_not_below(w2pk, _lib.SPLIT_LIMIT)
+        if bad:
+            raise SplitRangeError(f"pack_flow_branch_weights: {bad} weights are not below {_lib.SPLIT_LIMIT} in magnitude")
+    out = torch.empty(_lib.FLOW_BRANCH_WEIGHT_BYTES, dtype=torch.uint8, device=w98.device)
+    check(lib.mftx_pack_flow_branch_weights(_chk(w98, "w98"), _chk(w2pk, "w2pk"), out.data_ptr(), _stream()),
+          "mftx_pack_flow_branch_weights")
+    return out
+
+
+def flow_branch(coords: torch.Tensor, h: int, w: int, wflow: torch.Tensor, b1: torch.Tensor, b2: torch.Tensor,
+                out: torch.Tensor = None, hx: torch.Tensor = None) -> torch.Tensor:
+    """relu(convf2(relu(convf1(coords - grid)))) without materialising convf1's 128 channels (``mftx_flow_branch``;
+    split-fp16 arithmetic): coords [P, h*w, 2], wflow from ``pack_flow_branch_weights`` -> [P*h*w, 64] in SPLIT form
+    (``unsplit_activations`` decodes it).  hx (optional): [P*h*w, 384] split-form rows whose channels 382, 383 receive
+    the flow itself."""
+    lib = _lib.load()
+    P = coords.shape[0]
+    if out is None:
+        out = torch.empty(P * h * w, 64, dtype=torch.float32, device=coords.device)
+    check(lib.mftx_flow_branch(_chk(coords, "coords"), P, h, w, _chk(wflow, "wflow", torch.uint8), _chk(b1, "b1"),
+                               _chk(b2, "b2"), out.data_ptr(), out.stride(0),
+                               hx.data_ptr() if hx is not None else None, hx.stride(0) if hx is not None else 0, _stream()),
+          "mftx_flow_branch")
+    return out
+
+
 def corr_lookup_convc1(lv, coords: torch.Tensor, h: int, w: int, wfused: torch.Tensor, bias: torch.Tensor,
                        out_split: bool = False):
     """relu(convc1(lookup(coords)) + bias) without materialising the lookup (``mftx_corr_lookup_convc1``; split-fp16
@@ -573,10 +607,10 @@ class RaftEngine:
     # WeightSlot indices (csrc/raft_engine.hip) of the weights that feed GEMM layers
     GEMM_SLOTS = (0, 2, 6, 8, 10, 11, 13, 14, 16, 17, 19, 20, 22, 26, 28, 30)
 
-    OPTIONS = {"fork": 0, "presplit": 1, "group": 2, "fuse_lookup": 3, "graph": 4}      # MFTX_RAFT_OPT_*
+    OPTIONS = {"fork": 0, "presplit": 1, "group": 2, "fuse_lookup": 3, "graph": 4, "fuse_flow": 5}      # MFTX_RAFT_OPT_*
 
     def __init__(self, state_dict: dict, device, ondemand_corr=False, arith=ARITH_SPLIT, options=None):
-        """options: {"fork" | "presplit" | "group" | "fuse_lookup": int} scheduling options of this handle
+        """options: {"fork" | "presplit" | "group" | "fuse_lookup" | "graph" | "fuse_flow": int} scheduling options of this handle
         (``mftx_raft_set_option``; defaults are the measured best)."""
         lib = _lib.load()
         self.device = torch.device(device)
@@ -594,6 +628,9 @@ class RaftEngine:
             # lookup + convc1 as one kernel (the 324 features never leave the CU): convc1's weights as its fragment stream
             self.wfused = pack_lookup_convc1_weights(self.weights[0])
             check(lib.mftx_raft_set_lookup_fused(self._h, self.wfused.data_ptr()), "mftx_raft_set_lookup_fused")
+            # the flow branch (convf1 -> convf2) as one kernel: both weights as its fragment streams
+            self.wflow = pack_flow_branch_weights(self.weights[4], self.weights[6])
+            check(lib.mftx_raft_set_flow_fused(self._h, self.wflow.data_ptr()), "mftx_raft_set_flow_fused")
         elif self.arith != ARITH_F32:
             raise MftxError(f"unknown arithmetic {arith!r}")
         for k, v in (options or {}).items():

@@ -963,7 +963,7 @@ def test_engine_register_split_bitwise():
     other epilogue variants, GRU state in fp32 only) agrees with the default engine (activations stored in split form by
     their producers) to the last digits; with the flow branch in order on one stream (fork = 0) and with the grouped
     launches kept apart (group = 0) bit for bit.  Options are per handle (mftx_raft_set_option), not process state."""
-    base = {"fuse_lookup": 0}
+    base = {"fuse_lookup": 0, "fuse_flow": 0}
     outs = {tag: _engine_outputs(dict(base, **extra)) for tag, extra in
             (("default", {}), ("nopresplit", {"presplit": 0}), ("nofork", {"fork": 0}), ("nogroup", {"group": 0, "fork": 0}))}
     assert np.isfinite(outs["default"]).all()
@@ -979,6 +979,85 @@ def test_engine_fused_lookup_matches_unfused():
     fused kernel sums convc1's 324 products in another order (level by level, 16 at a time), so the iterations drift
     apart by fp32 rounding only."""
     fused, apart = _engine_outputs({}), _engine_outputs({"fuse_lookup": 0})
+    assert np.isfinite(fused).all()
+    n = 3 * 2 * 192 * 320
+    d = (fused[:n] - apart[:n]).reshape(3, 2, -1)
+    epe = np.sqrt((d ** 2).sum(1)).mean()
+    assert epe < 1e-4, epe
+    assert np.abs(fused[n:] - apart[n:]).max() < 1e-3
+
+
+def _flow_branch_case(ops_mod, P, h, w, spread, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    w1 = torch.randn(128, 2, 7, 7, generator=g) * 0.1
+    b1 = torch.randn(128, generator=g) * 0.1
+    w2 = torch.randn(64, 128, 3, 3, generator=g) * 0.05
+    b2 = torch.randn(64, generator=g) * 0.1
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    grid = torch.stack([xs, ys], -1).reshape(1, h * w, 2)
+    coords = grid + spread * torch.randn(P, h * w, 2, generator=g)
+    w98 = w1.permute(2, 3, 1, 0).reshape(98, 128).contiguous().cuda()
+    wflow = ops_mod.pack_flow_branch_weights(w98, ops_mod.pack_conv_weight(w2.cuda()))
+    return coords, grid, (w1, b1, w2, b2), wflow
+
+
+@pytest.mark.parametrize("P,h,w,spread", [(1, 8, 16, 2.0), (2, 21, 37, 5.0), (1, 64, 64, 1.0), (3, 17, 16, 40.0), (1, 9, 1, 3.0)])
+def test_flow_branch_fused_vs_fp64(ops_mod, P, h, w, spread):
+    """convf1 -> convf2 as one kernel (mftx_flow_branch) against the two convolutions in fp64 (core/update.py:154-156):
+    whole and ragged tiles, images smaller than a tile, the zero padding of BOTH layers (convf2 sees zeros, not convf1
+    of the padding, outside the image), and the flow written to the tail of the GRU input."""
+    coords, grid, (w1, b1, w2, b2), wflow = _flow_branch_case(ops_mod, P, h, w, spread)
+    hx = torch.zeros(P * h * w, 384, device=DEV)
+    out = ops_mod.flow_branch(coords.cuda(), h, w, wflow, b1.cuda(), b2.cuda(), hx=hx)
+    got = ops_mod.unsplit_activations(out).cpu().double()
+    flow = (coords - grid).double().reshape(P, h, w, 2).permute(0, 3, 1, 2)
+    f1 = torch.relu(torch.nn.functional.conv2d(flow, w1.double(), b1.double(), padding=3))
+    ref = torch.relu(torch.nn.functional.conv2d(f1, w2.double(), b2.double(), padding=1)).permute(0, 2, 3, 1).reshape(P * h * w, 64)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 2e-6 * max(scale, 1.0), (float((got - ref).abs().max()), scale)
+    want = torch.zeros(P * h * w, 384)
+    want[:, 382:384] = (coords - grid).reshape(P * h * w, 2)
+    assert torch.equal(hx.cpu(), ops_mod.split_activations(want.cuda()).cpu()), "flow tail of hx (and nothing else of it)"
+
+
+def test_flow_branch_batch_invariance_and_stale_lds(ops_mod):
+    """A pair's result does not depend on the batch it is part of, nor on what the workgroup's LDS held before."""
+    h, w = 24, 40
+    coords, grid, (w1, b1, w2, b2), wflow = _flow_branch_case(ops_mod, 3, h, w, 4.0)
+    c = coords.cuda()
+    full = ops_mod.flow_branch(c, h, w, wflow, b1.cuda(), b2.cuda())
+    for k in range(3):
+        one = ops_mod.flow_branch(c[k:k + 1].contiguous(), h, w, wflow, b1.cuda(), b2.cuda())
+        assert torch.equal(one, full[k * h * w:(k + 1) * h * w]), k
+    for _ in range(5):      # other kernels in between leave other bytes in LDS
+        torch.randn(1 << 20, device=DEV).sort()
+        assert torch.equal(ops_mod.flow_branch(c, h, w, wflow, b1.cuda(), b2.cuda()), full)
+
+
+def test_flow_branch_out_of_range_is_nan_and_argument_errors(ops_mod):
+    h, w = 16, 32
+    coords, grid, (w1, b1, w2, b2), wflow = _flow_branch_case(ops_mod, 1, h, w, 1.0)
+    c = coords.clone()
+    c[0, 5 * w + 7, 0] += 1e5                                   # a flow beyond the fp16 range of the high halves
+    out = ops_mod.unsplit_activations(ops_mod.flow_branch(c.cuda(), h, w, wflow, b1.cuda(), b2.cuda())).cpu().reshape(h, w, 64)
+    ok = ops_mod.unsplit_activations(ops_mod.flow_branch(coords.cuda(), h, w, wflow, b1.cuda(), b2.cuda())).cpu().reshape(h, w, 64)
+    bad = ~torch.isfinite(out).all(-1)
+    assert bad[5, 7] and bad.sum() <= 9 * 9                       # NaN inside the receptive field (7 x 7, then 3 x 3) ...
+    ys, xs = torch.nonzero(bad, as_tuple=True)
+    assert int((ys - 5).abs().max()) <= 4 and int((xs - 7).abs().max()) <= 4
+    assert torch.equal(out[~bad], ok[~bad])                       # ... and the same bits everywhere else: never a finite wrong value
+    with pytest.raises(ops_mod.MftxError):
+        ops_mod.pack_flow_branch_weights(torch.zeros(98, 64, device=DEV), torch.zeros(128, 9, 128, device=DEV))
+    with pytest.raises(ops_mod.SplitRangeError):
+        ops_mod.pack_flow_branch_weights(torch.full((98, 128), 7e4, device=DEV), torch.zeros(128, 9, 128, device=DEV))
+    with pytest.raises(ops_mod.MftxError):                        # a split-form output needs 32-byte rows
+        ops_mod.flow_branch(coords.cuda(), h, w, wflow, b1.cuda(), b2.cuda(), out=torch.zeros(h * w, 68, device=DEV))
+
+
+def test_engine_fused_flow_matches_unfused():
+    """The engine with the flow branch as ONE kernel (the default) against the same engine with convf1 (fp32 VALU) and
+    convf2 (split GEMM) kept apart: other summation orders, split products where convf1 had fp32 ones -- fp32 rounding."""
+    fused, apart = _engine_outputs({}), _engine_outputs({"fuse_flow": 0})
     assert np.isfinite(fused).all()
     n = 3 * 2 * 192 * 320
     d = (fused[:n] - apart[:n]).reshape(3, 2, -1)

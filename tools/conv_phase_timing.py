@@ -17,21 +17,26 @@ raw = C.CDLL(os.environ["MFTX_LIB"])
 buf = (C.c_ulonglong * 16)()
 P, h, w = 7, 64, 64
 M = P * h * w
+PRE = "--a-split" in sys.argv        # A and output in split form (what the engine runs)
+TILE = int(sys.argv[sys.argv.index("--tile") + 1]) if "--tile" in sys.argv else None
 for name, cin, cout, kh, kw in (("gru zr 1x5 256->256", 256, 256, 1, 5), ("gru q 1x5 256->128", 256, 128, 1, 5),
                                 ("fh1 3x3 128->256", 128, 256, 3, 3), ("convc1 1x1 324->256", 324, 256, 1, 1),
                                 ("convc2 3x3 256->192", 256, 192, 3, 3), ("convf2 3x3 128->64", 128, 64, 3, 3)):
     x = torch.randn(M, cin, device="cuda")
+    if PRE:
+        x = ops.split_activations(x)
+    kw_ = dict(a_split=PRE, out_split=PRE and cout % 8 == 0, tile=TILE)
     wt = ops.split_weights(ops.pack_conv_weight(torch.randn(cout, cin, kh, kw, device="cuda") * 0.05))
     b = torch.randn(cout, device="cuda")
     for _ in range(3):
-        ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu", arith=1)
+        ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu", arith=1, **kw_)
     torch.cuda.synchronize()
     raw.mftx_debug_timing(buf, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     reps = 10
     for _ in range(reps):
-        ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu", arith=1)
+        ops.conv2d(x, wt, b, P, h, w, cout, kh, kw, act="relu", arith=1, **kw_)
     e1.record()
     torch.cuda.synchronize()
     raw.mftx_debug_timing(buf, 1)
