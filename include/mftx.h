@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MFTX_VERSION 301
+#define MFTX_VERSION 302
 
 #define MFTX_E_ARG (-1)      /* null pointer / non-positive size / unsupported shape */
 #define MFTX_E_ALIGN (-2)    /* pointer or leading dimension not 16-byte aligned */
@@ -175,6 +175,17 @@ int mftx_conv2d(const mftx_conv_desc *d, void *stream);
  * shapes, built with -DMFTX_EXPERIMENTAL_TILES only).  A shape that does not exist for the arithmetic falls back to the
  * arithmetic's default small tile. */
 int mftx_conv2d_tile(const mftx_conv_desc *d, int tile, void *stream);
+
+/* ---- a8-a10, tile-resident form: the update block's convolutions whose input tile fits a CU's LDS ------------------
+ * The same layer as mftx_conv2d with arith = MFTX_ARITH_SPLIT, a_split = 1 -- a 3 x 3 convolution over 128 channels or a
+ * 1 x 5 / 5 x 1 one over 128 or 256 (two segments of 128: c0 = c1 = 128), N = 128 or 256, stride 1, "same" padding, act
+ * none or relu, optional bias and pre-activation addend -- by another kernel (csrc/tile_conv.hip): the
+ * input of an output tile of 128 cells is loaded into LDS ONCE, the weights stream from L2 into registers; no LDS ring,
+ * no barrier in the K loop.  Results agree with mftx_conv2d to fp32 rounding of the K sum (not bit for bit).
+ * wtile: N * taps * cin * 4 bytes (16-byte aligned) filled by mftx_pack_tile_conv_weights from the layer's weight in the
+ * mftx_conv2d packing wpk = [>= N rows][taps][cin_pad] fp32.  d->wpk is ignored. */
+int mftx_pack_tile_conv_weights(const float *wpk, int N, int taps, int cin, int cin_pad, void *wtile, void *stream);
+int mftx_tile_conv2d(const mftx_conv_desc *d, const void *wtile, void *stream);
 /* packed fp32 weights (n_floats of them, a multiple of 8) -> the split form MFTX_ARITH_SPLIT streams: same size,
  * every 8 consecutive floats replaced by their 8 fp16 high halves and 8 fp16 low halves (x 2048) */
 int mftx_split_weights(const float *wpk, void *out, long long n_floats, void *stream);
@@ -216,6 +227,11 @@ int mftx_raft_set_lookup_fused(mftx_raft *r, const void *wfused);
  * arithmetic every iteration then runs the motion encoder's flow branch as the one fused kernel above, in order on the
  * call's stream (no side stream).  NULL: off. */
 int mftx_raft_set_flow_fused(mftx_raft *r, const void *wflow);
+/* tile: MFTX_RAFT_NUM_WEIGHTS pointers, the mftx_pack_tile_conv_weights form of the weights of the layers that have a
+ * tile-resident kernel -- the GRU gates' eight slots (per-iteration and context parts), the first layers of the flow head
+ * and of the mask head -- NULL elsewhere (and NULL for a layer to keep on mftx_conv2d's kernel); with the split arithmetic
+ * those layers then run on csrc/tile_conv.hip.  The pointers are kept.  tile = NULL: off. */
+int mftx_raft_set_tile_weights(mftx_raft *r, const void *const *tile, int n);
 /* Debug payload of RAFT.forward(vis_debug=True) (core/raft.py:159-176, 255-257): trace = (iters + 1) x [P*h*w][2] floats
  * (device, kept) receives coords1 as every iteration finds it and, last, as the final iteration leaves it; NULL: off.  The
  * cost-volume pyramid of the same call stays in the workspace (mftx_raft_workspace_layout_for: lvl0..3). */
@@ -229,13 +245,15 @@ int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
  *                            touches the workspace only -- is captured per (shape, workspace, stream) on its second use and
  *                            replayed as a hipGraph from then on: same kernels, same bits, ~170 launches less host work),
  *                            0 plain launches
- *   MFTX_RAFT_OPT_FUSE_FLOW  1 default (use the fused convf1 + convf2 kernel when its weights are set), 0 keep them apart */
+ *   MFTX_RAFT_OPT_FUSE_FLOW  1 default (use the fused convf1 + convf2 kernel when its weights are set), 0 keep them apart
+ *   MFTX_RAFT_OPT_TILE_CONV  1 default (layers with tile-resident weights set run on that kernel), 0 all on mftx_conv2d's */
 #define MFTX_RAFT_OPT_FORK 0
 #define MFTX_RAFT_OPT_PRESPLIT 1
 #define MFTX_RAFT_OPT_GROUP 2
 #define MFTX_RAFT_OPT_FUSE_LOOKUP 3
 #define MFTX_RAFT_OPT_GRAPH 4
 #define MFTX_RAFT_OPT_FUSE_FLOW 5
+#define MFTX_RAFT_OPT_TILE_CONV 6
 int mftx_raft_set_option(mftx_raft *r, int option, int value);
 /* graphs captured / graph launches so far (tests, bench) */
 int mftx_raft_graph_stats(const mftx_raft *r, unsigned long long *captures, unsigned long long *replays);

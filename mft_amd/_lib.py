@@ -54,6 +54,9 @@ SIGNATURES = {
     "mftx_raft_arith": (C.c_int, [C.c_void_p]),
     "mftx_raft_set_lookup_fused": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mftx_raft_set_flow_fused": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mftx_raft_set_tile_weights": (C.c_int, [C.c_void_p, _PP, C.c_int]),
+    "mftx_pack_tile_conv_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mftx_tile_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p]),
     "mftx_pack_flow_branch_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mftx_flow_branch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_int, C.c_void_p, C.c_int, C.c_void_p]),

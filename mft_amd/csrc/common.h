@@ -149,6 +149,21 @@ int launch_lookup_convc1(const float *const lvl[4], const float *coords, int P, 
 int launch_pack_flow_branch(const float *w98, const float *w2pk, void *out, hipStream_t s);
 int launch_flow_branch(const float *coords, int P, int h, int w, const void *wf, const float *b1, const float *b2, float *out,
                        int ld_out, float *hx, int ld_hx, hipStream_t s);
+// tile-resident convolution GEMM (csrc/tile_conv.hip): the update block's layers whose input tile fits a CU's LDS
+struct TileConvLaunch {
+    const float *a0; int lda0;          // 128 channels per cell in split form
+    const float *a1; int lda1;          // 128 more (cin = 256) or null
+    int cin;                            // 128 or 256
+    const void *wf;                     // launch_pack_tile_conv
+    const float *bias;                  // [N] or null
+    const float *addend; int ld_addend; // pre-activation addend [M][N] or null
+    float *out; int ldo; int out_split; // epi 0 (linear) / 1 (relu)
+    float *z, *rh, *hf, *hx; int ld_hf, ld_hx;      // epi 2 (z | r gates) / 3 (candidate + blend): as GruEpilogue
+    int P, h, w, N, kh, kw, epi;
+};
+bool tile_conv_applicable(int kh, int kw, int cin, int N);
+int launch_pack_tile_conv(const float *wpk, int N, int taps, int cin, int cin_pad, void *out, hipStream_t s);
+int launch_tile_conv(const TileConvLaunch &d, hipStream_t s);
 // on-demand correlation (csrc/corr_ondemand.hip): pooled feature pyramid + lookup without a stored volume
 int launch_fmap_pyramid(const float *f2, int P, int C, int h, int w, float *const lvl[3], hipStream_t s);
 int launch_corr_ondemand(const float *f1, const float *const f2lvl[4], const float *coords, int P, int h, int w,

@@ -183,7 +183,8 @@ struct mftx_raft {
     GraphCache *graphs;            // the refinement's launch sequence between its first and last kernels, captured per (shape, workspace, mode)
     const void *wfused;            // convc1's weights for the fused lookup + convc1 kernel (csrc/lookup_convc1.hip), or null
     const void *wflow;             // convf1's and convf2's weights for the fused flow-branch kernel (csrc/flow_branch.hip), or null
-    int opt[6];                    // MFTX_RAFT_OPT_*
+    const void *wt[W_COUNT];       // weight streams of the tile-resident conv kernel (csrc/tile_conv.hip) per slot, or null
+    int opt[7];                    // MFTX_RAFT_OPT_*
 };
 // weights that go through the conv GEMM (the others feed VALU kernels and stay fp32)
 static constexpr int GEMM_SLOTS[] = {W_CONVC1, W_CONVC2, W_CONVF2, W_CONV, W_ZR1_DYN, W_ZR1_INP, W_Q1_DYN, W_Q1_INP,
@@ -205,9 +206,10 @@ extern "C" int mftx_raft_create(const float *const *weights, int n_weights, mftx
     r->side = nullptr; r->ev_fork = nullptr; r->ev_join = nullptr;
     r->wfused = nullptr;
     r->wflow = nullptr;
+    for (int i = 0; i < W_COUNT; ++i) r->wt[i] = nullptr;
     r->coords_trace = nullptr;
     r->graphs = new (std::nothrow) GraphCache;
-    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1; r->opt[MFTX_RAFT_OPT_FUSE_FLOW] = 1;
+    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1; r->opt[MFTX_RAFT_OPT_FUSE_FLOW] = 1; r->opt[MFTX_RAFT_OPT_TILE_CONV] = 1;
     for (int i = 0; i < W_COUNT; ++i) r->w[i] = r->wg[i] = weights[i];
     *out = r;
     return 0;
@@ -280,6 +282,17 @@ extern "C" int mftx_raft_set_flow_fused(mftx_raft *r, const void *wflow) {
     return 0;
 }
 
+extern "C" int mftx_raft_set_tile_weights(mftx_raft *r, const void *const *tile, int n) {
+    if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_tile_weights: bad handle");
+    if (r->graphs) r->graphs->clear();
+    if (!tile) { for (int i = 0; i < W_COUNT; ++i) r->wt[i] = nullptr; return 0; }
+    if (n != W_COUNT) return fail(MFTX_E_ARG, "raft_set_tile_weights: expected %d slots, got %d", (int)W_COUNT, n);
+    for (int i = 0; i < W_COUNT; ++i)
+        if (tile[i] && !aligned16(tile[i])) return fail(MFTX_E_ALIGN, "raft_set_tile_weights: slot %d not 16-byte aligned", i);
+    for (int i = 0; i < W_COUNT; ++i) r->wt[i] = tile[i];
+    return 0;
+}
+
 extern "C" int mftx_raft_set_coords_trace(mftx_raft *r, float *trace) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_coords_trace: bad handle");
     r->coords_trace = trace;
@@ -288,7 +301,7 @@ extern "C" int mftx_raft_set_coords_trace(mftx_raft *r, float *trace) {
 
 extern "C" int mftx_raft_set_option(mftx_raft *r, int option, int value) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_option: bad handle");
-    if (option < 0 || option > MFTX_RAFT_OPT_FUSE_FLOW) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
+    if (option < 0 || option > MFTX_RAFT_OPT_TILE_CONV) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
     r->opt[option] = value;
     if (r->graphs) r->graphs->clear();
     return 0;
@@ -402,10 +415,28 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     // The gate convolutions are linear in their input [h | inp | motion] and `inp` does not change
     // over the iterations (core/raft.py:146-149): its third of every gate sum (+ bias) is computed
     // once here and enters the per-iteration GEMMs as an epilogue addend.  Same terms, summed once.
+    // Layers whose input tile fits a CU's LDS run on the tile-resident kernel (csrc/tile_conv.hip) when its weight streams are set
+    const bool tiles_on = SP && r->opt[MFTX_RAFT_OPT_TILE_CONV] != 0;
+    auto tile_w = [&](int slot) -> const void * { return tiles_on ? r->wt[slot] : nullptr; };
+    auto tile_layer = [&](const float *a0, int lda0, const float *a1, int lda1, const void *wf, const float *bias, int N, int kh, int kw, int epi) {
+        TileConvLaunch t{};
+        t.a0 = a0; t.lda0 = lda0; t.a1 = a1; t.lda1 = lda1; t.cin = a1 ? 256 : 128; t.wf = wf; t.bias = bias;
+        t.P = P; t.h = h; t.w = w; t.N = N; t.kh = kh; t.kw = kw; t.epi = epi;
+        return t;
+    };
     for (int pass = 0; pass < 2; ++pass) {
         const int kh = pass ? 5 : 1, kw = pass ? 1 : 5;
-        TRY(launch_conv(gemm(conv_desc(ws.hx + 128, 384, 128, nullptr, 0, 0, G[pass ? W_ZR2_INP : W_ZR1_INP], W[pass ? B_ZR2 : B_ZR1], ws.pre_zr[pass], 256, P, h, w, 256, kh, kw, 0), true, false), s));
-        TRY(launch_conv(gemm(conv_desc(ws.hx + 128, 384, 128, nullptr, 0, 0, G[pass ? W_Q2_INP : W_Q1_INP], W[pass ? B_Q2 : B_Q1], ws.pre_q[pass], 128, P, h, w, 128, kh, kw, 0), true, false), s));
+        const int szr = pass ? W_ZR2_INP : W_ZR1_INP, sq = pass ? W_Q2_INP : W_Q1_INP;
+        if (tile_w(szr)) {
+            TileConvLaunch t = tile_layer(ws.hx + 128, 384, nullptr, 0, tile_w(szr), W[pass ? B_ZR2 : B_ZR1], 256, kh, kw, 0);
+            t.out = ws.pre_zr[pass]; t.ldo = 256;
+            TRY(launch_tile_conv(t, s));
+        } else TRY(launch_conv(gemm(conv_desc(ws.hx + 128, 384, 128, nullptr, 0, 0, G[szr], W[pass ? B_ZR2 : B_ZR1], ws.pre_zr[pass], 256, P, h, w, 256, kh, kw, 0), true, false), s));
+        if (tile_w(sq)) {
+            TileConvLaunch t = tile_layer(ws.hx + 128, 384, nullptr, 0, tile_w(sq), W[pass ? B_Q2 : B_Q1], 128, kh, kw, 0);
+            t.out = ws.pre_q[pass]; t.ldo = 128;
+            TRY(launch_tile_conv(t, s));
+        } else TRY(launch_conv(gemm(conv_desc(ws.hx + 128, 384, 128, nullptr, 0, 0, G[sq], W[pass ? B_Q2 : B_Q1], ws.pre_q[pass], 128, P, h, w, 128, kh, kw, 0), true, false), s));
     }
     const float *lv[4] = {ws.lvl[0], ws.lvl[1], ws.lvl[2], ws.lvl[3]};
     const int strips = cdiv(w, F1_CELLS);
@@ -491,13 +522,30 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         // SepConvGRU (core/update.py:108-123): horizontal 1x5 then vertical 5x1
         for (int pass = 0; pass < 2; ++pass) {
             const int kh = pass ? 5 : 1, kw = pass ? 1 : 5;
-            GruEpilogue g1{1, ws.hx, 384, ws.z, ws.rh, SP ? ws.hf : nullptr, 128};
-            TRY(launch_conv_gru(gemm(conv_desc(ws.hx, 384, 128, ws.hx + 256, 384, 128, G[pass ? W_ZR2_DYN : W_ZR1_DYN], nullptr, ws.z, 128, P, h, w, 256, kh, kw, 2, 1.f, ws.pre_zr[pass], 256), true, true), g1, s));
-            GruEpilogue g2{2, ws.hx, 384, ws.z, ws.rh, SP ? ws.hf : nullptr, 128};
-            TRY(launch_conv_gru(gemm(conv_desc(ws.rh, 128, 128, ws.hx + 256, 384, 128, G[pass ? W_Q2_DYN : W_Q1_DYN], nullptr, ws.hx, 384, P, h, w, 128, kh, kw, 3, 1.f, ws.pre_q[pass], 128), true, true), g2, s));
+            const int szr = pass ? W_ZR2_DYN : W_ZR1_DYN, sq = pass ? W_Q2_DYN : W_Q1_DYN;
+            if (tile_w(szr)) {
+                TileConvLaunch t = tile_layer(ws.hx, 384, ws.hx + 256, 384, tile_w(szr), nullptr, 256, kh, kw, 2);
+                t.addend = ws.pre_zr[pass]; t.ld_addend = 256; t.z = ws.z; t.rh = ws.rh; t.hf = ws.hf; t.ld_hf = 128;
+                TRY(launch_tile_conv(t, s));
+            } else {
+                GruEpilogue g1{1, ws.hx, 384, ws.z, ws.rh, SP ? ws.hf : nullptr, 128};
+                TRY(launch_conv_gru(gemm(conv_desc(ws.hx, 384, 128, ws.hx + 256, 384, 128, G[szr], nullptr, ws.z, 128, P, h, w, 256, kh, kw, 2, 1.f, ws.pre_zr[pass], 256), true, true), g1, s));
+            }
+            if (tile_w(sq)) {
+                TileConvLaunch t = tile_layer(ws.rh, 128, ws.hx + 256, 384, tile_w(sq), nullptr, 128, kh, kw, 3);
+                t.addend = ws.pre_q[pass]; t.ld_addend = 128; t.z = ws.z; t.hf = ws.hf; t.ld_hf = 128; t.hx = ws.hx; t.ld_hx = 384;
+                TRY(launch_tile_conv(t, s));
+            } else {
+                GruEpilogue g2{2, ws.hx, 384, ws.z, ws.rh, SP ? ws.hf : nullptr, 128};
+                TRY(launch_conv_gru(gemm(conv_desc(ws.rh, 128, 128, ws.hx + 256, 384, 128, G[sq], nullptr, ws.hx, 384, P, h, w, 128, kh, kw, 3, 1.f, ws.pre_q[pass], 128), true, true), g2, s));
+            }
         }
         // flow head (core/update.py:6-14) and coordinate update (core/raft.py:184)
-        TRY(launch_conv(gemm(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, G[W_FH1], W[B_FH1], ws.fh, 256, P, h, w, 256, 3, 3, 1), true, false), s));
+        if (tile_w(W_FH1)) {
+            TileConvLaunch t = tile_layer(ws.hx, 384, nullptr, 0, tile_w(W_FH1), W[B_FH1], 256, 3, 3, 1);
+            t.out = ws.fh; t.ldo = 256;
+            TRY(launch_tile_conv(t, s));
+        } else TRY(launch_conv(gemm(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, G[W_FH1], W[B_FH1], ws.fh, 256, P, h, w, 256, 3, 3, 1), true, false), s));
         // last layer of the flow head, fused with coords1 += delta_flow (core/raft.py:184)
         {
             const mftx_conv_desc fh2 = conv_desc(ws.fh, 256, 256, nullptr, 0, 0, W[W_FH2], W[B_FH2], ws.delta, 2, P, h, w, 2, 3, 3, 0);
@@ -510,7 +558,11 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
             return fail(MFTX_E_STATE, "raft_refine: coords trace copy failed");
         // The upsampling mask is consumed only after the last iteration in test
         // mode (core/raft.py:190-196,234-239), so it is computed once.
-        TRY(launch_conv(gemm(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, G[W_MASK0], W[B_MASK0], ws.fh, 256, P, h, w, 256, 3, 3, 1), true, false), s));
+        if (tile_w(W_MASK0)) {
+            TileConvLaunch t = tile_layer(ws.hx, 384, nullptr, 0, tile_w(W_MASK0), W[B_MASK0], 256, 3, 3, 1);
+            t.out = ws.fh; t.ldo = 256;
+            TRY(launch_tile_conv(t, s));
+        } else TRY(launch_conv(gemm(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, G[W_MASK0], W[B_MASK0], ws.fh, 256, P, h, w, 256, 3, 3, 1), true, false), s));
         TRY(launch_conv(gemm(conv_desc(ws.fh, 256, 256, nullptr, 0, 0, G[W_MASK2], W[B_MASK2], ws.mask, 576, P, h, w, 576, 1, 1, 0, 0.25f), false, false), s));
         // occlusion + uncertainty heads (core/update.py:196-214)
         {
@@ -531,7 +583,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         key.v[0] = (uintptr_t)P; key.v[1] = (uintptr_t)h; key.v[2] = (uintptr_t)w; key.v[3] = (uintptr_t)iters;
         key.v[4] = reinterpret_cast<uintptr_t>(workspace); key.v[5] = reinterpret_cast<uintptr_t>(flow_lr_out);
         key.v[6] = (uintptr_t)AR; key.v[7] = reinterpret_cast<uintptr_t>(r->wfused); key.v[8] = reinterpret_cast<uintptr_t>(s);
-        key.v[9] = reinterpret_cast<uintptr_t>(r->wflow);
+        key.v[9] = reinterpret_cast<uintptr_t>(r->wflow); key.v[10] = reinterpret_cast<uintptr_t>(r->wt[W_ZR1_DYN]);
         TRY(r->graphs->run(key, s, core));
     } else {
         TRY(core());
@@ -610,6 +662,24 @@ extern "C" int mftx_corr_lookup_convc1(const float *lvl0, const float *lvl1, con
         return fail(MFTX_E_ALIGN, "corr_lookup_convc1: operands must be 16-byte aligned (a split-form output: 32-byte rows)");
     const float *lv[4] = {lvl0, lvl1, lvl2, lvl3};
     return launch_lookup_convc1(lv, coords, P, h, w, wfused, bias, out, ld_out, out_split ? 1 : 0, (hipStream_t)stream);
+}
+
+extern "C" int mftx_pack_tile_conv_weights(const float *wpk, int N, int taps, int cin, int cin_pad, void *wtile, void *stream) {
+    return launch_pack_tile_conv(wpk, N, taps, cin, cin_pad, wtile, (hipStream_t)stream);
+}
+
+extern "C" int mftx_tile_conv2d(const mftx_conv_desc *d, const void *wtile, void *stream) {
+    if (!d || !wtile) return fail(MFTX_E_ARG, "tile_conv2d: null pointer");
+    if (d->arith != MFTX_ARITH_SPLIT || !d->a_split) return fail(MFTX_E_ARG, "tile_conv2d: split arithmetic with a split-form input only");
+    if (d->act != 0 && d->act != 1) return fail(MFTX_E_ARG, "tile_conv2d: activation none or relu");
+    if (d->stride > 1 || d->residual_mode != 0 || d->out_scale != 1.f || (d->hin && d->hin != d->h) || (d->win && d->win != d->w) || d->pad_y != 0 || d->pad_x != 0)
+        return fail(MFTX_E_ARG, "tile_conv2d: stride 1, same padding, no output scale");
+    if (d->c0 != 128 || (d->c1 != 0 && d->c1 != 128)) return fail(MFTX_E_ARG, "tile_conv2d: channel segments of 128");
+    TileConvLaunch t{};
+    t.a0 = d->a0; t.lda0 = d->lda0; t.a1 = d->c1 ? d->a1 : nullptr; t.lda1 = d->lda1; t.cin = d->c0 + d->c1; t.wf = wtile; t.bias = d->bias;
+    t.addend = d->addend; t.ld_addend = d->ld_addend; t.out = d->out; t.ldo = d->ldo; t.out_split = d->out_split;
+    t.P = d->P; t.h = d->h; t.w = d->w; t.N = d->N; t.kh = d->kh; t.kw = d->kw; t.epi = d->act;
+    return launch_tile_conv(t, (hipStream_t)stream);
 }
 
 extern "C" int mftx_pack_flow_branch_weights(const float *w98, const float *w2pk, void *wflow, void *stream) {

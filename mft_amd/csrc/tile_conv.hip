@@ -1,0 +1,413 @@
+// Tile-resident convolution GEMM (split arithmetic): the layers of the update block whose input tile fits a CU's LDS.
+//
+// conv_gemm.hip streams BOTH operands through an LDS ring, chunk by chunk: per 32-wide K chunk every wave issues its share
+// of the LDS-DMA pieces, waits for them, meets the others at a barrier -- the matrix pipes idle for a third of the loop
+// (DESIGN.md section 4).  For a 3 x 3 / 1 x 5 / 5 x 1 convolution over <= 256 split-form channels the WHOLE input of an
+// output tile of 128 cells -- halo included -- is 95-150 KB: it is loaded into LDS once, and then the K loop is nothing but
+//     8 ds_read_b128 (A fragments at compile-time offsets) + 2 global loads (the wave's weight fragments, streamed from
+//     L2 straight into registers, three steps ahead: no other wave of the workgroup reads them) + 12 MFMAs
+// per 16-wide k group and wave, without a barrier, a DMA or a counted wait in it.  Measured on the same structure in
+// flow_branch.hip: 0.82 of the matrix pipe inside the loop.
+//
+//   tile      TH x TW = 128 output cells: 8 x 16 (3 x 3), 4 x 32 (1 x 5), 32 x 4 (5 x 1); input halo tile in LDS, cell by
+//             cell [C0 channels of segment 0 | C1 of segment 1 | 16 bytes], split form, zeros outside the image;
+//   product   D = W x A^T (weights as the MFMA's first operand): a lane holds 4 x 4 consecutive output channels of one
+//             cell per 32-cell row tile;
+//   waves     N = 256: wave = one 32-channel column tile, all of K; N = 128: wave = (column tile, K half) -- channel
+//             groups of the wave's parity -- the halves meet in LDS and are summed in a fixed order;
+//   epilogue  every wave parks acc + accx / 2048 in LDS ([cell][channel] fp32, in the space of the input tile), then all
+//             512 threads walk it row-wise, 8 consecutive channels of a cell each: bias / addend, activation or GRU gate
+//             algebra (core/update.py:108-123), 32 contiguous bytes per lane out.
+//
+// Results do not depend on the batch or on a cell's place in its tile (one fixed sequence of products and sums per
+// output).  They differ from conv_gemm.hip's in the order of the K sum (tap-major here as there, but the cross terms
+// go to their accumulator in another order for N = 128): fp32 rounding.
+#include "common.h"
+#include "profile.h"
+
+namespace mftx {
+
+typedef float tc_f32x16 __attribute__((ext_vector_type(16)));
+typedef float tc_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned tc_u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 tc_f16x8 __attribute__((ext_vector_type(8)));
+
+enum TcEpi { TC_LINEAR = 0, TC_RELU = 1, TC_GRU_ZR = 2, TC_GRU_Q = 3 };
+
+// Tuning builds only (-DMFTX_LF_TRACE): s_memtime stamps of workgroup 0's waves at the phase boundaries (tools/tc_trace.py)
+#ifdef MFTX_LF_TRACE
+__device__ unsigned long long tc_trace_buf[8][16];
+#define TC_T(code) do { if (blockIdx.x == 0 && tcount < 16) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                        if ((threadIdx.x & 63) == 0) tc_trace_buf[threadIdx.x >> 6][tcount] = ((unsigned long long)(code) << 56) | (t_ & 0x00ffffffffffffffull); ++tcount; } } while (0)
+#else
+#define TC_T(code) do { } while (0)
+#endif
+
+struct TileConvArgs {
+    const float *a0; int lda0;      // segment 0: 128 channels per cell, split form, at a0 + cell * lda0 floats
+    const float *a1; int lda1;      // segment 1 (128 more channels) or unused
+    const void *wf;                 // mftx_pack_tile_conv_weights
+    const float *bias;              // [N] or null
+    const float *addend; int ld_addend;     // pre-activation addend [M][N] fp32 or null
+    float *out; int ldo; int out_split;     // TC_LINEAR / TC_RELU
+    float *z, *rh, *hf, *hx; int ld_hf, ld_hx;      // GRU epilogues (conv_gemm.hip: GruEpilogue)
+    int P, h, w, tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ void tc_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ tc_f32x16 tc_mfma(const tc_f16x8 &a, const tc_f16x8 &b, const tc_f32x16 &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// hi / lo halves of 8 consecutive values (conv_gemm.hip: split8)
+__device__ __forceinline__ void tc_split8(const tc_f32x4 &u, const tc_f32x4 &v, float k2048, tc_u32x4 &hi, tc_u32x4 &lo) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    float r0, r1, r2, r3, r4, r5, r6, r7;
+    asm("v_cvt_pk_f16_f32 %0, %16, %17\n\t"
+        "v_cvt_pk_f16_f32 %1, %18, %19\n\t"
+        "v_cvt_pk_f16_f32 %2, %20, %21\n\t"
+        "v_cvt_pk_f16_f32 %3, %22, %23\n\t"
+        "v_fma_mix_f32 %8, %0, -1.0, %16 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %9, %0, -1.0, %17 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %10, %1, -1.0, %18 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %11, %1, -1.0, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %12, %2, -1.0, %20 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %13, %2, -1.0, %21 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %14, %3, -1.0, %22 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %15, %3, -1.0, %23 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %4, %8, %24, 0\n\t"
+        "v_fma_mixlo_f16 %5, %10, %24, 0\n\t"
+        "v_fma_mixlo_f16 %6, %12, %24, 0\n\t"
+        "v_fma_mixlo_f16 %7, %14, %24, 0\n\t"
+        "v_fma_mixhi_f16 %4, %9, %24, 0\n\t"
+        "v_fma_mixhi_f16 %5, %11, %24, 0\n\t"
+        "v_fma_mixhi_f16 %6, %13, %24, 0\n\t"
+        "v_fma_mixhi_f16 %7, %15, %24, 0"
+        : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3),
+          "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(k2048));
+    hi = tc_u32x4{h0, h1, h2, h3};
+    lo = tc_u32x4{l0, l1, l2, l3};
+}
+
+// the gate algebra, as conv_gemm.hip spells it (same functions: the two kernels agree to fp32 rounding of the K sum)
+__device__ __forceinline__ float tc_sigmoid(float s) { return __frcp_rn(1.f + __expf(-s)); }
+__device__ __forceinline__ float tc_tanh(float s) {
+    const float t = __expf(-2.f * fabsf(s));
+    return copysignf((1.f - t) * __frcp_rn(1.f + t), s);
+}
+__device__ __forceinline__ float tc_blend(float z, float h, float q) { return __fmaf_rn(z, q, __fmul_rn(__fsub_rn(1.f, z), h)); }
+
+template <int TH, int TW, int KH, int KW, int CIN, int N>
+struct TcGeom {
+    static constexpr int HH = TH + KH - 1, HWD = TW + KW - 1, HCELLS = HH * HWD;
+    static constexpr int CELLB = CIN * 4 + 16;              // consecutive cells start an odd number of 16-byte slots apart
+    static constexpr int NT = N / 32, KS = 8 / NT;          // column tiles; K splits (waves per column tile)
+    static constexpr int CG = CIN / 16, GPW = CG / KS;      // channel groups per tap; of them per wave
+    static constexpr int STEPS = KH * KW * GPW;             // 16-wide k groups per wave
+    static constexpr int RED_ROW = N + 4;                   // floats per cell of the parked sums
+    static constexpr int A_BYTES = HCELLS * CELLB, RED_BYTES = KS * 128 * RED_ROW * 4;
+    static constexpr int LDS = A_BYTES > RED_BYTES ? A_BYTES : RED_BYTES;
+    static_assert(TH * TW == 128 && (N == 128 || N == 256) && (CIN == 128 || CIN == 256), "tile_conv: shapes");
+    static_assert(LDS <= 160 * 1024, "tile_conv: the input tile must fit the CU's LDS");
+};
+
+template <int TH, int TW, int KH, int KW, int CIN, int N, int EPI>
+__global__ __launch_bounds__(512, 2) void tile_conv_kernel(TileConvArgs p) {
+    using G = TcGeom<TH, TW, KH, KW, CIN, N>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tc_lds[];
+    unsigned char *lds = tc_lds;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = (int)blockIdx.x;
+    const int tx_ = tile % p.tiles_x, ty_ = (tile / p.tiles_x) % p.tiles_y, img = tile / (p.tiles_x * p.tiles_y);
+    const int x0 = tx_ * TW, y0 = ty_ * TH;
+    const long long img_base = (long long)img * p.h * p.w;
+    const int nt = wv % G::NT, ks = wv / G::NT;
+    const uint4 *__restrict__ w2 = reinterpret_cast<const uint4 *>(p.wf) + (long long)((nt * G::KS + ks) * G::STEPS) * 128 + lane;
+
+#ifdef MFTX_LF_TRACE
+    int tcount = 0;
+#endif
+    TC_T(1);
+    // weight fragments of the first steps: in flight while the input tile loads
+    constexpr int PF = 3;
+    uint4 bq[PF][2];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) { bq[s][0] = w2[s * 128]; bq[s][1] = w2[s * 128 + 64]; }
+
+    // ---- the input tile (halo included) -> LDS, 16-byte pieces, zeros outside the image
+    {
+        constexpr int PPC = CIN / 4;                         // pieces per cell
+        constexpr int TOTAL = G::HCELLS * PPC, ROUNDS = (TOTAL + 511) / 512, B = 6;
+#pragma unroll 1
+        for (int r0 = 0; r0 < ROUNDS; r0 += B) {
+            uint4 v[B];
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                const int q = (r0 + k) * 512 + tid;
+                v[k] = make_uint4(0u, 0u, 0u, 0u);
+                if (r0 + k < ROUNDS && q < TOTAL) {
+                    const int c = q / PPC, pc = q - c * PPC;
+                    const int cy = c / G::HWD, cx = c - cy * G::HWD;
+                    const int yy = y0 - KH / 2 + cy, xx = x0 - KW / 2 + cx;
+                    if (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w) {
+                        const long long cell = img_base + (long long)yy * p.w + xx;
+                        const float *src = (CIN == 256 && pc >= 32) ? p.a1 + cell * p.lda1 + (pc - 32) * 4 : p.a0 + cell * p.lda0 + pc * 4;
+                        v[k] = *reinterpret_cast<const uint4 *>(src);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                const int q = (r0 + k) * 512 + tid;
+                if (r0 + k < ROUNDS && q < TOTAL) {
+                    const int c = q / PPC, pc = q - c * PPC;
+                    *reinterpret_cast<uint4 *>(lds + c * G::CELLB + pc * 16) = v[k];
+                }
+            }
+        }
+    }
+    TC_T(2);
+    tc_barrier();
+    TC_T(3);
+
+    // ---- the K loop
+    tc_f32x16 acc[4], accx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accx[i][r] = 0.f; }
+    const unsigned char *abase[4];
+    {
+        const int r = lane & 31;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = 32 * i + r;
+            abase[i] = lds + ((m / TW) * G::HWD + (m % TW)) * G::CELLB + (lane >> 5) * 32 + ks * 64;
+        }
+    }
+    tc_f16x8 ah[2][4], al[2][4];
+    auto read_a = [&](int s, int set) {
+        const int tap = s / G::GPW, gg = s % G::GPW;
+        const int off = ((tap / KW) * G::HWD + tap % KW) * G::CELLB + gg * 64 * G::KS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[set][i] = *reinterpret_cast<const tc_f16x8 *>(abase[i] + off);
+            al[set][i] = *reinterpret_cast<const tc_f16x8 *>(abase[i] + off + 16);
+        }
+    };
+    read_a(0, 0);
+#pragma unroll
+    for (int s = 0; s < G::STEPS; ++s) {
+        const int set = s & 1;
+        const tc_f16x8 bh = __builtin_bit_cast(tc_f16x8, bq[s % PF][0]), bl = __builtin_bit_cast(tc_f16x8, bq[s % PF][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < G::STEPS) read_a(s + 1, set ^ 1);
+        if (s + PF < G::STEPS) { bq[s % PF][0] = w2[(s + PF) * 128]; bq[s % PF][1] = w2[(s + PF) * 128 + 64]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = tc_mfma(bh, ah[set][i], acc[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accx[i] = tc_mfma(bl, ah[set][i], accx[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accx[i] = tc_mfma(bh, al[set][i], accx[i]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    TC_T(4);
+    tc_barrier();           // every wave is done with the input tile: its space takes the sums
+    TC_T(5);
+
+    // ---- sums -> LDS [K split][cell][channel]
+    const float inv2048 = 1.f / 2048.f;
+    float *red = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            tc_f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * b + e] + accx[i][4 * b + e] * inv2048;
+            *reinterpret_cast<tc_f32x4 *>(red + (ks * 128 + 32 * i + (lane & 31)) * G::RED_ROW + 32 * nt + 8 * b + 4 * (lane >> 5)) = v;
+        }
+    TC_T(6);
+    tc_barrier();
+    TC_T(7);
+
+    // ---- row-wise epilogue: 8 consecutive channels of a cell per lane
+    const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));
+    constexpr int GPC = N / 8, ITEMS = 128 * GPC;
+#pragma unroll
+    for (int it = 0; it < ITEMS / 512; ++it) {
+        const int item = tid + 512 * it, m = item / GPC, n0 = (item % GPC) * 8;
+        const int yy = y0 + m / TW, xx = x0 + m % TW;
+        const float *src = red + m * G::RED_ROW + n0;
+        tc_f32x4 u = *reinterpret_cast<const tc_f32x4 *>(src), v = *reinterpret_cast<const tc_f32x4 *>(src + 4);
+        if constexpr (G::KS == 2) {
+            u += *reinterpret_cast<const tc_f32x4 *>(src + 128 * G::RED_ROW);
+            v += *reinterpret_cast<const tc_f32x4 *>(src + 128 * G::RED_ROW + 4);
+        }
+        if (yy >= p.h || xx >= p.w) continue;
+        const long long cell = img_base + (long long)yy * p.w + xx;
+        if (p.bias) {
+            u += *reinterpret_cast<const tc_f32x4 *>(p.bias + n0);
+            v += *reinterpret_cast<const tc_f32x4 *>(p.bias + n0 + 4);
+        }
+        if (p.addend) {
+            u += *reinterpret_cast<const tc_f32x4 *>(p.addend + cell * p.ld_addend + n0);
+            v += *reinterpret_cast<const tc_f32x4 *>(p.addend + cell * p.ld_addend + n0 + 4);
+        }
+        auto store_split = [&](float *row, int c0) {        // 8 channels c0 .. c0 + 7 (c0 % 8 == 0) of a split-form row
+            tc_u32x4 hi, lo;
+            tc_split8(u, v, k2048, hi, lo);
+            uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(row) + (c0 >> 3) * 32);
+            dst[0] = __builtin_bit_cast(uint4, hi);
+            dst[1] = __builtin_bit_cast(uint4, lo);
+        };
+        if constexpr (EPI == TC_GRU_ZR) {                   // [z | r] gates; r is folded into r * h (core/update.py:113-115, 119-121)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { u[e] = tc_sigmoid(u[e]); v[e] = tc_sigmoid(v[e]); }
+            if (n0 < 128) {
+                *reinterpret_cast<tc_f32x4 *>(p.z + cell * 128 + n0) = u;
+                *reinterpret_cast<tc_f32x4 *>(p.z + cell * 128 + n0 + 4) = v;
+            } else {
+                u *= *reinterpret_cast<const tc_f32x4 *>(p.hf + cell * p.ld_hf + n0 - 128);
+                v *= *reinterpret_cast<const tc_f32x4 *>(p.hf + cell * p.ld_hf + n0 - 128 + 4);
+                store_split(p.rh + cell * 128, n0 - 128);
+            }
+        } else if constexpr (EPI == TC_GRU_Q) {             // candidate q, h <- (1 - z) h + z q (core/update.py:116-117, 122-123)
+            const tc_f32x4 z0 = *reinterpret_cast<const tc_f32x4 *>(p.z + cell * 128 + n0), z1 = *reinterpret_cast<const tc_f32x4 *>(p.z + cell * 128 + n0 + 4);
+            float *hrow = p.hf + cell * p.ld_hf + n0;
+            const tc_f32x4 h0 = *reinterpret_cast<const tc_f32x4 *>(hrow), h1 = *reinterpret_cast<const tc_f32x4 *>(hrow + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { u[e] = tc_blend(z0[e], h0[e], tc_tanh(u[e])); v[e] = tc_blend(z1[e], h1[e], tc_tanh(v[e])); }
+            *reinterpret_cast<tc_f32x4 *>(hrow) = u;
+            *reinterpret_cast<tc_f32x4 *>(hrow + 4) = v;
+            store_split(p.hx + cell * p.ld_hx, n0);
+        } else {
+            if constexpr (EPI == TC_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { u[e] = relu_keep_nan(u[e]); v[e] = relu_keep_nan(v[e]); }
+            }
+            if (p.out_split) store_split(p.out + cell * p.ldo, n0);
+            else {
+                *reinterpret_cast<tc_f32x4 *>(p.out + cell * p.ldo + n0) = u;
+                *reinterpret_cast<tc_f32x4 *>(p.out + cell * p.ldo + n0 + 4) = v;
+            }
+        }
+    }
+    TC_T(8);
+}
+
+#ifdef MFTX_LF_TRACE
+extern "C" int mftx_debug_tc_trace(unsigned long long *out) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tc_trace_buf), sizeof(unsigned long long) * 8 * 16) != hipSuccess) return -1;
+    unsigned long long z[8 * 16] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(tc_trace_buf), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
+
+// ---- weights: the GEMM's packed form [>= N rows][taps][cin_pad] fp32 -> [nt][ks][step][hi | lo][lane] x 16 bytes
+__global__ void pack_tile_conv_kernel(const float *__restrict__ wpk, int taps, int cin, int cin_pad, int N, uint4 *__restrict__ out, long long pieces) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= pieces) return;
+    const int NT = N / 32, KS = 8 / NT, GPW = cin / 16 / KS, STEPS = taps * GPW;
+    const int lane = (int)(idx & 63), part = (int)((idx >> 6) & 1);
+    const long long t = idx >> 7;
+    const int step = (int)(t % STEPS), ks = (int)((t / STEPS) % KS), nt = (int)(t / STEPS / KS);
+    const int tap = step / GPW, g = (step % GPW) * KS + ks;
+    const int n = 32 * nt + (lane & 31);
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long long base = ((long long)n * taps + tap) * cin_pad + 16 * g + 8 * (lane >> 5) + 2 * e;
+        const unsigned a = split_halves(wpk[base]), b = split_halves(wpk[base + 1]);
+        w[e] = part ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+    }
+    out[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+int launch_pack_tile_conv(const float *wpk, int N, int taps, int cin, int cin_pad, void *out, hipStream_t s) {
+    if (!wpk || !out) return fail(MFTX_E_ARG, "pack_tile_conv_weights: null pointer");
+    if ((N != 128 && N != 256) || (cin != 128 && cin != 256) || (taps != 9 && taps != 5) || cin_pad < cin)
+        return fail(MFTX_E_ARG, "pack_tile_conv_weights: N in {128, 256}, cin in {128, 256}, 5 or 9 taps");
+    if (!aligned16(out)) return fail(MFTX_E_ALIGN, "pack_tile_conv_weights: output not 16-byte aligned");
+    const long long pieces = (long long)N * taps * cin * 4 / 16;
+    hipLaunchKernelGGL(pack_tile_conv_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, wpk, taps, cin, cin_pad, N,
+                       reinterpret_cast<uint4 *>(out), pieces);
+    return check_launch("pack_tile_conv");
+}
+
+template <int TH, int TW, int KH, int KW, int CIN, int N, int EPI>
+static int tc_launch(TileConvArgs a, hipStream_t s) {
+    using G = TcGeom<TH, TW, KH, KW, CIN, N>;
+    a.tiles_x = cdiv(a.w, TW); a.tiles_y = cdiv(a.h, TH);
+    const long long tiles = (long long)a.P * a.tiles_x * a.tiles_y;
+    if (tiles > 0x7fffffffLL) return fail(MFTX_E_ARG, "tile_conv: too many tiles");
+    auto kern = tile_conv_kernel<TH, TW, KH, KW, CIN, N, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess)
+            return fail(MFTX_E_STATE, "tile_conv: cannot reserve %d bytes of LDS", G::LDS);
+        attr_set = true;
+    }
+    ProfScope prof(PC_CONV_GEMM, s, 2.0 * a.P * a.h * a.w * (double)N * KH * KW * CIN);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), G::LDS, s, a);
+    return check_launch("tile_conv");
+}
+
+template <int KH, int KW, int CIN, int N>
+static int tc_dispatch_epi(const TileConvArgs &a, int epi, hipStream_t s) {
+    constexpr int TH = KH == 3 ? 8 : (KH == 1 ? 4 : 32), TW = 128 / TH;
+    switch (epi) {
+        case TC_LINEAR: return tc_launch<TH, TW, KH, KW, CIN, N, TC_LINEAR>(a, s);
+        case TC_RELU: return tc_launch<TH, TW, KH, KW, CIN, N, TC_RELU>(a, s);
+        case TC_GRU_ZR: if constexpr (N == 256 && CIN == 256) return tc_launch<TH, TW, KH, KW, CIN, N, TC_GRU_ZR>(a, s); break;
+        case TC_GRU_Q: if constexpr (N == 128 && CIN == 256) return tc_launch<TH, TW, KH, KW, CIN, N, TC_GRU_Q>(a, s); break;
+    }
+    return fail(MFTX_E_ARG, "tile_conv: no kernel for this epilogue and shape");
+}
+
+// which layers have a tile-resident kernel: 3 x 3 over 128 channels; 1 x 5 / 5 x 1 over 128 or 256; N = 128 or 256
+bool tile_conv_applicable(int kh, int kw, int cin, int N) {
+    if (N != 128 && N != 256) return false;
+    if (kh == 3 && kw == 3) return cin == 128;
+    if ((kh == 1 && kw == 5) || (kh == 5 && kw == 1)) return cin == 128 || cin == 256;
+    return false;
+}
+
+int launch_tile_conv(const TileConvLaunch &d, hipStream_t s) {
+    if (!d.a0 || !d.wf) return fail(MFTX_E_ARG, "tile_conv: null pointer");
+    if (d.P <= 0 || d.h <= 0 || d.w <= 0) return fail(MFTX_E_ARG, "tile_conv: bad sizes");
+    if (!tile_conv_applicable(d.kh, d.kw, d.cin, d.N)) return fail(MFTX_E_ARG, "tile_conv: no kernel for a %d x %d convolution over %d channels, N = %d", d.kh, d.kw, d.cin, d.N);
+    if (d.cin == 256 && !d.a1) return fail(MFTX_E_ARG, "tile_conv: 256 channels come as two segments of 128");
+    auto bad_split = [](const float *p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 31) != 0 || (ld % 8) != 0; };
+    if (bad_split(d.a0, d.lda0) || (d.cin == 256 && bad_split(d.a1, d.lda1)) || !aligned16(d.wf) || (d.bias && !aligned16(d.bias)) ||
+        (d.addend && (!aligned16(d.addend) || d.ld_addend % 4)))
+        return fail(MFTX_E_ALIGN, "tile_conv: split-form rows are 32-byte aligned with strides in multiples of 8; weights, bias and addend 16-byte aligned");
+    TileConvArgs a{};
+    a.a0 = d.a0; a.lda0 = d.lda0; a.a1 = d.a1; a.lda1 = d.lda1; a.wf = d.wf; a.bias = d.bias; a.addend = d.addend; a.ld_addend = d.ld_addend;
+    a.out = d.out; a.ldo = d.ldo; a.out_split = d.out_split;
+    a.z = d.z; a.rh = d.rh; a.hf = d.hf; a.hx = d.hx; a.ld_hf = d.ld_hf; a.ld_hx = d.ld_hx;
+    a.P = d.P; a.h = d.h; a.w = d.w;
+    if (d.epi == TC_LINEAR || d.epi == TC_RELU) {
+        if (!d.out || !aligned16(d.out) || d.ldo % 4 || (d.out_split && bad_split(d.out, d.ldo))) return fail(MFTX_E_ALIGN, "tile_conv: output misaligned");
+    } else if (d.epi == TC_GRU_ZR) {
+        if (!d.z || !d.rh || !d.hf || !aligned16(d.z) || bad_split(d.rh, 128) || !aligned16(d.hf) || d.ld_hf % 4) return fail(MFTX_E_ARG, "tile_conv: z | r epilogue operands");
+    } else if (d.epi == TC_GRU_Q) {
+        if (!d.z || !d.hf || !d.hx || !aligned16(d.z) || !aligned16(d.hf) || d.ld_hf % 4 || bad_split(d.hx, d.ld_hx)) return fail(MFTX_E_ARG, "tile_conv: q epilogue operands");
+    } else return fail(MFTX_E_ARG, "tile_conv: unknown epilogue");
+    if (d.kh == 3) return d.N == 256 ? tc_dispatch_epi<3, 3, 128, 256>(a, d.epi, s) : tc_dispatch_epi<3, 3, 128, 128>(a, d.epi, s);
+    if (d.kh == 1) {
+        if (d.cin == 128) return d.N == 256 ? tc_dispatch_epi<1, 5, 128, 256>(a, d.epi, s) : tc_dispatch_epi<1, 5, 128, 128>(a, d.epi, s);
+        return d.N == 256 ? tc_dispatch_epi<1, 5, 256, 256>(a, d.epi, s) : tc_dispatch_epi<1, 5, 256, 128>(a, d.epi, s);
+    }
+    if (d.cin == 128) return d.N == 256 ? tc_dispatch_epi<5, 1, 128, 256>(a, d.epi, s) : tc_dispatch_epi<5, 1, 128, 128>(a, d.epi, s);
+    return d.N == 256 ? tc_dispatch_epi<5, 1, 256, 256>(a, d.epi, s) : tc_dispatch_epi<5, 1, 256, 128>(a, d.epi, s);
+}
+
+}  // namespace mftx

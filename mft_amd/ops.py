@@ -357,6 +357,48 @@ def pack_lookup_convc1_weights(wpk: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_tile_conv_weights(wpk: torch.Tensor, N: int, cin: int, check_range: bool = True) -> torch.Tensor:
+    """A layer's weight in the ``pack_conv_weight`` form [>= N, taps, cin_pad] -> the weight stream of the tile-resident
+    conv kernel (``mftx_pack_tile_conv_weights``; opaque bytes, N * taps * cin * 4 of them).  Operands of the split
+    arithmetic: with ``check_range`` a value not below 65504 raises ``SplitRangeError``."""
+    lib = _lib.load()
+    if wpk.dim() != 3 or wpk.shape[0] < N or wpk.shape[2] < cin:
+        raise MftxError("pack_tile_conv_weights: expected the packed weight [>= N, taps, >= cin]")
+    if check_range:
+        bad = count_not_below(wpk, _lib.SPLIT_LIMIT)
+        if bad:
+            raise SplitRangeError(f"pack_tile_conv_weights: {bad} weights are not below {_lib.SPLIT_LIMIT} in magnitude")
+    taps = wpk.shape[1]
+    out = torch.empty(N * taps * cin * 4, dtype=torch.uint8, device=wpk.device)
+    check(lib.mftx_pack_tile_conv_weights(_chk(wpk, "wpk"), N, taps, cin, wpk.shape[2], out.data_ptr(), _stream()),
+          "mftx_pack_tile_conv_weights")
+    return out
+
+
+def tile_conv2d(x: torch.Tensor, wtile: torch.Tensor, bias, P, h, w, N, kh, kw, act=None, x2=None, addend=None,
+                out_split=False, out=None):
+    """``conv2d(..., arith=ARITH_SPLIT, a_split=True)`` on the tile-resident kernel (``mftx_tile_conv2d``): x (and x2)
+    [P*h*w, 128] in split form, wtile from ``pack_tile_conv_weights`` -> [P*h*w, N] (fp32, or split form)."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(P * h * w, N, dtype=torch.float32, device=x.device)
+    d = ConvDesc()
+    d.a0, d.lda0, d.c0 = _chk(x, "x"), x.shape[1], x.shape[1]
+    if x2 is not None:
+        d.a1, d.lda1, d.c1 = _chk(x2, "x2"), x2.shape[1], x2.shape[1]
+    else:
+        d.a1, d.lda1, d.c1 = None, 0, 0
+    d.wpk = None
+    d.bias = _chk(bias, "bias") if bias is not None else None
+    d.out, d.ldo = _chk(out, "out"), out.shape[1]
+    d.P, d.h, d.w, d.N, d.kh, d.kw = P, h, w, N, kh, kw
+    d.act, d.out_scale = ACT[act], 1.0
+    d.addend, d.ld_addend = (_chk(addend, "addend"), addend.shape[1]) if addend is not None else (None, 0)
+    d.arith, d.a_split, d.out_split = ARITH_SPLIT, 1, int(bool(out_split))
+    check(lib.mftx_tile_conv2d(C.byref(d), _chk(wtile, "wtile", torch.uint8), _stream()), "mftx_tile_conv2d")
+    return out
+
+
 def pack_flow_branch_weights(w98: torch.Tensor, w2pk: torch.Tensor, check_range: bool = True) -> torch.Tensor:
     """convf1's weight as [98 = (ky, kx, c), 128] and convf2's in the ``pack_conv_weight`` form [>= 64, 9, 128] -> the
     fragment streams of the fused flow-branch kernel (``mftx_pack_flow_branch_weights``; opaque bytes).  The weights are
@@ -607,10 +649,14 @@ class RaftEngine:
     # WeightSlot indices (csrc/raft_engine.hip) of the weights that feed GEMM layers
     GEMM_SLOTS = (0, 2, 6, 8, 10, 11, 13, 14, 16, 17, 19, 20, 22, 26, 28, 30)
 
-    OPTIONS = {"fork": 0, "presplit": 1, "group": 2, "fuse_lookup": 3, "graph": 4, "fuse_flow": 5}      # MFTX_RAFT_OPT_*
+    OPTIONS = {"fork": 0, "presplit": 1, "group": 2, "fuse_lookup": 3, "graph": 4, "fuse_flow": 5, "tile_conv": 6}      # MFTX_RAFT_OPT_*
+    # WeightSlot -> (N, cin) of the layers with a tile-resident kernel (csrc/tile_conv.hip): GRU gates (per-iteration and
+    # context parts, both passes), flow head and mask head first layers
+    TILE_SLOTS = {10: (256, 256), 11: (256, 128), 13: (128, 256), 14: (128, 128), 16: (256, 256), 17: (256, 128),
+                  19: (128, 256), 20: (128, 128), 22: (256, 128), 26: (256, 128)}
 
     def __init__(self, state_dict: dict, device, ondemand_corr=False, arith=ARITH_SPLIT, options=None):
-        """options: {"fork" | "presplit" | "group" | "fuse_lookup" | "graph" | "fuse_flow": int} scheduling options of this handle
+        """options: {"fork" | "presplit" | "group" | "fuse_lookup" | "graph" | "fuse_flow" | "tile_conv": int} scheduling options of this handle
         (``mftx_raft_set_option``; defaults are the measured best)."""
         lib = _lib.load()
         self.device = torch.device(device)
@@ -631,6 +677,11 @@ class RaftEngine:
             # the flow branch (convf1 -> convf2) as one kernel: both weights as its fragment streams
             self.wflow = pack_flow_branch_weights(self.weights[4], self.weights[6])
             check(lib.mftx_raft_set_flow_fused(self._h, self.wflow.data_ptr()), "mftx_raft_set_flow_fused")
+            # the layers whose input tile fits a CU's LDS: weights as the streams of the tile-resident kernel
+            self.wtile = [pack_tile_conv_weights(t, *self.TILE_SLOTS[i]) if i in self.TILE_SLOTS else None
+                          for i, t in enumerate(self.weights)]
+            tarr, self._keep_tile = _lib.ptr_array([t.data_ptr() if t is not None else None for t in self.wtile])
+            check(lib.mftx_raft_set_tile_weights(self._h, tarr, len(self.wtile)), "mftx_raft_set_tile_weights")
         elif self.arith != ARITH_F32:
             raise MftxError(f"unknown arithmetic {arith!r}")
         for k, v in (options or {}).items():

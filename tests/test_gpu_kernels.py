@@ -963,7 +963,7 @@ def test_engine_register_split_bitwise():
     other epilogue variants, GRU state in fp32 only) agrees with the default engine (activations stored in split form by
     their producers) to the last digits; with the flow branch in order on one stream (fork = 0) and with the grouped
     launches kept apart (group = 0) bit for bit.  Options are per handle (mftx_raft_set_option), not process state."""
-    base = {"fuse_lookup": 0, "fuse_flow": 0}
+    base = {"fuse_lookup": 0, "fuse_flow": 0, "tile_conv": 0}
     outs = {tag: _engine_outputs(dict(base, **extra)) for tag, extra in
             (("default", {}), ("nopresplit", {"presplit": 0}), ("nofork", {"fork": 0}), ("nogroup", {"group": 0, "fork": 0}))}
     assert np.isfinite(outs["default"]).all()
@@ -1064,6 +1064,68 @@ def test_engine_fused_flow_matches_unfused():
     epe = np.sqrt((d ** 2).sum(1)).mean()
     assert epe < 1e-4, epe
     assert np.abs(fused[n:] - apart[n:]).max() < 1e-3
+
+
+@pytest.mark.parametrize("cin,cout,kh,kw,P,h,w,act", [
+    (128, 256, 3, 3, 2, 21, 37, "relu"), (128, 256, 3, 3, 1, 64, 64, "relu"), (128, 128, 3, 3, 1, 9, 5, None),
+    (256, 256, 1, 5, 2, 13, 70, None), (256, 256, 5, 1, 1, 70, 13, "relu"), (256, 128, 1, 5, 1, 24, 40, None),
+    (256, 128, 5, 1, 3, 40, 24, None), (128, 256, 1, 5, 1, 16, 33, None), (128, 128, 5, 1, 1, 33, 16, "relu")])
+def test_tile_conv_vs_conv_gemm_and_fp64(ops_mod, cin, cout, kh, kw, P, h, w, act):
+    """The tile-resident kernel (mftx_tile_conv2d) against the ring-buffered GEMM on the same split-form operands and
+    against fp64: whole and ragged tiles, images smaller than a tile, both channel segments, bias + addend, fp32 and
+    split-form outputs."""
+    g = torch.Generator().manual_seed(cin + cout + kh)
+    M = P * h * w
+    x = torch.randn(M, cin, generator=g)
+    wt = torch.randn(cout, cin, kh, kw, generator=g) * 0.05
+    b = torch.randn(cout, generator=g)
+    add = torch.randn(M, cout, generator=g)
+    wpk = ops_mod.pack_conv_weight(wt.cuda())
+    xs = ops_mod.split_activations(x.cuda())
+    x1, x2 = (xs, None) if cin == 128 else (xs[:, :128].contiguous(), xs[:, 128:].contiguous())
+    wtile = ops_mod.pack_tile_conv_weights(wpk, cout, cin)
+    got = ops_mod.tile_conv2d(x1, wtile, b.cuda(), P, h, w, cout, kh, kw, act=act, x2=x2, addend=add.cuda())
+    ref = ops_mod.conv2d(x1, ops_mod.split_weights(wpk), b.cuda(), P, h, w, cout, kh, kw, act=act, x2=x2, addend=add.cuda(),
+                         arith=1, a_split=True)
+    xi = x.double().reshape(P, h, w, cin).permute(0, 3, 1, 2)
+    r64 = torch.nn.functional.conv2d(xi, wt.double(), b.double(), padding=(kh // 2, kw // 2)).permute(0, 2, 3, 1).reshape(M, cout) + add.double()
+    if act == "relu":
+        r64 = torch.relu(r64)
+    scale = float(r64.abs().max())
+    e_tile, e_ring = float((got.cpu().double() - r64).abs().max()), float((ref.cpu().double() - r64).abs().max())
+    assert e_tile < 3e-6 * scale and e_tile < 2 * e_ring + 1e-6 * scale, (e_tile, e_ring, scale)
+    gs = ops_mod.tile_conv2d(x1, wtile, b.cuda(), P, h, w, cout, kh, kw, act=act, x2=x2, addend=add.cuda(), out_split=True)
+    assert torch.equal(gs, ops_mod.split_activations(got))
+
+
+def test_tile_conv_batch_invariance_and_argument_errors(ops_mod):
+    g = torch.Generator().manual_seed(2)
+    P, h, w = 3, 24, 40
+    x = ops_mod.split_activations(torch.randn(P * h * w, 128, generator=g).cuda())
+    wpk = ops_mod.pack_conv_weight((torch.randn(256, 128, 3, 3, generator=g) * 0.05).cuda())
+    wtile = ops_mod.pack_tile_conv_weights(wpk, 256, 128)
+    full = ops_mod.tile_conv2d(x, wtile, None, P, h, w, 256, 3, 3, act="relu")
+    for k in range(P):
+        one = ops_mod.tile_conv2d(x[k * h * w:(k + 1) * h * w].contiguous(), wtile, None, 1, h, w, 256, 3, 3, act="relu")
+        assert torch.equal(one, full[k * h * w:(k + 1) * h * w]), k
+    with pytest.raises(ops_mod.MftxError):          # 3 x 3 over 256 channels does not fit a CU's LDS: no kernel
+        ops_mod.tile_conv2d(x, wtile, None, P, h, w, 256, 3, 3, x2=x)
+    with pytest.raises(ops_mod.MftxError):
+        ops_mod.tile_conv2d(x, wtile, None, P, h, w, 192, 3, 3)
+    with pytest.raises(ops_mod.SplitRangeError):
+        ops_mod.pack_tile_conv_weights(torch.full((256, 9, 128), 1e5, device=DEV), 256, 128)
+
+
+def test_engine_tile_conv_matches_ring_gemm():
+    """The engine with the GRU gates, their context parts and the flow / mask heads' first layers on the tile-resident
+    kernel (the default) against the same engine with every layer on the ring-buffered GEMM: fp32 rounding of the K sums."""
+    tiled, ring = _engine_outputs({}), _engine_outputs({"tile_conv": 0})
+    assert np.isfinite(tiled).all()
+    n = 3 * 2 * 192 * 320
+    d = (tiled[:n] - ring[:n]).reshape(3, 2, -1)
+    epe = np.sqrt((d ** 2).sum(1)).mean()
+    assert epe < 1e-4, epe
+    assert np.abs(tiled[n:] - ring[n:]).max() < 1e-3
 
 
 def _tile_layers(arith, tile, ref=False):
