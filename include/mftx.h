@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MFTX_VERSION 302
+#define MFTX_VERSION 303
 
 #define MFTX_E_ARG (-1)      /* null pointer / non-positive size / unsupported shape */
 #define MFTX_E_ALIGN (-2)    /* pointer or leading dimension not 16-byte aligned */
@@ -186,6 +186,18 @@ int mftx_conv2d_tile(const mftx_conv_desc *d, int tile, void *stream);
  * mftx_conv2d packing wpk = [>= N rows][taps][cin_pad] fp32.  d->wpk is ignored. */
 int mftx_pack_tile_conv_weights(const float *wpk, int N, int taps, int cin, int cin_pad, void *wtile, void *stream);
 int mftx_tile_conv2d(const mftx_conv_desc *d, const void *wtile, void *stream);
+/* The flow head (core/update.py:6-14: delta = conv2(relu(conv1(h))), 3 x 3, 128 -> 256 -> 2) without materialising the 256
+ * hidden channels: the tile-resident kernel keeps relu(conv1) of a tile in LDS and multiplies it there with conv2's filter
+ * as a [256 x 18] matrix -- T[m][2 tap + o], the partial product of cell m for tap and output o -- and a second small
+ * kernel adds the nine shifted terms: delta[m][o] = b2[o] + sum_tap T[m + offset(tap)][2 tap + o] (zero padding), and, when
+ * coords is given, coords[m][o] += delta[m][o] (core/raft.py:184).
+ * hsplit: h in split form, 128 channels at hsplit + m * ld_h floats; wtile: conv1's weight from mftx_pack_tile_conv_weights
+ * (N = 256, 9 taps, cin = 128); wproj: 32768 bytes filled by mftx_pack_flow_head_weights from conv2's weight in the
+ * mftx_conv2d packing [>= 2 rows][9][256]; b1: 256 floats, b2: 2; T: [P*h*w][18] floats of scratch; delta: [P*h*w][2]. */
+#define MFTX_FLOW_HEAD_WEIGHT_BYTES 32768
+int mftx_pack_flow_head_weights(const float *w2pk, void *wproj, void *stream);
+int mftx_flow_head(const float *hsplit, int ld_h, int P, int h, int w, const void *wtile, const float *b1, const void *wproj,
+                   const float *b2, float *T, float *delta, float *coords, void *stream);
 /* packed fp32 weights (n_floats of them, a multiple of 8) -> the split form MFTX_ARITH_SPLIT streams: same size,
  * every 8 consecutive floats replaced by their 8 fp16 high halves and 8 fp16 low halves (x 2048) */
 int mftx_split_weights(const float *wpk, void *out, long long n_floats, void *stream);
@@ -232,6 +244,9 @@ int mftx_raft_set_flow_fused(mftx_raft *r, const void *wflow);
  * and of the mask head -- NULL elsewhere (and NULL for a layer to keep on mftx_conv2d's kernel); with the split arithmetic
  * those layers then run on csrc/tile_conv.hip.  The pointers are kept.  tile = NULL: off. */
 int mftx_raft_set_tile_weights(mftx_raft *r, const void *const *tile, int n);
+/* wproj (mftx_pack_flow_head_weights of the engine's flow_head.conv2 weight; kept): with the flow head's first layer on the
+ * tile-resident kernel, both layers run as mftx_flow_head does.  NULL: off. */
+int mftx_raft_set_flow_head(mftx_raft *r, const void *wproj);
 /* Debug payload of RAFT.forward(vis_debug=True) (core/raft.py:159-176, 255-257): trace = (iters + 1) x [P*h*w][2] floats
  * (device, kept) receives coords1 as every iteration finds it and, last, as the final iteration leaves it; NULL: off.  The
  * cost-volume pyramid of the same call stays in the workspace (mftx_raft_workspace_layout_for: lvl0..3). */
@@ -246,7 +261,8 @@ int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
  *                            replayed as a hipGraph from then on: same kernels, same bits, ~170 launches less host work),
  *                            0 plain launches
  *   MFTX_RAFT_OPT_FUSE_FLOW  1 default (use the fused convf1 + convf2 kernel when its weights are set), 0 keep them apart
- *   MFTX_RAFT_OPT_TILE_CONV  1 default (layers with tile-resident weights set run on that kernel), 0 all on mftx_conv2d's */
+ *   MFTX_RAFT_OPT_TILE_CONV  1 default (layers with tile-resident weights set run on that kernel), 0 all on mftx_conv2d's
+ *   MFTX_RAFT_OPT_FUSE_HEAD  1 default (both layers of the flow head as mftx_flow_head when its weights are set), 0 two layers */
 #define MFTX_RAFT_OPT_FORK 0
 #define MFTX_RAFT_OPT_PRESPLIT 1
 #define MFTX_RAFT_OPT_GROUP 2
@@ -254,6 +270,7 @@ int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
 #define MFTX_RAFT_OPT_GRAPH 4
 #define MFTX_RAFT_OPT_FUSE_FLOW 5
 #define MFTX_RAFT_OPT_TILE_CONV 6
+#define MFTX_RAFT_OPT_FUSE_HEAD 7
 int mftx_raft_set_option(mftx_raft *r, int option, int value);
 /* graphs captured / graph launches so far (tests, bench) */
 int mftx_raft_graph_stats(const mftx_raft *r, unsigned long long *captures, unsigned long long *replays);

@@ -13,6 +13,7 @@ MAX_CANDIDATES = 16
 NUM_RAFT_WEIGHTS = 34
 LOOKUP_CONVC1_WEIGHT_BYTES = 393216
 FLOW_BRANCH_WEIGHT_BYTES = 352256
+FLOW_HEAD_WEIGHT_BYTES = 32768
 SPLIT_LIMIT = 65504.0      # MFTX_SPLIT_LIMIT: operands of the split arithmetic must stay below it in magnitude
 
 
@@ -55,6 +56,9 @@ SIGNATURES = {
     "mftx_raft_set_lookup_fused": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mftx_raft_set_flow_fused": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mftx_raft_set_tile_weights": (C.c_int, [C.c_void_p, _PP, C.c_int]),
+    "mftx_raft_set_flow_head": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mftx_pack_flow_head_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mftx_flow_head": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8),
     "mftx_pack_tile_conv_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mftx_tile_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p]),
     "mftx_pack_flow_branch_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

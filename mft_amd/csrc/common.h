@@ -159,8 +159,11 @@ struct TileConvLaunch {
     const float *addend; int ld_addend; // pre-activation addend [M][N] or null
     float *out; int ldo; int out_split; // epi 0 (linear) / 1 (relu)
     float *z, *rh, *hf, *hx; int ld_hf, ld_hx;      // epi 2 (z | r gates) / 3 (candidate + blend): as GruEpilogue
+    const void *wproj; float *tout;     // epi 4 (flow head: relu, then the next layer's 3 x 3 x 2 filter as [256 x 18] partial products -> tout [M][18])
     int P, h, w, N, kh, kw, epi;
 };
+int launch_pack_flow_head(const float *w2pk, void *out, hipStream_t s);
+int launch_flow_head_sum(const float *T, const float *b2, float *delta, float *coords, int P, int h, int w, hipStream_t s);
 bool tile_conv_applicable(int kh, int kw, int cin, int N);
 int launch_pack_tile_conv(const float *wpk, int N, int taps, int cin, int cin_pad, void *out, hipStream_t s);
 int launch_tile_conv(const TileConvLaunch &d, hipStream_t s);

@@ -183,8 +183,9 @@ struct mftx_raft {
     GraphCache *graphs;            // the refinement's launch sequence between its first and last kernels, captured per (shape, workspace, mode)
     const void *wfused;            // convc1's weights for the fused lookup + convc1 kernel (csrc/lookup_convc1.hip), or null
     const void *wflow;             // convf1's and convf2's weights for the fused flow-branch kernel (csrc/flow_branch.hip), or null
+    const void *wproj;             // the flow head's last layer as the projection epilogue of its first (csrc/tile_conv.hip: TC_RELU_PROJ), or null
     const void *wt[W_COUNT];       // weight streams of the tile-resident conv kernel (csrc/tile_conv.hip) per slot, or null
-    int opt[7];                    // MFTX_RAFT_OPT_*
+    int opt[8];                    // MFTX_RAFT_OPT_*
 };
 // weights that go through the conv GEMM (the others feed VALU kernels and stay fp32)
 static constexpr int GEMM_SLOTS[] = {W_CONVC1, W_CONVC2, W_CONVF2, W_CONV, W_ZR1_DYN, W_ZR1_INP, W_Q1_DYN, W_Q1_INP,
@@ -206,10 +207,11 @@ extern "C" int mftx_raft_create(const float *const *weights, int n_weights, mftx
     r->side = nullptr; r->ev_fork = nullptr; r->ev_join = nullptr;
     r->wfused = nullptr;
     r->wflow = nullptr;
+    r->wproj = nullptr;
     for (int i = 0; i < W_COUNT; ++i) r->wt[i] = nullptr;
     r->coords_trace = nullptr;
     r->graphs = new (std::nothrow) GraphCache;
-    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1; r->opt[MFTX_RAFT_OPT_FUSE_FLOW] = 1; r->opt[MFTX_RAFT_OPT_TILE_CONV] = 1;
+    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1; r->opt[MFTX_RAFT_OPT_FUSE_FLOW] = 1; r->opt[MFTX_RAFT_OPT_TILE_CONV] = 1; r->opt[MFTX_RAFT_OPT_FUSE_HEAD] = 1;
     for (int i = 0; i < W_COUNT; ++i) r->w[i] = r->wg[i] = weights[i];
     *out = r;
     return 0;
@@ -293,6 +295,14 @@ extern "C" int mftx_raft_set_tile_weights(mftx_raft *r, const void *const *tile,
     return 0;
 }
 
+extern "C" int mftx_raft_set_flow_head(mftx_raft *r, const void *wproj) {
+    if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_flow_head: bad handle");
+    if (wproj && !aligned16(wproj)) return fail(MFTX_E_ALIGN, "raft_set_flow_head: weights not 16-byte aligned");
+    r->wproj = wproj;
+    if (r->graphs) r->graphs->clear();
+    return 0;
+}
+
 extern "C" int mftx_raft_set_coords_trace(mftx_raft *r, float *trace) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_coords_trace: bad handle");
     r->coords_trace = trace;
@@ -301,7 +311,7 @@ extern "C" int mftx_raft_set_coords_trace(mftx_raft *r, float *trace) {
 
 extern "C" int mftx_raft_set_option(mftx_raft *r, int option, int value) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_option: bad handle");
-    if (option < 0 || option > MFTX_RAFT_OPT_TILE_CONV) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
+    if (option < 0 || option > MFTX_RAFT_OPT_FUSE_HEAD) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
     r->opt[option] = value;
     if (r->graphs) r->graphs->clear();
     return 0;
@@ -541,13 +551,21 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
             }
         }
         // flow head (core/update.py:6-14) and coordinate update (core/raft.py:184)
-        if (tile_w(W_FH1)) {
+        const bool head_fused = tile_w(W_FH1) && r->wproj != nullptr && r->opt[MFTX_RAFT_OPT_FUSE_HEAD] != 0;
+        if (head_fused) {
+            // both layers of the flow head: relu(conv1) stays in LDS, multiplied there with conv2's filter as [256 x 18] partial
+            // products per cell (-> ws.fh, [M][18]); the nine shifted terms are added, and coords1 updated, by a small kernel
+            TileConvLaunch t = tile_layer(ws.hx, 384, nullptr, 0, tile_w(W_FH1), W[B_FH1], 256, 3, 3, 4);
+            t.wproj = r->wproj; t.tout = ws.fh;
+            TRY(launch_tile_conv(t, s));
+            TRY(launch_flow_head_sum(ws.fh, W[B_FH2], ws.delta, ws.coords1, P, h, w, s));
+        } else if (tile_w(W_FH1)) {
             TileConvLaunch t = tile_layer(ws.hx, 384, nullptr, 0, tile_w(W_FH1), W[B_FH1], 256, 3, 3, 1);
             t.out = ws.fh; t.ldo = 256;
             TRY(launch_tile_conv(t, s));
         } else TRY(launch_conv(gemm(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, G[W_FH1], W[B_FH1], ws.fh, 256, P, h, w, 256, 3, 3, 1), true, false), s));
         // last layer of the flow head, fused with coords1 += delta_flow (core/raft.py:184)
-        {
+        if (!head_fused) {
             const mftx_conv_desc fh2 = conv_desc(ws.fh, 256, 256, nullptr, 0, 0, W[W_FH2], W[B_FH2], ws.delta, 2, P, h, w, 2, 3, 3, 0);
             if (!conv_small_applicable(fh2)) return fail(MFTX_E_STATE, "raft_refine: flow-head layer does not fit the small-N kernel");
             TRY(launch_conv_small(fh2, s, ws.coords1, 2));
@@ -583,7 +601,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         key.v[0] = (uintptr_t)P; key.v[1] = (uintptr_t)h; key.v[2] = (uintptr_t)w; key.v[3] = (uintptr_t)iters;
         key.v[4] = reinterpret_cast<uintptr_t>(workspace); key.v[5] = reinterpret_cast<uintptr_t>(flow_lr_out);
         key.v[6] = (uintptr_t)AR; key.v[7] = reinterpret_cast<uintptr_t>(r->wfused); key.v[8] = reinterpret_cast<uintptr_t>(s);
-        key.v[9] = reinterpret_cast<uintptr_t>(r->wflow); key.v[10] = reinterpret_cast<uintptr_t>(r->wt[W_ZR1_DYN]);
+        key.v[9] = reinterpret_cast<uintptr_t>(r->wflow); key.v[10] = reinterpret_cast<uintptr_t>(r->wt[W_ZR1_DYN]); key.v[11] = reinterpret_cast<uintptr_t>(r->wproj);
         TRY(r->graphs->run(key, s, core));
     } else {
         TRY(core());
@@ -680,6 +698,20 @@ extern "C" int mftx_tile_conv2d(const mftx_conv_desc *d, const void *wtile, void
     t.addend = d->addend; t.ld_addend = d->ld_addend; t.out = d->out; t.ldo = d->ldo; t.out_split = d->out_split;
     t.P = d->P; t.h = d->h; t.w = d->w; t.N = d->N; t.kh = d->kh; t.kw = d->kw; t.epi = d->act;
     return launch_tile_conv(t, (hipStream_t)stream);
+}
+
+extern "C" int mftx_pack_flow_head_weights(const float *w2pk, void *wproj, void *stream) {
+    return launch_pack_flow_head(w2pk, wproj, (hipStream_t)stream);
+}
+
+extern "C" int mftx_flow_head(const float *hsplit, int ld_h, int P, int h, int w, const void *wtile, const float *b1, const void *wproj,
+                              const float *b2, float *T, float *delta, float *coords, void *stream) {
+    if (!hsplit || !wtile || !b1 || !wproj || !b2 || !T || !delta) return fail(MFTX_E_ARG, "flow_head: null pointer");
+    TileConvLaunch t{};
+    t.a0 = hsplit; t.lda0 = ld_h; t.cin = 128; t.wf = wtile; t.bias = b1; t.wproj = wproj; t.tout = T;
+    t.P = P; t.h = h; t.w = w; t.N = 256; t.kh = 3; t.kw = 3; t.epi = 4;
+    if (int e = launch_tile_conv(t, (hipStream_t)stream)) return e;
+    return launch_flow_head_sum(T, b2, delta, coords, P, h, w, (hipStream_t)stream);
 }
 
 extern "C" int mftx_pack_flow_branch_weights(const float *w98, const float *w2pk, void *wflow, void *stream) {

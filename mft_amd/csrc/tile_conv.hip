@@ -32,7 +32,8 @@ typedef float tc_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned tc_u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 tc_f16x8 __attribute__((ext_vector_type(8)));
 
-enum TcEpi { TC_LINEAR = 0, TC_RELU = 1, TC_GRU_ZR = 2, TC_GRU_Q = 3 };
+enum TcEpi { TC_LINEAR = 0, TC_RELU = 1, TC_GRU_ZR = 2, TC_GRU_Q = 3,
+             TC_RELU_PROJ = 4 };     // relu(. + bias) is not stored: it is multiplied, in place, with the NEXT layer's 3 x 3 x 2 filter (see below)
 
 // Tuning builds only (-DMFTX_LF_TRACE): s_memtime stamps of workgroup 0's waves at the phase boundaries (tools/tc_trace.py)
 #ifdef MFTX_LF_TRACE
@@ -51,6 +52,7 @@ struct TileConvArgs {
     const float *addend; int ld_addend;     // pre-activation addend [M][N] fp32 or null
     float *out; int ldo; int out_split;     // TC_LINEAR / TC_RELU
     float *z, *rh, *hf, *hx; int ld_hf, ld_hx;      // GRU epilogues (conv_gemm.hip: GruEpilogue)
+    const void *wproj; float *tout;                 // TC_RELU_PROJ: the next layer's filter (launch_pack_flow_head) and the [M][18] partial products
     int P, h, w, tiles_x, tiles_y;
 };
 
@@ -113,6 +115,7 @@ struct TcGeom {
     static constexpr int RED_ROW = N + 4;                   // floats per cell of the parked sums
     static constexpr int A_BYTES = HCELLS * CELLB, RED_BYTES = KS * 128 * RED_ROW * 4;
     static constexpr int LDS = A_BYTES > RED_BYTES ? A_BYTES : RED_BYTES;
+    static constexpr int PROJ_ROW = 20, PROJ_BYTES = 2 * 128 * PROJ_ROW * 4;        // TC_RELU_PROJ: two K halves of [cell][18 (+ 2)] behind the parked sums
     static_assert(TH * TW == 128 && (N == 128 || N == 256) && (CIN == 128 || CIN == 256), "tile_conv: shapes");
     static_assert(LDS <= 160 * 1024, "tile_conv: the input tile must fit the CU's LDS");
 };
@@ -238,8 +241,61 @@ __global__ __launch_bounds__(512, 2) void tile_conv_kernel(TileConvArgs p) {
     tc_barrier();
     TC_T(7);
 
-    // ---- row-wise epilogue: 8 consecutive channels of a cell per lane
     const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));
+    if constexpr (EPI == TC_RELU_PROJ) {
+        // The flow head (core/update.py:6-14): delta = conv2(relu(conv1(h))), conv2 a 3 x 3 filter with TWO outputs.  Its 256
+        // input channels are this kernel's output, and by linearity
+        //     delta[c][o] = b2[o] + sum over taps t of T[c + offset(t)][t][o],   T[c'][t][o] = sum_k relu(conv1)[c'][k] W2[o][k][t]:
+        // the 18 numbers T[c'][.][.] need cell c' alone.  So relu(conv1) -- 29 MB per iteration at 7 pairs of 512 x 512 -- is
+        // never stored: the tile's [128 cells x 256] block, parked in LDS, is multiplied here with W2 as a [256 x 18] matrix
+        // (split arithmetic; 192 more MFMAs after the layer's 6912) and only T leaves (2 MB); flow_head_sum_kernel adds the
+        // nine shifted terms.  Wave (row tile mt, K half kh): 8 k groups; the halves meet in LDS, summed in a fixed order.
+        const int mt = wv & 3, kh = wv >> 2;
+        const uint4 *__restrict__ wp = reinterpret_cast<const uint4 *>(p.wproj) + lane;
+        tc_f32x16 d, dx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { d[r] = 0.f; dx[r] = 0.f; }
+        const float *xrow = red + (32 * mt + (lane & 31)) * G::RED_ROW + 8 * (lane >> 5);
+#pragma unroll
+        for (int gg = 0; gg < 8; ++gg) {
+            const int g = 8 * kh + gg;
+            tc_f32x4 u = *reinterpret_cast<const tc_f32x4 *>(xrow + 16 * g), v = *reinterpret_cast<const tc_f32x4 *>(xrow + 16 * g + 4);
+            u += *reinterpret_cast<const tc_f32x4 *>(p.bias + 16 * g + 8 * (lane >> 5));
+            v += *reinterpret_cast<const tc_f32x4 *>(p.bias + 16 * g + 8 * (lane >> 5) + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { u[e] = relu_keep_nan(u[e]); v[e] = relu_keep_nan(v[e]); }
+            tc_u32x4 hi, lo;
+            tc_split8(u, v, k2048, hi, lo);
+            const tc_f16x8 wh = __builtin_bit_cast(tc_f16x8, wp[(g * 2) * 64]), wl = __builtin_bit_cast(tc_f16x8, wp[(g * 2 + 1) * 64]);
+            asm volatile("s_nop 1" : "+v"(hi), "+v"(lo));      // (the split's results, two wait states before the MFMA reads them)
+            const tc_f16x8 xh = __builtin_bit_cast(tc_f16x8, hi), xl = __builtin_bit_cast(tc_f16x8, lo);
+            d = tc_mfma(wh, xh, d);
+            dx = tc_mfma(wl, xh, dx);
+            dx = tc_mfma(wh, xl, dx);
+        }
+        float *tp = reinterpret_cast<float *>(lds + G::RED_BYTES);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j0 = 8 * b + 4 * (lane >> 5);          // this lane's outputs j0 .. j0 + 3 of cell 32 mt + (lane & 31); 18 exist
+            if (j0 < G::PROJ_ROW) {
+                tc_f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = d[4 * b + e] + dx[4 * b + e] * inv2048;
+                *reinterpret_cast<tc_f32x4 *>(tp + (kh * 128 + 32 * mt + (lane & 31)) * G::PROJ_ROW + j0) = v;
+            }
+        }
+        tc_barrier();
+        for (int idx = tid; idx < 128 * 18; idx += 512) {
+            const int m = idx / 18, j = idx - m * 18;
+            const int yy = y0 + m / TW, xx = x0 + m % TW;
+            if (yy < p.h && xx < p.w)
+                p.tout[(img_base + (long long)yy * p.w + xx) * 18 + j] = tp[m * G::PROJ_ROW + j] + tp[(128 + m) * G::PROJ_ROW + j];
+        }
+        TC_T(8);
+        return;
+    }
+
+    // ---- row-wise epilogue: 8 consecutive channels of a cell per lane
     constexpr int GPC = N / 8, ITEMS = 128 * GPC;
 #pragma unroll
     for (int it = 0; it < ITEMS / 512; ++it) {
@@ -349,14 +405,16 @@ static int tc_launch(TileConvArgs a, hipStream_t s) {
     const long long tiles = (long long)a.P * a.tiles_x * a.tiles_y;
     if (tiles > 0x7fffffffLL) return fail(MFTX_E_ARG, "tile_conv: too many tiles");
     auto kern = tile_conv_kernel<TH, TW, KH, KW, CIN, N, EPI>;
+    constexpr int lds_bytes = G::LDS + (EPI == TC_RELU_PROJ ? G::PROJ_BYTES : 0);
+    static_assert(lds_bytes <= 160 * 1024, "tile_conv: LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess)
-            return fail(MFTX_E_STATE, "tile_conv: cannot reserve %d bytes of LDS", G::LDS);
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+            return fail(MFTX_E_STATE, "tile_conv: cannot reserve %d bytes of LDS", lds_bytes);
         attr_set = true;
     }
-    ProfScope prof(PC_CONV_GEMM, s, 2.0 * a.P * a.h * a.w * (double)N * KH * KW * CIN);
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), G::LDS, s, a);
+    ProfScope prof(PC_CONV_GEMM, s, 2.0 * a.P * a.h * a.w * ((double)N * KH * KW * CIN + (EPI == TC_RELU_PROJ ? 256.0 * 18 : 0.0)));
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds_bytes, s, a);
     return check_launch("tile_conv");
 }
 
@@ -368,6 +426,7 @@ static int tc_dispatch_epi(const TileConvArgs &a, int epi, hipStream_t s) {
         case TC_RELU: return tc_launch<TH, TW, KH, KW, CIN, N, TC_RELU>(a, s);
         case TC_GRU_ZR: if constexpr (N == 256 && CIN == 256) return tc_launch<TH, TW, KH, KW, CIN, N, TC_GRU_ZR>(a, s); break;
         case TC_GRU_Q: if constexpr (N == 128 && CIN == 256) return tc_launch<TH, TW, KH, KW, CIN, N, TC_GRU_Q>(a, s); break;
+        case TC_RELU_PROJ: if constexpr (N == 256 && CIN == 128 && KH == 3) return tc_launch<TH, TW, KH, KW, CIN, N, TC_RELU_PROJ>(a, s); break;
     }
     return fail(MFTX_E_ARG, "tile_conv: no kernel for this epilogue and shape");
 }
@@ -393,6 +452,7 @@ int launch_tile_conv(const TileConvLaunch &d, hipStream_t s) {
     a.a0 = d.a0; a.lda0 = d.lda0; a.a1 = d.a1; a.lda1 = d.lda1; a.wf = d.wf; a.bias = d.bias; a.addend = d.addend; a.ld_addend = d.ld_addend;
     a.out = d.out; a.ldo = d.ldo; a.out_split = d.out_split;
     a.z = d.z; a.rh = d.rh; a.hf = d.hf; a.hx = d.hx; a.ld_hf = d.ld_hf; a.ld_hx = d.ld_hx;
+    a.wproj = d.wproj; a.tout = d.tout;
     a.P = d.P; a.h = d.h; a.w = d.w;
     if (d.epi == TC_LINEAR || d.epi == TC_RELU) {
         if (!d.out || !aligned16(d.out) || d.ldo % 4 || (d.out_split && bad_split(d.out, d.ldo))) return fail(MFTX_E_ALIGN, "tile_conv: output misaligned");
@@ -400,6 +460,8 @@ int launch_tile_conv(const TileConvLaunch &d, hipStream_t s) {
         if (!d.z || !d.rh || !d.hf || !aligned16(d.z) || bad_split(d.rh, 128) || !aligned16(d.hf) || d.ld_hf % 4) return fail(MFTX_E_ARG, "tile_conv: z | r epilogue operands");
     } else if (d.epi == TC_GRU_Q) {
         if (!d.z || !d.hf || !d.hx || !aligned16(d.z) || !aligned16(d.hf) || d.ld_hf % 4 || bad_split(d.hx, d.ld_hx)) return fail(MFTX_E_ARG, "tile_conv: q epilogue operands");
+    } else if (d.epi == TC_RELU_PROJ) {
+        if (!d.wproj || !d.tout || !d.bias || !aligned16(d.wproj) || !aligned16(d.tout)) return fail(MFTX_E_ARG, "tile_conv: projection epilogue operands");
     } else return fail(MFTX_E_ARG, "tile_conv: unknown epilogue");
     if (d.kh == 3) return d.N == 256 ? tc_dispatch_epi<3, 3, 128, 256>(a, d.epi, s) : tc_dispatch_epi<3, 3, 128, 128>(a, d.epi, s);
     if (d.kh == 1) {
@@ -408,6 +470,63 @@ int launch_tile_conv(const TileConvLaunch &d, hipStream_t s) {
     }
     if (d.cin == 128) return d.N == 256 ? tc_dispatch_epi<5, 1, 128, 256>(a, d.epi, s) : tc_dispatch_epi<5, 1, 128, 128>(a, d.epi, s);
     return d.N == 256 ? tc_dispatch_epi<5, 1, 256, 256>(a, d.epi, s) : tc_dispatch_epi<5, 1, 256, 128>(a, d.epi, s);
+}
+
+// ---- the flow head's second layer, in two pieces (see TC_RELU_PROJ) -----------------------------------------------------
+// its filter in the GEMM's packed form [>= 2 rows][9 taps][256] fp32 -> MFMA A fragments of the [18 (+ 14 zero rows) x 256]
+// matrix W2'[j = 2 tap + o][k]: [k group 0..15][hi | lo][lane] x 16 bytes
+__global__ void pack_flow_head_kernel(const float *__restrict__ w2pk, uint4 *__restrict__ out) {
+    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (idx >= 16 * 2 * 64) return;
+    const int lane = idx & 63, part = (idx >> 6) & 1, g = idx >> 7;
+    const int j = lane & 31;
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = 16 * g + 8 * (lane >> 5) + 2 * e;
+        const float v0 = j < 18 ? w2pk[((long long)(j & 1) * 9 + (j >> 1)) * 256 + k] : 0.f;
+        const float v1 = j < 18 ? w2pk[((long long)(j & 1) * 9 + (j >> 1)) * 256 + k + 1] : 0.f;
+        const unsigned a = split_halves(v0), b = split_halves(v1);
+        w[e] = part ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+    }
+    out[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+int launch_pack_flow_head(const float *w2pk, void *out, hipStream_t s) {
+    if (!w2pk || !out) return fail(MFTX_E_ARG, "pack_flow_head_weights: null pointer");
+    if (!aligned16(out)) return fail(MFTX_E_ALIGN, "pack_flow_head_weights: output not 16-byte aligned");
+    hipLaunchKernelGGL(pack_flow_head_kernel, dim3(8), dim3(256), 0, s, w2pk, reinterpret_cast<uint4 *>(out));
+    return check_launch("pack_flow_head");
+}
+
+// delta[c][o] = b2[o] + sum over the 9 taps of T[c + (dy - 1, dx - 1)][2 (3 dy + dx) + o], neighbours outside the image
+// contributing nothing (conv2's zero padding); coords[c] += delta[c] (core/raft.py:184)
+__global__ __launch_bounds__(256) void flow_head_sum_kernel(const float *__restrict__ T, const float *__restrict__ b2, float *__restrict__ delta,
+                                                            float *__restrict__ coords, int P, int h, int w) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over cells x 2
+    if (i >= (long long)P * h * w * 2) return;
+    const int o = (int)(i & 1);
+    const long long cell = i >> 1;
+    const int rem = (int)(cell % ((long long)h * w)), y = rem / w, x = rem - y * w;
+    float sum = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int yy = y + dy - 1, xx = x + dx - 1;
+            if (yy >= 0 && yy < h && xx >= 0 && xx < w) sum += T[(cell + (long long)(dy - 1) * w + (dx - 1)) * 18 + 2 * (3 * dy + dx) + o];
+        }
+    const float dl = sum + b2[o];
+    delta[i] = dl;
+    if (coords) coords[i] += dl;
+}
+
+int launch_flow_head_sum(const float *T, const float *b2, float *delta, float *coords, int P, int h, int w, hipStream_t s) {
+    if (!T || !b2 || !delta) return fail(MFTX_E_ARG, "flow_head_sum: null pointer");
+    const long long n = (long long)P * h * w * 2;
+    ProfScope prof(PC_CONV_SMALL, s, 2.0 * P * h * w * 2 * 9);
+    hipLaunchKernelGGL(flow_head_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T, b2, delta, coords, P, h, w);
+    return check_launch("flow_head_sum");
 }
 
 }  // namespace mftx

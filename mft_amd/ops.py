@@ -399,6 +399,33 @@ def tile_conv2d(x: torch.Tensor, wtile: torch.Tensor, bias, P, h, w, N, kh, kw, 
     return out
 
 
+def pack_flow_head_weights(w2pk: torch.Tensor, check_range: bool = True) -> torch.Tensor:
+    """flow_head.conv2's weight in the ``pack_conv_weight`` form [>= 2, 9, 256] -> the projection matrix of the fused
+    flow head (``mftx_pack_flow_head_weights``; opaque bytes)."""
+    lib = _lib.load()
+    if w2pk.dim() != 3 or w2pk.shape[0] < 2 or tuple(w2pk.shape[1:]) != (9, 256):
+        raise MftxError("pack_flow_head_weights: expected the packed weight [>= 2, 9, 256]")
+    if check_range and count_not_below(w2pk, _lib.SPLIT_LIMIT):
+        raise SplitRangeError(f"pack_flow_head_weights: weights not below {_lib.SPLIT_LIMIT} in magnitude")
+    out = torch.empty(_lib.FLOW_HEAD_WEIGHT_BYTES, dtype=torch.uint8, device=w2pk.device)
+    check(lib.mftx_pack_flow_head_weights(_chk(w2pk, "w2pk"), out.data_ptr(), _stream()), "mftx_pack_flow_head_weights")
+    return out
+
+
+def flow_head(hsplit: torch.Tensor, h: int, w: int, wtile: torch.Tensor, b1, wproj: torch.Tensor, b2, coords=None):
+    """delta = conv2(relu(conv1(h))) of the flow head without materialising the 256 hidden channels (``mftx_flow_head``):
+    hsplit [P*h*w, >= 128] split-form rows -> delta [P*h*w, 2]; coords (optional, [P*h*w, 2]) += delta in place."""
+    lib = _lib.load()
+    M = hsplit.shape[0]
+    P = M // (h * w)
+    T = torch.empty(M, 18, dtype=torch.float32, device=hsplit.device)
+    delta = torch.empty(M, 2, dtype=torch.float32, device=hsplit.device)
+    check(lib.mftx_flow_head(_chk(hsplit, "hsplit"), hsplit.stride(0), P, h, w, _chk(wtile, "wtile", torch.uint8), _chk(b1, "b1"),
+                             _chk(wproj, "wproj", torch.uint8), _chk(b2, "b2"), T.data_ptr(), delta.data_ptr(),
+                             _chk(coords, "coords") if coords is not None else None, _stream()), "mftx_flow_head")
+    return delta
+
+
 def pack_flow_branch_weights(w98: torch.Tensor, w2pk: torch.Tensor, check_range: bool = True) -> torch.Tensor:
     """convf1's weight as [98 = (ky, kx, c), 128] and convf2's in the ``pack_conv_weight`` form [>= 64, 9, 128] -> the
     fragment streams of the fused flow-branch kernel (``mftx_pack_flow_branch_weights``; opaque bytes).  The weights are
@@ -649,14 +676,14 @@ class RaftEngine:
     # WeightSlot indices (csrc/raft_engine.hip) of the weights that feed GEMM layers
     GEMM_SLOTS = (0, 2, 6, 8, 10, 11, 13, 14, 16, 17, 19, 20, 22, 26, 28, 30)
 
-    OPTIONS = {"fork": 0, "presplit": 1, "group": 2, "fuse_lookup": 3, "graph": 4, "fuse_flow": 5, "tile_conv": 6}      # MFTX_RAFT_OPT_*
+    OPTIONS = {"fork": 0, "presplit": 1, "group": 2, "fuse_lookup": 3, "graph": 4, "fuse_flow": 5, "tile_conv": 6, "fuse_head": 7}      # MFTX_RAFT_OPT_*
     # WeightSlot -> (N, cin) of the layers with a tile-resident kernel (csrc/tile_conv.hip): GRU gates (per-iteration and
     # context parts, both passes), flow head and mask head first layers
     TILE_SLOTS = {10: (256, 256), 11: (256, 128), 13: (128, 256), 14: (128, 128), 16: (256, 256), 17: (256, 128),
                   19: (128, 256), 20: (128, 128), 22: (256, 128), 26: (256, 128)}
 
     def __init__(self, state_dict: dict, device, ondemand_corr=False, arith=ARITH_SPLIT, options=None):
-        """options: {"fork" | "presplit" | "group" | "fuse_lookup" | "graph" | "fuse_flow" | "tile_conv": int} scheduling options of this handle
+        """options: {"fork" | "presplit" | "group" | "fuse_lookup" | "graph" | "fuse_flow" | "tile_conv" | "fuse_head": int} scheduling options of this handle
         (``mftx_raft_set_option``; defaults are the measured best)."""
         lib = _lib.load()
         self.device = torch.device(device)
@@ -682,6 +709,9 @@ class RaftEngine:
                           for i, t in enumerate(self.weights)]
             tarr, self._keep_tile = _lib.ptr_array([t.data_ptr() if t is not None else None for t in self.wtile])
             check(lib.mftx_raft_set_tile_weights(self._h, tarr, len(self.wtile)), "mftx_raft_set_tile_weights")
+            # ... and the flow head's last layer as the projection epilogue of its first (the 256 hidden channels stay in LDS)
+            self.wproj = pack_flow_head_weights(self.weights[24])
+            check(lib.mftx_raft_set_flow_head(self._h, self.wproj.data_ptr()), "mftx_raft_set_flow_head")
         elif self.arith != ARITH_F32:
             raise MftxError(f"unknown arithmetic {arith!r}")
         for k, v in (options or {}).items():

@@ -963,7 +963,7 @@ def test_engine_register_split_bitwise():
     other epilogue variants, GRU state in fp32 only) agrees with the default engine (activations stored in split form by
     their producers) to the last digits; with the flow branch in order on one stream (fork = 0) and with the grouped
     launches kept apart (group = 0) bit for bit.  Options are per handle (mftx_raft_set_option), not process state."""
-    base = {"fuse_lookup": 0, "fuse_flow": 0, "tile_conv": 0}
+    base = {"fuse_lookup": 0, "fuse_flow": 0, "tile_conv": 0, "fuse_head": 0}
     outs = {tag: _engine_outputs(dict(base, **extra)) for tag, extra in
             (("default", {}), ("nopresplit", {"presplit": 0}), ("nofork", {"fork": 0}), ("nogroup", {"group": 0, "fork": 0}))}
     assert np.isfinite(outs["default"]).all()
@@ -1126,6 +1126,39 @@ def test_engine_tile_conv_matches_ring_gemm():
     epe = np.sqrt((d ** 2).sum(1)).mean()
     assert epe < 1e-4, epe
     assert np.abs(tiled[n:] - ring[n:]).max() < 1e-3
+
+
+@pytest.mark.parametrize("P,h,w", [(1, 8, 16), (2, 21, 37), (1, 64, 64), (1, 3, 5)])
+def test_flow_head_fused_vs_fp64(ops_mod, P, h, w):
+    """Both layers of the flow head as the tile-resident kernel with the projection epilogue + the stencil sum
+    (mftx_flow_head) against the two convolutions in fp64 (core/update.py:6-14), and coords += delta."""
+    g = torch.Generator().manual_seed(9)
+    M = P * h * w
+    x = torch.randn(M, 128, generator=g)
+    w1, b1 = torch.randn(256, 128, 3, 3, generator=g) * 0.05, torch.randn(256, generator=g) * 0.1
+    w2, b2 = torch.randn(2, 256, 3, 3, generator=g) * 0.05, torch.randn(2, generator=g) * 0.1
+    coords = torch.randn(M, 2, generator=g)
+    wtile = ops_mod.pack_tile_conv_weights(ops_mod.pack_conv_weight(w1.cuda()), 256, 128)
+    wproj = ops_mod.pack_flow_head_weights(ops_mod.pack_conv_weight(w2.cuda()))
+    cd = coords.cuda()
+    delta = ops_mod.flow_head(ops_mod.split_activations(x.cuda()), h, w, wtile, b1.cuda(), wproj, b2.cuda(), coords=cd)
+    xi = x.double().reshape(P, h, w, 128).permute(0, 3, 1, 2)
+    f1 = torch.relu(torch.nn.functional.conv2d(xi, w1.double(), b1.double(), padding=1))
+    ref = torch.nn.functional.conv2d(f1, w2.double(), b2.double(), padding=1).permute(0, 2, 3, 1).reshape(M, 2)
+    scale = float(ref.abs().max())
+    assert float((delta.cpu().double() - ref).abs().max()) < 3e-6 * max(scale, 1.0)
+    assert torch.equal(cd.cpu(), coords + delta.cpu())
+
+
+def test_engine_fused_flow_head_matches_two_kernels():
+    """The engine with the flow head as one tile-resident kernel + stencil sum (the default) against the engine with its
+    second layer as the small-N kernel on a materialised first layer: other summation order, fp32 rounding."""
+    fused, apart = _engine_outputs({}), _engine_outputs({"fuse_head": 0})
+    assert np.isfinite(fused).all()
+    n = 3 * 2 * 192 * 320
+    d = (fused[:n] - apart[:n]).reshape(3, 2, -1)
+    assert np.sqrt((d ** 2).sum(1)).mean() < 1e-4
+    assert np.abs(fused[n:] - apart[n:]).max() < 1e-3
 
 
 def _tile_layers(arith, tile, ref=False):
