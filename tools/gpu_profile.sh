@@ -13,9 +13,13 @@ BENCH="python bench.py --steps 20 --warmup 5"
 QUIET="--no-cpu-baseline --no-profile --no-parity --no-host-io --sync-encode --no-alt-arith --no-graphs"
 
 $BENCH > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
-# A/B of the round's two structural changes, same box, same run
+# A/B of the round's structural changes, same box, same run (results do not depend on any of them beyond fp32 rounding)
 $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-graphs > $OUT/bench_no_graphs.json 2>/dev/null; echo "bench no-graphs rc=$?"
 $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-fused-lookup > $OUT/bench_no_fused_lookup.json 2>/dev/null; echo "bench no-fused-lookup rc=$?"
+(for o in "" "fuse_head=0" "tile_conv=0" "fuse_flow=0" "fuse_lookup=0" "fuse_head=0 tile_conv=0 fuse_flow=0" "fuse_head=0 tile_conv=0 fuse_flow=0 fuse_lookup=0 graph=0"; do
+   args=""; for kv in $o; do args="$args --engine-opt $kv"; done
+   for rep in 1 2; do $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-host-io $args 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('engine options [$o]:', round(d['value'],1), 'frames/s, host', round(d['host_enqueue_ms_per_step'],2), 'ms per frame, conv GEMM', round(d['roofline']['frac'],3), 'of the fp16 MFMA peak')"; done
+ done) > $OUT/engine_options_ab.txt
 python bench.py --steps 20 --warmup 5 --height 256 --width 256 --no-cpu-baseline --no-parity --no-alt-arith > $OUT/bench_256.json 2>/dev/null
 python bench.py --steps 5 --warmup 2 --height 1080 --width 1920 --no-cpu-baseline --no-parity --no-alt-arith --no-host-io > $OUT/bench_1080p.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --force-sharded --no-cpu-baseline --no-parity --no-alt-arith > $OUT/bench_forced_sharded_x1.json 2>/dev/null
@@ -24,10 +28,20 @@ IO_ALL=1 timeout 300 python tools/io_paths3.py 2>&1 | grep -v amdgpu.ids > $OUT/
 timeout 100 python tools/io_kernel_copy.py 2>&1 | grep -v amdgpu.ids >> $OUT/io_paths.txt
 timeout 300 python tools/lf_stress.py 2>&1 | grep -v amdgpu.ids > $OUT/lf_stress.txt
 (for s in "7 64 64" "1 64 64" "7 136 240"; do timeout 200 python tools/bench_lookup_fused.py $s 2>&1 | tail -1; done) > $OUT/lookup_fused_micro.txt
+(for s in "7 64 64" "1 64 64" "7 135 240"; do timeout 200 python tools/bench_flow_branch.py $s 2>&1 | tail -1; done) > $OUT/flow_branch_micro.txt
+timeout 300 python tools/bench_tile_conv.py 2>&1 | grep -v amdgpu.ids > $OUT/tile_conv_micro.txt
+(timeout 200 python tools/bench_volume.py; timeout 200 python tools/bench_volume.py 2 135 240) 2>&1 | grep -v amdgpu.ids > $OUT/volume_micro.txt
 if [ -f build_tune/libmftx_tune.so ]; then
   (echo "# tools/lf_trace.py on a -DMFTX_TUNING -DMFTX_LF_TRACE build (tools/build_tuning.sh): s_memtime stamps of workgroup 0, P = 7, 64 x 64"
    MFTX_LIB=$PWD/build_tune/libmftx_tune.so timeout 200 python tools/lf_trace.py 2>&1 | grep -v amdgpu.ids
    for a in 1 2 8 10 32 64 128 512 1024; do echo "== MFTX_LF_ABLATE=$a"; MFTX_LIB=$PWD/build_tune/libmftx_tune.so MFTX_LF_ABLATE=$a timeout 200 python tools/lf_trace.py 2>&1 | tail -4; done) > $OUT/lf_trace.txt
+  (echo "# tools/fb_trace.py: s_memtime stamps of workgroup 0 of the fused flow-branch kernel, P = 7, 64 x 64 (kilo-cycles)"
+   MFTX_LIB=$PWD/build_tune/libmftx_tune.so timeout 200 python tools/fb_trace.py 2>&1 | grep -v amdgpu.ids) > $OUT/fb_trace.txt
+  (echo "# tools/tc_trace.py: s_memtime stamps of workgroup 0 of the tile-resident conv kernel (flow head first layer, 3 x 3, 128 -> 256) with P pairs of 64 x 64 cells"
+   echo "# = 32 P workgroups on the 256 CUs: the SAME cycles per workgroup take longer the more CUs are busy -- the clock follows the chip's power"
+   for P in 1 2 4 7; do echo "== P = $P"; MFTX_LIB=$PWD/build_tune/libmftx_tune.so timeout 200 python tools/tc_trace.py 128 256 3 3 $P 2>&1 | grep -v amdgpu.ids | sed -n "1,2p;9p"; done
+   echo "== GRU z | r gates (1 x 5, 256 -> 256), P = 7"; MFTX_LIB=$PWD/build_tune/libmftx_tune.so timeout 200 python tools/tc_trace.py 256 256 1 5 7 2>&1 | grep -v amdgpu.ids | sed -n "1,2p;9p"
+   echo "== GRU q gate (1 x 5, 256 -> 128), P = 7"; MFTX_LIB=$PWD/build_tune/libmftx_tune.so timeout 200 python tools/tc_trace.py 256 128 1 5 7 2>&1 | grep -v amdgpu.ids | sed -n "1,2p;9p") > $OUT/tc_trace.txt
 fi
 $BENCH --arith fp32 --no-cpu-baseline --no-host-io --no-alt-arith > $OUT/bench_fp32_arith.json 2> $OUT/bench_fp32.err; echo "bench fp32 rc=$?"
 for a in 0 1; do echo "== arithmetic $a (0 fp32 MFMA, 1 split fp16): error against an fp64 convolution"; timeout 200 python tools/conv_arith_error.py $a 2>&1 | grep -v amdgpu.ids; done > $OUT/conv_arith_error.txt
