@@ -166,7 +166,7 @@ def profiled_traffic():
         return None, None
     tot = n = 0.0
     for line in files[-1].read_text().splitlines():
-        if line.startswith("#") or "conv_gemm" not in line:
+        if line.startswith("#") or ("conv_gemm" not in line and "tile_conv_kernel" not in line):
             continue
         name, launches, _fetch, fetch_x2, write = line.rsplit(",", 4)     # the kernel name contains commas
         if "volume" in name or re.search(r"<\d+, \d+, \d+, \d+, 4[,>]", name):
@@ -461,7 +461,7 @@ def main():
         if dom:
             traffic, source = profiled_traffic()
             split = args.arith == "split"
-            result["roofline"] = {"kernel": "conv_gemm_kernel (%s implicit GEMM: update block + OU heads)" %
+            result["roofline"] = {"kernel": "conv_gemm_kernel + tile_conv_kernel (%s implicit GEMM, ring-buffered and tile-resident: update block + OU heads)" %
                                             ("split-fp16 MFMA" if split else "fp32 MFMA"),
                                   "bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"],
                                   "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,

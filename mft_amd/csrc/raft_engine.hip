@@ -426,7 +426,11 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     // over the iterations (core/raft.py:146-149): its third of every gate sum (+ bias) is computed
     // once here and enters the per-iteration GEMMs as an epilogue addend.  Same terms, summed once.
     // Layers whose input tile fits a CU's LDS run on the tile-resident kernel (csrc/tile_conv.hip) when its weight streams are set
-    const bool tiles_on = SP && r->opt[MFTX_RAFT_OPT_TILE_CONV] != 0;
+    // (option value 2: whatever the batch; 1, the default: only when the tiles fill the chip -- at 256 x 256 pixels or one pair
+    // per GPU the ring-buffered kernel's small tiles win)
+    const bool tiles_on = SP && r->opt[MFTX_RAFT_OPT_TILE_CONV] != 0 &&
+                          (r->opt[MFTX_RAFT_OPT_TILE_CONV] == 2 ||
+                           (tile_conv_fills_chip(P, h, w, 3, 3) && tile_conv_fills_chip(P, h, w, 1, 5) && tile_conv_fills_chip(P, h, w, 5, 1)));
     auto tile_w = [&](int slot) -> const void * { return tiles_on ? r->wt[slot] : nullptr; };
     auto tile_layer = [&](const float *a0, int lda0, const float *a1, int lda1, const void *wf, const float *bias, int N, int kh, int kw, int epi) {
         TileConvLaunch t{};

@@ -300,6 +300,28 @@ def test_fp32_mfma_arith_vs_golden_and_default(golden_dir, weights_np, flower, t
         RAFTWrapper(c, state_dict=weights_np)
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_tile_resident_layers_vs_golden(golden_dir, weights_np, tag):
+    """The GRU gates and the flow / mask heads on the tile-resident kernel, the flow head with its projection epilogue,
+    FORCED (engine option tile_conv = 2: by default they are used only when their 128-cell tiles fill the chip, which
+    the goldens' small images do not) against the reference-generated goldens at the default path's tolerances."""
+    from mft_amd.config import AttrDict, Config
+    from mft_amd.raft import RAFTWrapper
+    g = np.load(golden_dir / "compute_flow.npz")
+    H, W, iters, fa, fb = (int(v) for v in g[f"{tag}_meta"])
+    c = Config()
+    c.flow_iters = iters
+    c.raft_params = AttrDict(engine_options={"tile_conv": 2})
+    fl = RAFTWrapper(c, state_dict=weights_np)
+    vid = SyntheticVideo(H, W, n_frames=8, seed=5)
+    flow, extra = fl.compute_flow(vid[fa], vid[fb], mode="flow")
+    e = epe(flow.cpu(), T(g[f"{tag}_flow"]))
+    assert e.mean() < 1e-3 and e.max() < 1e-2, float(e.mean())
+    assert (extra["occlusion"].cpu() - T(g[f"{tag}_occl"])).abs().max() < 2e-3
+    rel = (extra["sigma"].cpu() - T(g[f"{tag}_sigma"])).abs() / T(g[f"{tag}_sigma"])
+    assert rel.max() < 2e-3
+
+
 def test_result_api(flower):
     from mft_amd.results import FlowOUTrackingResult, FlowOUResult
     assert FlowOUResult is FlowOUTrackingResult

@@ -1119,7 +1119,7 @@ def test_tile_conv_batch_invariance_and_argument_errors(ops_mod):
 def test_engine_tile_conv_matches_ring_gemm():
     """The engine with the GRU gates, their context parts and the flow / mask heads' first layers on the tile-resident
     kernel (the default) against the same engine with every layer on the ring-buffered GEMM: fp32 rounding of the K sums."""
-    tiled, ring = _engine_outputs({}), _engine_outputs({"tile_conv": 0})
+    tiled, ring = _engine_outputs({"tile_conv": 2}), _engine_outputs({"tile_conv": 0})      # (2: whatever the batch -- this one is small)
     assert np.isfinite(tiled).all()
     n = 3 * 2 * 192 * 320
     d = (tiled[:n] - ring[:n]).reshape(3, 2, -1)
@@ -1153,7 +1153,7 @@ def test_flow_head_fused_vs_fp64(ops_mod, P, h, w):
 def test_engine_fused_flow_head_matches_two_kernels():
     """The engine with the flow head as one tile-resident kernel + stencil sum (the default) against the engine with its
     second layer as the small-N kernel on a materialised first layer: other summation order, fp32 rounding."""
-    fused, apart = _engine_outputs({}), _engine_outputs({"fuse_head": 0})
+    fused, apart = _engine_outputs({"tile_conv": 2}), _engine_outputs({"tile_conv": 2, "fuse_head": 0})
     assert np.isfinite(fused).all()
     n = 3 * 2 * 192 * 320
     d = (fused[:n] - apart[:n]).reshape(3, 2, -1)
