@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MFTX_VERSION 303
+#define MFTX_VERSION 304
 
 #define MFTX_E_ARG (-1)      /* null pointer / non-positive size / unsupported shape */
 #define MFTX_E_ALIGN (-2)    /* pointer or leading dimension not 16-byte aligned */
@@ -264,7 +264,9 @@ int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
  *   MFTX_RAFT_OPT_TILE_CONV  1 default (layers with tile-resident weights set run on that kernel when its tiles of 128 cells come in
  *                            rounds of the chip that are at least 3/4 full -- e.g. 6 or 7 pairs of 512 x 512, 1080p), 2 always,
  *                            0 all on mftx_conv2d's
- *   MFTX_RAFT_OPT_FUSE_HEAD  1 default (both layers of the flow head as mftx_flow_head when its weights are set), 0 two layers */
+ *   MFTX_RAFT_OPT_FUSE_HEAD  1 default (both layers of the flow head as mftx_flow_head when its weights are set), 0 two layers
+ *   MFTX_RAFT_OPT_TILE_VOLUME 1 default (split arithmetic: the correlation volume by the tile-resident kernel, csrc/volume_tile.hip),
+ *                            0 the ring-buffered GEMM */
 #define MFTX_RAFT_OPT_FORK 0
 #define MFTX_RAFT_OPT_PRESPLIT 1
 #define MFTX_RAFT_OPT_GROUP 2
@@ -273,6 +275,7 @@ int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
 #define MFTX_RAFT_OPT_FUSE_FLOW 5
 #define MFTX_RAFT_OPT_TILE_CONV 6
 #define MFTX_RAFT_OPT_FUSE_HEAD 7
+#define MFTX_RAFT_OPT_TILE_VOLUME 8
 int mftx_raft_set_option(mftx_raft *r, int option, int value);
 /* graphs captured / graph launches so far (tests, bench) */
 int mftx_raft_graph_stats(const mftx_raft *r, unsigned long long *captures, unsigned long long *replays);

@@ -137,7 +137,10 @@ bool conv_small_applicable(const mftx_conv_desc &d);
 int launch_conv_small(const mftx_conv_desc &d, hipStream_t s, float *accum = nullptr, int ld_accum = 0);
 // all-pairs correlation volume + its 3 pooled levels in one launch (pyramid layout above)
 int launch_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, int w, float *const lvl[4], hipStream_t s,
-                        float *f2_split = nullptr);
+                        float *f2_split = nullptr, int tile_resident = 1);
+// the split-arithmetic volume with the target super-block resident in LDS (csrc/volume_tile.hip); f2s: split form of f2
+bool volume_tile_applicable(int C);
+int launch_volume_tile(const float *f1, const float *f2s, int P, int h, int w, float *const lvl[4], hipStream_t s);
 int launch_corr_lookup(const float *const lvl[4], const float *coords, int P, int h, int w,
                        float *out, int ld_out, hipStream_t s);
 // lookup fused into convc1 (csrc/lookup_convc1.hip): out = relu(convc1(lookup(coords)) + bias), [M][ld_out], fp32 or split form

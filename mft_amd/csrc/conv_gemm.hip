@@ -1736,7 +1736,7 @@ int launch_split_weights(const float *wpk, void *out, long long n, hipStream_t s
 // lvl[0][p][i][.] = <f1[p][i][:], f2[p][j][:]> / sqrt(C) over all target cells j (blocked layout), and the
 // three pooled levels, in one launch (core/corr.py:14-28, 53-69)
 // f2_split (optional): scratch of P * h * w * C floats -> the volume GEMM runs in split arithmetic (f2 is split into it first)
-int launch_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, int w, float *const lvl[4], hipStream_t s, float *f2_split) {
+int launch_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, int w, float *const lvl[4], hipStream_t s, float *f2_split, int tile_resident) {
     const int N = h * w;
     if ((long long)N * C * 4 > 0x7fffffffLL) return fail(MFTX_E_ARG, "corr_pyramid: feature map exceeds 2 GiB");
     const PyramidLayout L = pyramid_layout(h, w);
@@ -1755,6 +1755,8 @@ int launch_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, i
     // one wave = 32 queries x one super-block (128 columns): 128 x 128 tiles of four waves stacked along M
     if (f2_split != nullptr) {
         if (int e = launch_split_weights(f2, f2_split, (long long)P * N * C, s)) return e;
+        static const int ring_only = tune_env("MFTX_VOL_RING", 0);      // (tuning builds: the ring-buffered kernel, for A/B)
+        if (tile_resident && !ring_only && volume_tile_applicable(C)) return launch_volume_tile(f1, f2_split, P, h, w, lvl, s);
         a.w = f2_split;
         a.arith = AR_SPLIT;
         return launch_cfg<128, 128, 4, 1, EPI_VOLUME, 32, AR_SPLIT, 2>(a, P, s, PC_CORR_VOLUME, 2.0 * N * N * (double)C * P);

@@ -185,7 +185,7 @@ struct mftx_raft {
     const void *wflow;             // convf1's and convf2's weights for the fused flow-branch kernel (csrc/flow_branch.hip), or null
     const void *wproj;             // the flow head's last layer as the projection epilogue of its first (csrc/tile_conv.hip: TC_RELU_PROJ), or null
     const void *wt[W_COUNT];       // weight streams of the tile-resident conv kernel (csrc/tile_conv.hip) per slot, or null
-    int opt[8];                    // MFTX_RAFT_OPT_*
+    int opt[9];                    // MFTX_RAFT_OPT_*
 };
 // weights that go through the conv GEMM (the others feed VALU kernels and stay fp32)
 static constexpr int GEMM_SLOTS[] = {W_CONVC1, W_CONVC2, W_CONVF2, W_CONV, W_ZR1_DYN, W_ZR1_INP, W_Q1_DYN, W_Q1_INP,
@@ -211,7 +211,7 @@ extern "C" int mftx_raft_create(const float *const *weights, int n_weights, mftx
     for (int i = 0; i < W_COUNT; ++i) r->wt[i] = nullptr;
     r->coords_trace = nullptr;
     r->graphs = new (std::nothrow) GraphCache;
-    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1; r->opt[MFTX_RAFT_OPT_FUSE_FLOW] = 1; r->opt[MFTX_RAFT_OPT_TILE_CONV] = 1; r->opt[MFTX_RAFT_OPT_FUSE_HEAD] = 1;
+    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1; r->opt[MFTX_RAFT_OPT_FUSE_FLOW] = 1; r->opt[MFTX_RAFT_OPT_TILE_CONV] = 1; r->opt[MFTX_RAFT_OPT_FUSE_HEAD] = 1; r->opt[MFTX_RAFT_OPT_TILE_VOLUME] = 1;
     for (int i = 0; i < W_COUNT; ++i) r->w[i] = r->wg[i] = weights[i];
     *out = r;
     return 0;
@@ -311,7 +311,7 @@ extern "C" int mftx_raft_set_coords_trace(mftx_raft *r, float *trace) {
 
 extern "C" int mftx_raft_set_option(mftx_raft *r, int option, int value) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_option: bad handle");
-    if (option < 0 || option > MFTX_RAFT_OPT_FUSE_HEAD) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
+    if (option < 0 || option > MFTX_RAFT_OPT_TILE_VOLUME) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
     r->opt[option] = value;
     if (r->graphs) r->graphs->clear();
     return 0;
@@ -409,7 +409,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     // correlation volume + pyramid (core/corr.py:14-28)
     const float *f2lv[4] = {fmap2, ws.f2l[0], ws.f2l[1], ws.f2l[2]};
     if (ondemand) TRY(launch_fmap_pyramid(fmap2, P, 256, h, w, ws.f2l, s));   // core/corr.py:78-82 (only fmap2's pyramid is used)
-    else TRY(launch_corr_pyramid(fmap1, fmap2, P, 256, h, w, ws.lvl, s, r->arith == MFTX_ARITH_SPLIT ? ws.f2s : nullptr));
+    else TRY(launch_corr_pyramid(fmap1, fmap2, P, 256, h, w, ws.lvl, s, r->arith == MFTX_ARITH_SPLIT ? ws.f2s : nullptr, r->opt[MFTX_RAFT_OPT_TILE_VOLUME]));
     {
         const long long slots = (long long)M * 64;
         ProfScope prof(PC_GLUE, s, 0);

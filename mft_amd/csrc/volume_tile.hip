@@ -1,0 +1,284 @@
+// All-pairs correlation volume + its three pooled levels (core/corr.py:14-28, 53-69), tile-resident form, split arithmetic.
+//
+// The ring-buffered GEMM (conv_gemm.hip, EPI_VOLUME) spends its time in a K loop of eight chunks -- K is only 256 -- every
+// one of them exposed to the staging latency, 96 MFMAs per wave between two epilogues.  Here the 128
+// target cells of a super-block (16 x 8 cells of the second feature map: four 8 x 4 blocks of the blocked level 0) stay in
+// LDS for the whole workgroup (133 KB, split form, copied from the split f2 once), and every wave walks over query
+// blocks of 32 cells: per 16-wide k group 8 ds_read_b128 (the four target tiles' fragments, the same addresses for every
+// query block), 2 global loads of the queries' raw fp32 features (L2 -> registers, three groups ahead; split in registers
+// in the shadow of the MFMAs), 12 MFMAs -- no barrier after the first, no LDS ring, no DMA.
+//
+// The MFMAs take the TARGETS as their first operand (D = f2_tile x f1^T, targets x queries): a lane then holds, for ONE
+// query, the 4 x 4 patch (rows b, columns 4 (lane >> 5) + e) of each of the four blocks -- and the pooled levels form IN
+// REGISTERS: level 1 = 2 x 2 of the patch, level 2 = 2 x 2 of those, level 3 with one exchange between the two lane halves,
+// each in ATen's order ((a + b) + c + d) * 0.25 like avg_pool2d level by level (bit-identical to pooling the stored level
+// 0).  No LDS staging, no barrier in the epilogue either: the eight waves drift apart and one stores while another
+// multiplies.
+#include "common.h"
+#include "profile.h"
+
+namespace mftx {
+
+typedef float vt_f32x16 __attribute__((ext_vector_type(16)));
+typedef float vt_f32x4 __attribute__((ext_vector_type(4)));
+typedef float vt_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned vt_u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 vt_f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int VT_C = 256;                       // feature channels
+constexpr int VT_ROW = VT_C * 4 + 16;           // bytes per resident target row (consecutive targets 65 sixteen-byte slots apart)
+constexpr int VT_LDS = 128 * VT_ROW;            // 133 120
+
+struct VolTileArgs {
+    const float *f1;            // [P][N][256] fp32
+    const float *f2s;           // [P][N][256] split form
+    float *lvl0, *lvl1, *lvl2, *lvl3;
+    long long s0, s1, s2, s3;   // floats per query cell, per level (pyramid layout of common.h)
+    int P, N, h, w, sbw, n_sb, wb0;
+    float scale;
+    int qchunks, blocks_per_chunk;      // query blocks (of 32) per workgroup
+    int ablate;                         // tuning builds only (MFTX_VT_ABLATE): 1 no level-0 stores, 2 no pooled stores, 4 no MFMAs
+};
+
+__device__ __forceinline__ vt_f32x16 vt_mfma(const vt_f16x8 &a, const vt_f16x8 &b, const vt_f32x16 &c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// hi / lo halves of 8 consecutive k (conv_gemm.hip: split8); ends with the two wait states an MFMA needs behind a VALU write
+__device__ __forceinline__ void vt_split8(const vt_f32x4 &u, const vt_f32x4 &v, float k2048, vt_f16x8 &hi, vt_f16x8 &lo) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    float r0, r1, r2, r3, r4, r5, r6, r7;
+    asm("v_cvt_pk_f16_f32 %0, %16, %17\n\t"
+        "v_cvt_pk_f16_f32 %1, %18, %19\n\t"
+        "v_cvt_pk_f16_f32 %2, %20, %21\n\t"
+        "v_cvt_pk_f16_f32 %3, %22, %23\n\t"
+        "v_fma_mix_f32 %8, %0, -1.0, %16 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %9, %0, -1.0, %17 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %10, %1, -1.0, %18 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %11, %1, -1.0, %19 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %12, %2, -1.0, %20 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %13, %2, -1.0, %21 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %14, %3, -1.0, %22 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %15, %3, -1.0, %23 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %4, %8, %24, 0\n\t"
+        "v_fma_mixlo_f16 %5, %10, %24, 0\n\t"
+        "v_fma_mixlo_f16 %6, %12, %24, 0\n\t"
+        "v_fma_mixlo_f16 %7, %14, %24, 0\n\t"
+        "v_fma_mixhi_f16 %4, %9, %24, 0\n\t"
+        "v_fma_mixhi_f16 %5, %11, %24, 0\n\t"
+        "v_fma_mixhi_f16 %6, %13, %24, 0\n\t"
+        "v_fma_mixhi_f16 %7, %15, %24, 0\n\t"
+        "s_nop 1"
+        : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3),
+          "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(k2048));
+    hi = __builtin_bit_cast(vt_f16x8, vt_u32x4{h0, h1, h2, h3});
+    lo = __builtin_bit_cast(vt_f16x8, vt_u32x4{l0, l1, l2, l3});
+}
+
+// lane i <- lane i + N (row_shl) / lane i - N (row_shr) inside its row of 16 lanes; lanes without a source read 0
+template <int N>
+__device__ __forceinline__ float vt_shl(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
+}
+template <int N>
+__device__ __forceinline__ float vt_shr(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true));
+}
+
+// ATen's avg_pool2d order: ((a + b) + c + d) * 0.25, a b = top row, c d = bottom row
+__device__ __forceinline__ float vt_pool4(float a, float b, float c, float d) { return (((a + b) + c) + d) * 0.25f; }
+
+__global__ __launch_bounds__(512, 2) void volume_tile_kernel(VolTileArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vt_lds[];
+    unsigned char *lds = vt_lds;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = (int)blockIdx.x;
+    const int qc = wg % p.qchunks, sb = (wg / p.qchunks) % p.n_sb, bz = wg / (p.qchunks * p.n_sb);
+    const int sby = sb / p.sbw, sbx = sb - sby * p.sbw;
+    const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));
+
+    // ---- the super-block's 128 target rows -> LDS: row m = 32 j + 8 y + x is cell (y, x) of block j = (block row, block column) of the 2 x 2
+    {
+        const float *f2p = p.f2s + (long long)bz * p.N * VT_C;
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const int q = k * 512 + tid, m = q >> 6, pc = q & 63;
+            const int j = m >> 5, mm = m & 31;
+            const int ty = 8 * sby + 4 * (j >> 1) + (mm >> 3), tx = 16 * sbx + 8 * (j & 1) + (mm & 7);
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);                       // targets outside the map: zero rows (their columns of the padded blocks read 0)
+            if (ty < p.h && tx < p.w) v = *reinterpret_cast<const uint4 *>(f2p + ((long long)ty * p.w + tx) * VT_C + pc * 4);
+            *reinterpret_cast<uint4 *>(lds + m * VT_ROW + pc * 16) = v;
+        }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    const unsigned char *abase = lds + (lane & 31) * VT_ROW + (lane >> 5) * 32;      // + 32 j rows, + 64 g
+    const int n_blocks = (p.N + 31) >> 5;
+    const int b_lo = qc * p.blocks_per_chunk, b_hi = (b_lo + p.blocks_per_chunk < n_blocks) ? b_lo + p.blocks_per_chunk : n_blocks;
+    const long long qbase = (long long)bz * p.N;
+    const float inv2048 = 1.f / 2048.f;
+    const int hf = lane >> 5;
+    const int h2 = p.h >> 2, w2 = p.w >> 2, h3 = p.h >> 3, w3 = p.w >> 3;
+
+    // ds_bpermute byte addresses (pull): level-1 position p = 8 y1 + x1 of this half-wave <- merged lane 2 (x1 & 3) + 16 (y1 & 1) +
+    // ((x1 >> 2) & 1) + 8 (y1 >> 1); level 3: the level-2 cell one row of cells down (+ 16 lanes), and its right neighbour (+ 18)
+    const int pp = lane & 31;
+    const int l1_src = 4 * (32 * hf + 2 * (pp & 3) + 16 * ((pp >> 3) & 1) + ((pp >> 2) & 1) + 8 * (pp >> 4));
+    const int l3_src = 4 * ((lane + 16) & 63);
+    for (int qb = b_lo + wv; qb < b_hi; qb += 8) {
+        const int q = qb * 32 + (lane & 31);
+        const float *src = p.f1 + (qbase + (q < p.N ? q : p.N - 1)) * VT_C + 8 * hf;       // (rows past the last query: any row, nothing of them is stored)
+        vt_f32x16 acc[4], accx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; accx[j][r] = 0.f; }
+        constexpr int PF = 3;
+        vt_f32x4 raw[PF][2];
+#pragma unroll
+        for (int g = 0; g < PF; ++g) {
+            raw[g][0] = *reinterpret_cast<const vt_f32x4 *>(src + 16 * g);
+            raw[g][1] = *reinterpret_cast<const vt_f32x4 *>(src + 16 * g + 4);
+        }
+        vt_f16x8 ah[2][4], al[2][4];
+        auto read_a = [&](int g, int set) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ah[set][j] = *reinterpret_cast<const vt_f16x8 *>(abase + j * 32 * VT_ROW + g * 64);
+                al[set][j] = *reinterpret_cast<const vt_f16x8 *>(abase + j * 32 * VT_ROW + g * 64 + 16);
+            }
+        };
+        read_a(0, 0);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int set = g & 1;
+            vt_f16x8 bh, bl;
+            vt_split8(raw[g % PF][0], raw[g % PF][1], k2048, bh, bl);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < 16) read_a(g + 1, set ^ 1);
+            if (g + PF < 16) {
+                raw[g % PF][0] = *reinterpret_cast<const vt_f32x4 *>(src + 16 * (g + PF));
+                raw[g % PF][1] = *reinterpret_cast<const vt_f32x4 *>(src + 16 * (g + PF) + 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // (queries first: D = f1_block x f2_tile^T, queries x targets -- a lane holds ONE target cell of each block for 16 queries)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = vt_mfma(bh, ah[set][j], acc[j]);
+            // (cross terms in the ring-buffered kernel's order -- query hi x target lo, then query lo x target hi: the same sequence
+            // of products and sums per output, the same bits)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) accx[j] = vt_mfma(bh, al[set][j], accx[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) accx[j] = vt_mfma(bl, ah[set][j], accx[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- epilogue, in registers.  acc[j][r]: query row 8 (r >> 2) + 4 hf + (r & 3) of the block, target cell m = lane & 31 =
+        // 8 y + x of block j: per row and block a half-wave holds one whole 128-byte line of level 0.
+        const int m = lane & 31;
+        const int q0 = qb * 32;
+        const long long blk0 = ((long long)(2 * sby) * p.wb0 + 2 * sbx) * 32 + m;          // + (j >> 1) wb0 * 32 + (j & 1) * 32
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qrow = q0 + 8 * (r >> 2) + 4 * hf + (r & 3);
+            const bool row_ok = qrow < p.N;
+#ifdef MFTX_TUNING
+            const bool st0 = row_ok && !(p.ablate & 1), st1 = row_ok && !(p.ablate & 2);
+#else
+            const bool st0 = row_ok, st1 = row_ok;
+#endif
+            const long long qr = qbase + qrow;
+            float *o0 = p.lvl0 + qr * p.s0 + blk0;
+            float merged = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = (acc[j][r] + accx[j][r] * inv2048) * p.scale;
+                if (st0) o0[((long long)(j >> 1) * p.wb0 + (j & 1)) * 32] = v;
+                // level 1: the 2 x 2 cells (y, x), (y, x + 1), (y + 1, x), (y + 1, x + 1) are lanes m, m + 1, m + 8, m + 9 of one 16-lane row
+                // (valid where x and y are even), summed in ATen's order
+                float t = v + vt_shl<1>(v);
+                t = t + vt_shl<8>(v);
+                t = (t + vt_shl<9>(v)) * 0.25f;
+                // the four blocks' 8 valid lanes each -> one register, disjoint lanes: block j moves by (j & 1) + 8 (j >> 1)
+                // (the shifts are pinned in front of the selects: sunk into a lane-conditional block -- the compiler does that -- a
+                // DPP move finds its source lanes switched off and reads zeros)
+                if (j == 0) merged = t;
+                else {
+                    float sh = j == 1 ? vt_shr<1>(t) : (j == 2 ? vt_shr<8>(t) : vt_shr<9>(t));
+                    asm volatile("" : "+v"(sh));
+                    const bool take = j == 1 ? (m & 1) != 0 : (j == 2 ? ((m >> 3) & 1) && !(m & 1) : ((m >> 3) & 1) && (m & 1));
+                    merged = take ? sh : merged;
+                }
+            }
+            // merged lane 2 xx + 16 yy + (j & 1) + 8 (j >> 1) = level-1 cell (y1, x1) = (2 (j >> 1) + yy, 4 (j & 1) + xx): pull into
+            // position p = 8 y1 + x1 -- one 128-byte line of level 1 per half-wave
+            const float l1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(l1_src, __builtin_bit_cast(int, merged)));
+            if (st1) p.lvl1[qr * p.s1 + ((long long)sby * p.sbw + sbx) * 32 + m] = l1;
+            // level 2 from the level-1 line (8 wide, 4 tall: the same lane pattern), valid at even x1, even y1: cell (y1 >> 1, x1 >> 1)
+            float t2 = l1 + vt_shl<1>(l1);
+            t2 = t2 + vt_shl<8>(l1);
+            t2 = (t2 + vt_shl<9>(l1)) * 0.25f;
+            asm volatile("" : "+v"(t2));
+            const int y2 = 2 * sby + (m >> 4), x2 = 4 * sbx + ((m >> 1) & 3);
+            if (st1 && !(m & 1) && !((m >> 3) & 1) && y2 < h2 && x2 < w2) p.lvl2[qr * p.s2 + (long long)y2 * w2 + x2] = t2;
+            // level 3: cells x3l = 0, 1 = level-2 cells at lanes (4 x3l, 4 x3l + 2 | 16 + 4 x3l, 16 + 4 x3l + 2)
+            const float bq = vt_shl<2>(t2);
+            const float cq = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(l3_src, __builtin_bit_cast(int, t2)));
+            const float dq = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(l3_src + 8, __builtin_bit_cast(int, t2)));
+            float v3 = (((t2 + bq) + cq) + dq) * 0.25f;
+            asm volatile("" : "+v"(v3));
+            const int x3 = 2 * sbx + (m >> 2);
+            if (st1 && (m == 0 || m == 4) && sby < h3 && x3 < w3) p.lvl3[qr * p.s3 + (long long)sby * w3 + x3] = v3;
+        }
+    }
+}
+
+static int vt_num_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        return cus;
+    }();
+    return n;
+}
+
+bool volume_tile_applicable(int C) { return C == VT_C; }
+
+// f1: raw fp32 features [P][N][256]; f2s: the split form of f2 (launch_split_weights); lvl: the pyramid layout of common.h
+int launch_volume_tile(const float *f1, const float *f2s, int P, int h, int w, float *const lvl[4], hipStream_t s) {
+    const PyramidLayout L = pyramid_layout(h, w);
+    VolTileArgs a{};
+    a.f1 = f1; a.f2s = f2s; a.lvl0 = lvl[0]; a.lvl1 = lvl[1]; a.lvl2 = lvl[2]; a.lvl3 = lvl[3];
+    a.s0 = L.stride[0]; a.s1 = L.stride[1]; a.s2 = L.stride[2]; a.s3 = L.stride[3];
+    a.P = P; a.N = h * w; a.h = h; a.w = w; a.sbw = L.sbw; a.n_sb = L.sbh * L.sbw; a.wb0 = L.wb[0];
+    a.scale = 1.0f / sqrtf((float)VT_C);
+    // One workgroup per (pair, super-block) walks over ALL query blocks when those workgroups fill at least 3/4 of the CUs (7
+    // pairs of 64 x 64 cells: 224; measured 372 us against 397 with three query chunks each); smaller problems split the queries
+    // into chunks, at least one query block per wave each, to put ~one workgroup on every CU.
+    const int n_blocks = (a.N + 31) / 32;
+    const long long base = (long long)P * a.n_sb;
+    a.ablate = tune_env("MFTX_VT_ABLATE", 0);
+    static const int q_forced = tune_env("MFTX_VT_QCHUNKS", 0);
+    int qchunks = q_forced > 0 ? q_forced : (base * 4 >= 3LL * vt_num_cus() ? 1 : (int)((vt_num_cus() + base - 1) / base));
+    if (qchunks < 1) qchunks = 1;
+    if (qchunks > (n_blocks + 7) / 8) qchunks = (n_blocks + 7) / 8;
+    a.blocks_per_chunk = (n_blocks + qchunks - 1) / qchunks;
+    a.qchunks = (n_blocks + a.blocks_per_chunk - 1) / a.blocks_per_chunk;
+    const long long wgs = base * a.qchunks;
+    if (wgs > 0x7fffffffLL) return fail(MFTX_E_ARG, "corr_pyramid: too many workgroups");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(volume_tile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, VT_LDS) != hipSuccess)
+            return fail(MFTX_E_STATE, "corr_pyramid: cannot reserve %d bytes of LDS", VT_LDS);
+        attr_set = true;
+    }
+    ProfScope prof(PC_CORR_VOLUME, s, 2.0 * a.N * a.N * (double)VT_C * P);
+    hipLaunchKernelGGL(volume_tile_kernel, dim3((unsigned)wgs), dim3(512), VT_LDS, s, a);
+    return check_launch("volume_tile");
+}
+
+}  // namespace mftx

@@ -1161,6 +1161,14 @@ def test_engine_fused_flow_head_matches_two_kernels():
     assert np.abs(fused[n:] - apart[n:]).max() < 1e-3
 
 
+def test_engine_tile_resident_volume_bitwise():
+    """The correlation volume by the tile-resident kernel (csrc/volume_tile.hip, the default) and by the ring-buffered
+    GEMM: the same sequence of products and sums per output -- the engine's results are the same bits."""
+    tiled, ring = _engine_outputs({}), _engine_outputs({"tile_volume": 0})
+    assert np.isfinite(tiled).all()
+    assert np.array_equal(tiled, ring)
+
+
 def _tile_layers(arith, tile, ref=False):
     """A few conv GEMMs with the tile shape forced (mftx_conv2d_tile), outputs concatenated."""
     from mft_amd import ops

@@ -10,6 +10,6 @@ for b in "$@"; do
 done
 wait
 for b in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o abl/libmftx_$b.so api.o abl/conv_gemm_$b.o conv_small.o corr.o corr_ondemand.o lookup_convc1.o flow_branch.o tile_conv.o upsample.o chain.o raft_engine.o encoder.o codec.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o abl/libmftx_$b.so api.o abl/conv_gemm_$b.o conv_small.o corr.o corr_ondemand.o lookup_convc1.o flow_branch.o tile_conv.o volume_tile.o upsample.o chain.o raft_engine.o encoder.o codec.o
 done
 ls -la abl/*.so
