@@ -128,21 +128,27 @@ __global__ __launch_bounds__(512, 2) void volume_tile_kernel(VolTileArgs p) {
     const int pp = lane & 31;
     const int l1_src = 4 * (32 * hf + 2 * (pp & 3) + 16 * ((pp >> 3) & 1) + ((pp >> 2) & 1) + 8 * (pp >> 4));
     const int l3_src = 4 * ((lane + 16) & 63);
-    for (int qb = b_lo + wv; qb < b_hi; qb += 8) {
+    constexpr int PF = 3;
+    vt_f32x4 raw[PF][2];
+    auto row_of = [&](int qb) {
         const int q = qb * 32 + (lane & 31);
-        const float *src = p.f1 + (qbase + (q < p.N ? q : p.N - 1)) * VT_C + 8 * hf;       // (rows past the last query: any row, nothing of them is stored)
-        vt_f32x16 acc[4], accx[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; accx[j][r] = 0.f; }
-        constexpr int PF = 3;
-        vt_f32x4 raw[PF][2];
+        return p.f1 + (qbase + (q < p.N ? q : p.N - 1)) * VT_C + 8 * hf;       // (rows past the last query: any row, nothing of them is stored)
+    };
+    auto prefetch = [&](const float *src) {
 #pragma unroll
         for (int g = 0; g < PF; ++g) {
             raw[g][0] = *reinterpret_cast<const vt_f32x4 *>(src + 16 * g);
             raw[g][1] = *reinterpret_cast<const vt_f32x4 *>(src + 16 * g + 4);
         }
+    };
+    if (b_lo + wv < b_hi) prefetch(row_of(b_lo + wv));
+    for (int qb = b_lo + wv; qb < b_hi; qb += 8) {
+        const float *src = row_of(qb);
+        vt_f32x16 acc[4], accx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; accx[j][r] = 0.f; }
         vt_f16x8 ah[2][4], al[2][4];
         auto read_a = [&](int g, int set) {
 #pragma unroll
@@ -175,6 +181,11 @@ __global__ __launch_bounds__(512, 2) void volume_tile_kernel(VolTileArgs p) {
             for (int j = 0; j < 4; ++j) accx[j] = vt_mfma(bl, ah[set][j], accx[j]);
             __builtin_amdgcn_sched_barrier(0);
         }
+
+        // the next query block's first fragments are requested BEFORE this block's stores: memory operations of a wave complete in
+        // order, loads behind 100 stores would wait for every one of them
+        if (qb + 8 < b_hi) prefetch(row_of(qb + 8));
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- epilogue, in registers.  acc[j][r]: query row 8 (r >> 2) + 4 hf + (r & 3) of the block, target cell m = lane & 31 =
         // 8 y + x of block j: per row and block a half-wave holds one whole 128-byte line of level 0.
