@@ -49,5 +49,5 @@ for name, cin, cout, kh, kw, per_frame in (("fh1 / mask0 3x3 128->256", 128, 256
     gf = 2.0 * M * cout * kh * kw * cin * 1e-9
     tot_t += per_frame * t_t
     tot_r += per_frame * t_r
-    print(f"{name:28s} tile-resident {t_t:6.1f} us ({gf / t_t * 1e-3:5.0f} TF alg.) | ring GEMM {t_r:6.1f} us ({gf / t_r * 1e-3:5.0f} TF alg.)")
+    print(f"{name:28s} tile-resident {t_t:6.1f} us ({gf / t_t * 1e3:5.0f} TF alg.) | ring GEMM {t_r:6.1f} us ({gf / t_r * 1e3:5.0f} TF alg.)")
 print(f"per frame (12 iterations): tile-resident {tot_t * 1e-3:.2f} ms | ring GEMM {tot_r * 1e-3:.2f} ms")
