@@ -274,10 +274,14 @@ def run_frames(tracker, frames, first, count, window):
             HOST_MS.append(1e3 * (time.perf_counter() - t0))
             pairs.append(len(tracker.last_pairs))
         return pairs
-    # equal windows of at most `window` frames (20 frames, window 8: 7 + 7 + 6, not 8 + 8 + 4: every rank keeps a
-    # full batch in every window)
+    # full windows of `window` frames, the remainder last (20 frames, window 8: 8 + 8 + 4): with window = world size every rank
+    # gets exactly one full batch of 7 units per full window (8 x 7 units on 8 ranks); equal windows (7 + 7 + 6) round 49 / 8
+    # units up to 7 per rank in every window -- measured by emulation at G = 8: 916 vs 858 frames/s.
+    # MFT_BENCH_EQUAL_WINDOWS=1: the equal split.
     n_win = -(-count // window)
-    sizes = [count // n_win + (1 if k < count % n_win else 0) for k in range(n_win)]
+    sizes = [window] * (count // window) + ([count % window] if count % window else [])
+    if os.environ.get("MFT_BENCH_EQUAL_WINDOWS"):
+        sizes = [count // n_win + (1 if k < count % n_win else 0) for k in range(n_win)]
     i, got = first, 0
     for k, n in enumerate(sizes):
         nn = sizes[k + 1] if k + 1 < n_win else 0
