@@ -262,7 +262,7 @@ int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
  *                            0 plain launches
  *   MFTX_RAFT_OPT_FUSE_FLOW  1 default (use the fused convf1 + convf2 kernel when its weights are set), 0 keep them apart
  *   MFTX_RAFT_OPT_TILE_CONV  1 default (layers with tile-resident weights set run on that kernel when its tiles of 128 cells come in
- *                            rounds of the chip that are at least 3/4 full -- e.g. 6 or 7 pairs of 512 x 512, 1080p), 2 always,
+ *                            rounds of the chip that are at least 5/8 full -- e.g. 5 to 7 pairs of 512 x 512, 1080p), 2 always,
  *                            0 all on mftx_conv2d's
  *   MFTX_RAFT_OPT_FUSE_HEAD  1 default (both layers of the flow head as mftx_flow_head when its weights are set), 0 two layers
  *   MFTX_RAFT_OPT_TILE_VOLUME 1 default (split arithmetic: the correlation volume by the tile-resident kernel, csrc/volume_tile.hip),

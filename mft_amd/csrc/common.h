@@ -168,7 +168,7 @@ struct TileConvLaunch {
 int launch_pack_flow_head(const float *w2pk, void *out, hipStream_t s);
 int launch_flow_head_sum(const float *T, const float *b2, float *delta, float *coords, int P, int h, int w, hipStream_t s);
 bool tile_conv_applicable(int kh, int kw, int cin, int N);
-bool tile_conv_fills_chip(int P, int h, int w, int kh, int kw);     // its tiles come in rounds of the chip that are >= 3/4 full
+bool tile_conv_fills_chip(int P, int h, int w, int kh, int kw);     // its tiles come in rounds of the chip that are >= 5/8 full
 int launch_pack_tile_conv(const float *wpk, int N, int taps, int cin, int cin_pad, void *out, hipStream_t s);
 int launch_tile_conv(const TileConvLaunch &d, hipStream_t s);
 // on-demand correlation (csrc/corr_ondemand.hip): pooled feature pyramid + lookup without a stored volume

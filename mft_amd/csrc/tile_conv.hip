@@ -440,7 +440,7 @@ bool tile_conv_applicable(int kh, int kw, int cin, int N) {
 }
 
 // The kernel takes the time of ONE tile's K loop however few tiles there are (one workgroup per tile, one per CU): it pays
-// only when its tiles come in nearly whole rounds of the chip -- 7 pairs of 64 x 64 cells are 224 tiles on 256 CUs, at
+// only when its tiles come in nearly whole rounds of the chip (>= 5/8 full) -- 7 pairs of 64 x 64 cells are 224 tiles on 256 CUs, at
 // 256 x 256 pixels (56 tiles) the ring-buffered kernel's 64 x 64 tiles are 30 % faster (bench.py, 332 vs 254 frames/s)
 bool tile_conv_fills_chip(int P, int h, int w, int kh, int kw) {
     static const int cus = [] {
@@ -452,7 +452,7 @@ bool tile_conv_fills_chip(int P, int h, int w, int kh, int kw) {
     const int th = kh == 3 ? 8 : (kh == 1 ? 4 : 32), tw = 128 / th;
     const long long tiles = (long long)P * cdiv(h, th) * cdiv(w, tw);
     const long long rounds = (tiles + cus - 1) / cus;
-    return tiles * 4 >= rounds * cus * 3;
+    return tiles * 8 >= rounds * cus * 5;      // >= 5/8: one refinement of 5 / 6 / 7 pairs of 64 x 64 cells is 2 / 8 / 7 % faster with them, of 4 pairs 8 % slower (tools/bench_pairs.py)
 }
 
 int launch_tile_conv(const TileConvLaunch &d, hipStream_t s) {

@@ -392,9 +392,13 @@ def test_c5_1080p_pair_vs_oracle(flower, weights_np, weights_cpu):
     torch.cuda.empty_cache()
 
 
-def test_compute_flow_1080p_smoke(flower):
+def test_compute_flow_1080p_smoke(flower, weights_np):
     """BASELINE config 5 size (1080x1920, 135x240 grid, 4.2 GB level-0 volume per
-    pair): runs, is finite, and a pair's result does not depend on batching."""
+    pair): runs, is finite, and a pair's result does not depend on batching -- bit for bit while the engine picks the same
+    kernels for both batches (pinned here: the tile-resident GEMM layers are chosen by how well their 128-cell tiles fill
+    the chip, which one pair of this size does not and two do), to fp32 rounding of the K sums otherwise."""
+    from mft_amd.config import AttrDict, Config
+    from mft_amd.raft import RAFTWrapper
     vid = SyntheticVideo(1080, 1920, n_frames=3, seed=17)
     flower.C.flow_iters = 2
     try:
@@ -405,9 +409,19 @@ def test_compute_flow_1080p_smoke(flower):
     for t in a[0]:
         assert bool(torch.isfinite(t).all())
     assert a[0][0].shape == (2, 1080, 1920)
-    for x, y in zip(a[0], b[1]):
-        assert torch.equal(x, y)
-    torch.cuda.empty_cache()
+    assert epe(a[0][0].cpu(), b[1][0].cpu()).max() < 1e-4                 # (default selection: 1 pair ring-buffered, 2 pairs tile-resident)
+    assert (a[0][1] - b[1][1]).abs().max() < 1e-4
+    for opt in (0, 2):                                                      # the same kernels for both batches: the same bits
+        c = Config()
+        c.flow_iters = 2
+        c.raft_params = AttrDict(engine_options={"tile_conv": opt})
+        fl = RAFTWrapper(c, state_dict=weights_np)
+        a = fl.compute_flow_many([(None, vid[0])], (None, vid[2]))
+        b = fl.compute_flow_many([(None, vid[1]), (None, vid[0])], (None, vid[2]))
+        for x, y in zip(a[0], b[1]):
+            assert torch.equal(x, y), opt
+        del fl, a, b
+        torch.cuda.empty_cache()
 
 
 def test_async_encode_is_bitwise_identical(weights_np):

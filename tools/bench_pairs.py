@@ -19,7 +19,8 @@ from mft_amd import _lib  # noqa: E402
 from mft_amd.config import load_config  # noqa: E402
 from mft_amd.synth import SyntheticVideo  # noqa: E402
 
-CATS = ["corr_volume", "corr_pool", "lookup", "conv_gemm", "convf1", "glue", "upsample", "chain", "conv_small", "enc_norm"]
+CATS = ["corr_volume", "corr_pool", "lookup", "conv_gemm", "convf1", "glue", "upsample", "chain", "conv_small", "enc_norm",
+        "lookup_fused", "flow_fused"]
 
 
 def main():
@@ -29,6 +30,7 @@ def main():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--own-stream", action="store_true", help="run on a non-default stream (graph capture needs one)")
+    ap.add_argument("--engine-opt", action="append", metavar="NAME=INT", help="engine option, e.g. tile_conv=2 (always) / 0 (never)")
     a = ap.parse_args()
     conf = load_config(REPO / "configs" / "MFT_cfg.py")
     fc = conf.flow_config
@@ -37,6 +39,8 @@ def main():
     fc.flow_iters = a.iters
     fc.async_encode = False
     fc.split_streams = 1          # one batch on one stream: per-kernel event times must not overlap
+    if a.engine_opt:
+        fc.raft_params.engine_options = {kv.partition("=")[0]: int(kv.partition("=")[2]) for kv in a.engine_opt}
     flower = fc.of_class(fc)
     vid = SyntheticVideo(a.size, a.size, n_frames=8, seed=0)
     frames = [vid[i] for i in range(8)]
