@@ -140,3 +140,77 @@ def test_conv2d_random(c0, two, c1, cout, k, P, h, w, act, with_addend, seed):
                      addend=pm(add) if add is not None else None)
     got = out.reshape(P, h, w, cout).permute(0, 3, 1, 2).cpu()
     assert (got - ref).abs().max() < 3e-5 * max(1.0, float(lin.abs().max()))
+
+
+# ---- round 3: the tile-resident kernels over ragged shapes (tiles cut by the image border, images smaller than a tile,
+# odd widths, several pairs) against fp64 / the ring-buffered kernels
+
+@SET
+@given(h=st.integers(1, 27), w=st.integers(1, 41), P=st.integers(1, 3), seed=st.integers(0, 10_000),
+       spread=st.sampled_from([0.5, 6.0, 60.0]))
+def test_flow_branch_random(h, w, P, seed, spread):
+    from mft_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    w1, b1 = torch.randn(128, 2, 7, 7, generator=g) * 0.1, torch.randn(128, generator=g) * 0.1
+    w2, b2 = torch.randn(64, 128, 3, 3, generator=g) * 0.05, torch.randn(64, generator=g) * 0.1
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    grid = torch.stack([xs, ys], -1).reshape(1, h * w, 2)
+    coords = grid + spread * torch.randn(P, h * w, 2, generator=g)
+    wflow = ops.pack_flow_branch_weights(w1.permute(2, 3, 1, 0).reshape(98, 128).contiguous().to(DEV), ops.pack_conv_weight(w2.to(DEV)))
+    got = ops.unsplit_activations(ops.flow_branch(coords.to(DEV), h, w, wflow, b1.to(DEV), b2.to(DEV))).cpu().double()
+    flow = (coords - grid).double().reshape(P, h, w, 2).permute(0, 3, 1, 2)
+    f1 = torch.relu(torch.nn.functional.conv2d(flow, w1.double(), b1.double(), padding=3))
+    ref = torch.relu(torch.nn.functional.conv2d(f1, w2.double(), b2.double(), padding=1)).permute(0, 2, 3, 1).reshape(P * h * w, 64)
+    assert float((got - ref).abs().max()) < 2e-6 * max(float(ref.abs().max()), 1.0)
+
+
+@SET
+@given(shape=st.sampled_from([(128, 256, 3, 3), (128, 128, 3, 3), (256, 256, 1, 5), (256, 128, 1, 5), (256, 256, 5, 1),
+                              (256, 128, 5, 1), (128, 256, 5, 1), (128, 128, 1, 5)]),
+       h=st.integers(1, 37), w=st.integers(1, 37), P=st.integers(1, 2), act=st.sampled_from([None, "relu"]),
+       with_addend=st.booleans(), seed=st.integers(0, 10_000))
+def test_tile_conv_random(shape, h, w, P, act, with_addend, seed):
+    from mft_amd import ops
+    cin, cout, kh, kw = shape
+    g = torch.Generator().manual_seed(seed)
+    M = P * h * w
+    x = torch.randn(M, cin, generator=g)
+    wt = torch.randn(cout, cin, kh, kw, generator=g) * 0.05
+    b = torch.randn(cout, generator=g)
+    add = torch.randn(M, cout, generator=g) if with_addend else None
+    wpk = ops.pack_conv_weight(wt.to(DEV))
+    xs = ops.split_activations(x.to(DEV))
+    x1, x2 = (xs, None) if cin == 128 else (xs[:, :128].contiguous(), xs[:, 128:].contiguous())
+    got = ops.tile_conv2d(x1, ops.pack_tile_conv_weights(wpk, cout, cin), b.to(DEV), P, h, w, cout, kh, kw, act=act, x2=x2,
+                          addend=None if add is None else add.to(DEV))
+    xi = x.double().reshape(P, h, w, cin).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xi, wt.double(), b.double(), padding=(kh // 2, kw // 2)).permute(0, 2, 3, 1).reshape(M, cout)
+    if add is not None:
+        ref = ref + add.double()
+    if act == "relu":
+        ref = torch.relu(ref)
+    assert float((got.cpu().double() - ref).abs().max()) < 3e-6 * max(float(ref.abs().max()), 1.0)
+
+
+@SET
+@given(h=st.integers(8, 29), w=st.integers(8, 37), P=st.integers(1, 2), seed=st.integers(0, 10_000))
+def test_corr_pyramid_tile_resident_random(h, w, P, seed):
+    """Level 0 against fp64, the pooled levels bit for bit against avg_pool2d of the stored level 0 (ATen's order), over
+    shapes whose super-blocks are cut by the map's border and whose pooled sizes are odd."""
+    from mft_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    f1, f2 = torch.randn(P, h * w, 256, generator=g), torch.randn(P, h * w, 256, generator=g)
+    lv = ops.corr_pyramid(f1.to(DEV), f2.to(DEV), h, w, arith=1)
+    stride, _ = ops.pyramid_layout(h, w)
+    l0 = ops.unblock_level(lv[0], 0, h, w).reshape(P * h * w, 1, h, w).cpu()
+    ref = (f1.double() @ f2.double().transpose(1, 2) / 16).reshape(P * h * w, 1, h, w)
+    assert float((l0.double() - ref).abs().max()) < 3e-6 * float(ref.abs().max())
+    cur = l0
+    for l in (1, 2, 3):
+        cur = torch.nn.functional.avg_pool2d(cur, 2, 2)
+        hl, wl = h >> l, w >> l
+        if l == 1:
+            got = ops.unblock_level(lv[1], 1, h, w).reshape(P * h * w, 1, hl, wl).cpu()
+        else:
+            got = lv[l].reshape(P * h * w, -1)[:, :hl * wl].reshape(P * h * w, 1, hl, wl).cpu()
+        assert torch.equal(got, cur), l
