@@ -264,7 +264,9 @@ int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
  *   MFTX_RAFT_OPT_TILE_CONV  1 default (layers with tile-resident weights set run on that kernel when its tiles of 128 cells come in
  *                            rounds of the chip that are at least 5/8 full -- e.g. 5 to 7 pairs of 512 x 512, 1080p), 2 always,
  *                            0 all on mftx_conv2d's
- *   MFTX_RAFT_OPT_FUSE_HEAD  1 default (both layers of the flow head as mftx_flow_head when its weights are set), 0 two layers
+ *   MFTX_RAFT_OPT_FUSE_HEAD  1 default (both layers of the flow head as mftx_flow_head when its weights are set; with the fused flow
+ *                            branch, an iteration's coordinate update is applied by the next iteration's flow-branch kernel instead
+ *                            of by a launch of its own), 2 the same with the update always applied by its own kernel, 0 two layers
  *   MFTX_RAFT_OPT_TILE_VOLUME 1 default (split arithmetic: the correlation volume by the tile-resident kernel, csrc/volume_tile.hip),
  *                            0 the ring-buffered GEMM */
 #define MFTX_RAFT_OPT_FORK 0

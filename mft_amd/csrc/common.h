@@ -151,7 +151,8 @@ int launch_lookup_convc1(const float *const lvl[4], const float *coords, int P, 
 // the motion encoder's flow branch as one kernel (csrc/flow_branch.hip): out = relu(convf2(relu(convf1(coords - grid)))), split form
 int launch_pack_flow_branch(const float *w98, const float *w2pk, void *out, hipStream_t s);
 int launch_flow_branch(const float *coords, int P, int h, int w, const void *wf, const float *b1, const float *b2, float *out,
-                       int ld_out, float *hx, int ld_hx, hipStream_t s);
+                       int ld_out, float *hx, int ld_hx, hipStream_t s, const float *T = nullptr, const float *b2h = nullptr,
+                       float *coords_out = nullptr, float *delta_out = nullptr);
 // tile-resident convolution GEMM (csrc/tile_conv.hip): the update block's layers whose input tile fits a CU's LDS
 struct TileConvLaunch {
     const float *a0; int lda0;          // 128 channels per cell in split form
@@ -166,7 +167,7 @@ struct TileConvLaunch {
     int P, h, w, N, kh, kw, epi;
 };
 int launch_pack_flow_head(const float *w2pk, void *out, hipStream_t s);
-int launch_flow_head_sum(const float *T, const float *b2, float *delta, float *coords, int P, int h, int w, hipStream_t s);
+int launch_flow_head_sum(const float *T, const float *b2, float *delta, const float *coords_in, float *coords_out, int P, int h, int w, hipStream_t s);
 bool tile_conv_applicable(int kh, int kw, int cin, int N);
 bool tile_conv_fills_chip(int P, int h, int w, int kh, int kw);     // its tiles come in rounds of the chip that are >= 5/8 full
 int launch_pack_tile_conv(const float *wpk, int N, int taps, int cin, int cin_pad, void *out, hipStream_t s);

@@ -63,6 +63,12 @@ struct FlowBranchArgs {
     const float *b1, *b2;
     float *out; int ld_out;     // 64 channels per cell in split form at out + cell * ld_out (floats)
     float *hx; int ld_hx;       // split-form GRU input: the flow goes to channels 382, 383 (nullptr: not written)
+    // Optional: the previous iteration's flow-head update, not applied yet.  T [P*h*w][18] = the head's partial products
+    // (tile_conv.hip: TC_RELU_PROJ), b2h its bias: every cell of the tile (halo included) first becomes coords + delta,
+    // delta[o] = b2h[o] + the nine shifted T terms -- exactly flow_head_sum_kernel's sum -- and the tile's own cells are
+    // written to coords_out (ANOTHER buffer: the halo cells of this tile are other workgroups' own cells) and delta_out.
+    const float *T, *b2h;
+    float *coords_out, *delta_out;
     int P, h, w, tiles_x, tiles_y;
 };
 
@@ -162,7 +168,28 @@ __global__ __launch_bounds__(512, 2) void flow_branch_kernel(FlowBranchArgs p) {
         unsigned hw = 0u, lw = 0u;
         if (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w) {
             const long long cell = img_base + (long long)yy * p.w + xx;
-            const float2 cd = *reinterpret_cast<const float2 *>(p.coords + 2 * cell);
+            float2 cd = *reinterpret_cast<const float2 *>(p.coords + 2 * cell);
+            if (p.T) {                                                   // (flow_head_sum_kernel's arithmetic, term by term)
+                float sx = 0.f, sy = 0.f;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int ny = yy + dy - 1, nx = xx + dx - 1;
+                        if (ny >= 0 && ny < p.h && nx >= 0 && nx < p.w) {
+                            const float2 t = *reinterpret_cast<const float2 *>(p.T + (cell + (long long)(dy - 1) * p.w + (dx - 1)) * 18 + 2 * (3 * dy + dx));
+                            sx += t.x;
+                            sy += t.y;
+                        }
+                    }
+                const float dlx = sx + p.b2h[0], dly = sy + p.b2h[1];
+                cd.x += dlx;
+                cd.y += dly;
+                if (r >= 4 && r < 4 + FB_TH && c >= 4 && c < 4 + FB_TW) {
+                    *reinterpret_cast<float2 *>(p.coords_out + 2 * cell) = cd;
+                    *reinterpret_cast<float2 *>(p.delta_out + 2 * cell) = make_float2(dlx, dly);
+                }
+            }
             f.x = cd.x - (float)xx;
             f.y = cd.y - (float)yy;
             const unsigned sx = split_halves(f.x), sy = split_halves(f.y);
@@ -390,13 +417,16 @@ int launch_pack_flow_branch(const float *w98, const float *w2pk, void *out, hipS
 }
 
 int launch_flow_branch(const float *coords, int P, int h, int w, const void *wf, const float *b1, const float *b2, float *out,
-                       int ld_out, float *hx, int ld_hx, hipStream_t s) {
+                       int ld_out, float *hx, int ld_hx, hipStream_t s, const float *T, const float *b2h, float *coords_out, float *delta_out) {
+    if (T && (!b2h || !coords_out || !delta_out || coords_out == coords || (reinterpret_cast<uintptr_t>(T) & 7) || (reinterpret_cast<uintptr_t>(coords_out) & 7) ||
+              (reinterpret_cast<uintptr_t>(delta_out) & 7)))
+        return fail(MFTX_E_ARG, "flow_branch: a pending flow-head update needs its bias, a SECOND coordinate buffer and a delta buffer, 8-byte aligned");
     if (!coords || !wf || !b1 || !b2 || !out) return fail(MFTX_E_ARG, "flow_branch: null pointer");
     if (P <= 0 || h <= 0 || w <= 0) return fail(MFTX_E_ARG, "flow_branch: bad sizes");
     if (ld_out < 64 || ld_out % 8 || (reinterpret_cast<uintptr_t>(out) & 31) || (hx && (ld_hx < 384 || ld_hx % 8 || (reinterpret_cast<uintptr_t>(hx) & 31))))
         return fail(MFTX_E_ALIGN, "flow_branch: split-form rows are 32-byte aligned with strides in multiples of 8");
     if (!aligned16(wf) || !aligned16(b2) || (reinterpret_cast<uintptr_t>(coords) & 7)) return fail(MFTX_E_ALIGN, "flow_branch: weights / bias / coordinates misaligned");
-    FlowBranchArgs a{coords, wf, b1, b2, out, ld_out, hx, ld_hx, P, h, w, cdiv(w, FB_TW), cdiv(h, FB_TH)};
+    FlowBranchArgs a{coords, wf, b1, b2, out, ld_out, hx, ld_hx, T, b2h, coords_out, delta_out, P, h, w, cdiv(w, FB_TW), cdiv(h, FB_TH)};
     const long long tiles = (long long)P * a.tiles_x * a.tiles_y;
     if (tiles > 0x7fffffffLL) return fail(MFTX_E_ARG, "flow_branch: too many tiles");
     static bool attr_set = false;

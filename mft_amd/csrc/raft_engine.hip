@@ -454,10 +454,16 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     }
     const float *lv[4] = {ws.lvl[0], ws.lvl[1], ws.lvl[2], ws.lvl[3]};
     const int strips = cdiv(w, F1_CELLS);
+    // The coordinates the iteration works on.  With the flow branch and the flow head both fused, an iteration's update is
+    // applied by the NEXT iteration's flow-branch kernel (which reads every cell of its tile anyway) into the other of two
+    // buffers -- flo1 is free then -- instead of by a launch of its own; only the last update is applied by
+    // flow_head_sum_kernel, into coords1.
+    float *ccur = ws.coords1, *calt = ws.flo1;
+    bool pending = false;                    // ws.fh holds an update (T) that ccur does not contain yet
     for (int it = 0; it < iters; ++it) {
         const bool last = (it == iters - 1);
         if (r->coords_trace &&       // RAFT.forward(vis_debug=True): the coordinates every iteration starts from (core/raft.py:175-176)
-            hipMemcpyAsync(r->coords_trace + (size_t)it * M * 2, ws.coords1, (size_t)M * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            hipMemcpyAsync(r->coords_trace + (size_t)it * M * 2, ccur, (size_t)M * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
             return fail(MFTX_E_STATE, "raft_refine: coords trace copy failed");
         // The motion encoder has two independent branches (core/update.py:152-158): correlation lookup -> convc1 -> convc2
         // and convf1 -> convf2 on the flow.  Both need only coords1.  Split arithmetic, small batches (up to four
@@ -468,7 +474,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         // for the flow branch's small kernels: 129.2 -> 130.3 frames/s (MFTX_RAFT_FORK=0: in order on one stream, with
         // lookup + convf1 as one launch).  fp32 MFMA keeps round 1's grouping (lookup + convf1 in one launch,
         // convc2 + convf2 in one launch).  The per-kernel timing pass and MFTX_RAFT_NOFUSE run everything in order.
-        const ConvF1Args f1{ws.coords1, W[W_CONVF1], W[B_CONVF1], ws.flo1, ws.hx, h, w, strips, P * h * strips, SP ? 1 : 0};
+        const ConvF1Args f1{ccur, W[W_CONVF1], W[B_CONVF1], ws.flo1, ws.hx, h, w, strips, P * h * strips, SP ? 1 : 0};
         const int f1_blocks = cdiv(f1.n_strips, 2);
         const bool nofuse = r->opt[MFTX_RAFT_OPT_GROUP] == 0, nopair = nofuse;
         const mftx_conv_desc c2 = gemm(conv_desc(ws.cor1, 256, 256, nullptr, 0, 0, G[W_CONVC2], W[B_CONVC2], ws.corflo, 256, P, h, w, 192, 3, 3, 1), true, true);
@@ -476,7 +482,13 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         const int fork_env = r->opt[MFTX_RAFT_OPT_FORK];      // 0 never, -1 / 1 with the split arithmetic
         // the flow branch as ONE kernel (csrc/flow_branch.hip), in order on this stream: no side stream, no join
         const bool fuse_flow = SP && r->wflow != nullptr && r->opt[MFTX_RAFT_OPT_FUSE_FLOW] != 0 && !nofuse;
-        if (fuse_flow) TRY(launch_flow_branch(ws.coords1, P, h, w, r->wflow, W[B_CONVF1], W[B_CONVF2], ws.corflo + 192, 256, ws.hx, 384, s));
+        if (fuse_flow) {
+            if (pending) {
+                TRY(launch_flow_branch(ccur, P, h, w, r->wflow, W[B_CONVF1], W[B_CONVF2], ws.corflo + 192, 256, ws.hx, 384, s, ws.fh, W[B_FH2], calt, ws.delta));
+                float *t = ccur; ccur = calt; calt = t;
+                pending = false;
+            } else TRY(launch_flow_branch(ccur, P, h, w, r->wflow, W[B_CONVF1], W[B_CONVF2], ws.corflo + 192, 256, ws.hx, 384, s));
+        }
         const bool serial = fuse_flow || prof_enabled() || nofuse || (AR == MFTX_ARITH_SPLIT && (fork_env == 0 || fork_env == 2));
         const bool forked = !serial && AR == MFTX_ARITH_SPLIT;
         const bool flow_first = !fuse_flow && serial && fuse_lookup && fork_env == 2 && !prof_enabled() && !nofuse;    // convf1, convf2, then the correlation branch
@@ -493,14 +505,14 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
             TRY(check_launch("convf1"));
             TRY(launch_conv(f2, r->side));
             // fused lookup: the features themselves are needed once, by ou_gather behind the last iteration -- off the critical path
-            if (fuse_lookup && last) TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr, r->side));
+            if (fuse_lookup && last) TRY(launch_corr_lookup(lv, ccur, P, h, w, ws.corr, ws.ld_corr, r->side));
             if (hipEventRecord(r->ev_join, r->side) != hipSuccess) return fail(MFTX_E_STATE, "raft_refine: join event failed");
         }
         // lookup + convf1 as ONE launch (HBM gathers beside VALU work) whenever the flow branch is not on the side stream:
         // 113.7 vs 113.2 frames/s with the split arithmetic; the timing pass and MFTX_RAFT_NOFUSE keep them apart
         if (fuse_lookup) {
-            if (last && !forked) TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr, s));
-            TRY(launch_lookup_convc1(lv, ws.coords1, P, h, w, r->wfused, W[B_CONVC1], ws.cor1, 256, 1, s));
+            if (last && !forked) TRY(launch_corr_lookup(lv, ccur, P, h, w, ws.corr, ws.ld_corr, s));
+            TRY(launch_lookup_convc1(lv, ccur, P, h, w, r->wfused, W[B_CONVC1], ws.cor1, 256, 1, s));
             if (!forked && !flow_first && !fuse_flow) {
                 ProfScope prof(PC_CONVF1, s, 2.0 * M * 128 * 98);
                 hipLaunchKernelGGL(convf1_kernel, dim3(f1_blocks), dim3(256), 0, s, f1);
@@ -508,14 +520,14 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         } else if (prof_enabled() || nofuse || forked || ondemand || fuse_flow) {
             // (the 324 features stay fp32: written in split form the lookup takes 31 instead of 27 us, more than convc1
             // gains from a pre-split A -- and its HBM roofline is the one with a north-star target)
-            if (ondemand) TRY(launch_corr_ondemand(fmap1, f2lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr, s));
-            else TRY(launch_corr_lookup(lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr, s));
+            if (ondemand) TRY(launch_corr_ondemand(fmap1, f2lv, ccur, P, h, w, ws.corr, ws.ld_corr, s));
+            else TRY(launch_corr_lookup(lv, ccur, P, h, w, ws.corr, ws.ld_corr, s));
             if (!forked && !fuse_flow) {
                 ProfScope prof(PC_CONVF1, s, 2.0 * M * 128 * 98);
                 hipLaunchKernelGGL(convf1_kernel, dim3(f1_blocks), dim3(256), 0, s, f1);
             }
         } else {
-            const LookupArgs la = make_lookup_args(lv, ws.coords1, P, h, w, ws.corr, ws.ld_corr);
+            const LookupArgs la = make_lookup_args(lv, ccur, P, h, w, ws.corr, ws.ld_corr);
             const int lookup_blocks = cdiv(cdiv(la.cells, 2), LK_WAVES);
             hipLaunchKernelGGL(lookup_convf1_kernel, dim3(lookup_blocks + f1_blocks), dim3(256), 0, s, la, f1,
                                lookup_blocks, f1_blocks);
@@ -562,7 +574,15 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
             TileConvLaunch t = tile_layer(ws.hx, 384, nullptr, 0, tile_w(W_FH1), W[B_FH1], 256, 3, 3, 4);
             t.wproj = r->wproj; t.tout = ws.fh;
             TRY(launch_tile_conv(t, s));
-            TRY(launch_flow_head_sum(ws.fh, W[B_FH2], ws.delta, ws.coords1, P, h, w, s));
+            // (the update is left pending for the next iteration's flow-branch kernel when that kernel runs; the last one, and every
+            // one under a debug trace, is applied here -- the last into coords1, whichever buffer is current)
+            const bool defer = !last && fuse_flow && r->opt[MFTX_RAFT_OPT_FUSE_HEAD] != 2 && !r->coords_trace;       // (fuse_flow: the same for every iteration)
+            if (defer) pending = true;
+            else {
+                float *dst = last ? ws.coords1 : ccur;
+                TRY(launch_flow_head_sum(ws.fh, W[B_FH2], ws.delta, ccur, dst, P, h, w, s));
+                ccur = dst;
+            }
         } else if (tile_w(W_FH1)) {
             TileConvLaunch t = tile_layer(ws.hx, 384, nullptr, 0, tile_w(W_FH1), W[B_FH1], 256, 3, 3, 1);
             t.out = ws.fh; t.ldo = 256;
@@ -572,11 +592,11 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
         if (!head_fused) {
             const mftx_conv_desc fh2 = conv_desc(ws.fh, 256, 256, nullptr, 0, 0, W[W_FH2], W[B_FH2], ws.delta, 2, P, h, w, 2, 3, 3, 0);
             if (!conv_small_applicable(fh2)) return fail(MFTX_E_STATE, "raft_refine: flow-head layer does not fit the small-N kernel");
-            TRY(launch_conv_small(fh2, s, ws.coords1, 2));
+            TRY(launch_conv_small(fh2, s, ccur, 2));
         }
         if (!last) continue;
         if (r->coords_trace &&       // ... and the final ones (core/raft.py:255-256)
-            hipMemcpyAsync(r->coords_trace + (size_t)iters * M * 2, ws.coords1, (size_t)M * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            hipMemcpyAsync(r->coords_trace + (size_t)iters * M * 2, ccur, (size_t)M * 8, hipMemcpyDeviceToDevice, s) != hipSuccess)
             return fail(MFTX_E_STATE, "raft_refine: coords trace copy failed");
         // The upsampling mask is consumed only after the last iteration in test
         // mode (core/raft.py:190-196,234-239), so it is computed once.
@@ -591,7 +611,7 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
             const long long slots = (long long)M * 178;
             ProfScope prof(PC_GLUE, s, 0);
             hipLaunchKernelGGL(ou_gather_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, ws.hx,
-                               ws.corr, ws.ld_corr, ws.coords1, ws.delta, ws.ouin, flow_lr, M, h, w, SP ? 1 : 0);
+                               ws.corr, ws.ld_corr, ccur, ws.delta, ws.ouin, flow_lr, M, h, w, SP ? 1 : 0);
             TRY(check_launch("ou_gather"));
         }
         TRY(launch_conv(gemm(conv_desc(ws.ouin, 712, 712, nullptr, 0, 0, G[W_OU1], W[B_OU1], ws.ouh, 256, P, h, w, 256, 3, 3, 1), true, false), s));
@@ -715,7 +735,7 @@ extern "C" int mftx_flow_head(const float *hsplit, int ld_h, int P, int h, int w
     t.a0 = hsplit; t.lda0 = ld_h; t.cin = 128; t.wf = wtile; t.bias = b1; t.wproj = wproj; t.tout = T;
     t.P = P; t.h = h; t.w = w; t.N = 256; t.kh = 3; t.kw = 3; t.epi = 4;
     if (int e = launch_tile_conv(t, (hipStream_t)stream)) return e;
-    return launch_flow_head_sum(T, b2, delta, coords, P, h, w, (hipStream_t)stream);
+    return launch_flow_head_sum(T, b2, delta, coords, coords, P, h, w, (hipStream_t)stream);
 }
 
 extern "C" int mftx_pack_flow_branch_weights(const float *w98, const float *w2pk, void *wflow, void *stream) {

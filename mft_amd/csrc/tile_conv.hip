@@ -518,7 +518,7 @@ int launch_pack_flow_head(const float *w2pk, void *out, hipStream_t s) {
 // delta[c][o] = b2[o] + sum over the 9 taps of T[c + (dy - 1, dx - 1)][2 (3 dy + dx) + o], neighbours outside the image
 // contributing nothing (conv2's zero padding); coords[c] += delta[c] (core/raft.py:184)
 __global__ __launch_bounds__(256) void flow_head_sum_kernel(const float *__restrict__ T, const float *__restrict__ b2, float *__restrict__ delta,
-                                                            float *__restrict__ coords, int P, int h, int w) {
+                                                            const float *coords_in, float *coords_out, int P, int h, int w) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over cells x 2
     if (i >= (long long)P * h * w * 2) return;
     const int o = (int)(i & 1);
@@ -534,14 +534,14 @@ __global__ __launch_bounds__(256) void flow_head_sum_kernel(const float *__restr
         }
     const float dl = sum + b2[o];
     delta[i] = dl;
-    if (coords) coords[i] += dl;
+    if (coords_out) coords_out[i] = coords_in[i] + dl;         // (in place or into another buffer: element-wise)
 }
 
-int launch_flow_head_sum(const float *T, const float *b2, float *delta, float *coords, int P, int h, int w, hipStream_t s) {
-    if (!T || !b2 || !delta) return fail(MFTX_E_ARG, "flow_head_sum: null pointer");
+int launch_flow_head_sum(const float *T, const float *b2, float *delta, const float *coords_in, float *coords_out, int P, int h, int w, hipStream_t s) {
+    if (!T || !b2 || !delta || (coords_out && !coords_in)) return fail(MFTX_E_ARG, "flow_head_sum: null pointer");
     const long long n = (long long)P * h * w * 2;
     ProfScope prof(PC_CONV_SMALL, s, 2.0 * P * h * w * 2 * 9);
-    hipLaunchKernelGGL(flow_head_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T, b2, delta, coords, P, h, w);
+    hipLaunchKernelGGL(flow_head_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T, b2, delta, coords_in, coords_out, P, h, w);
     return check_launch("flow_head_sum");
 }
 

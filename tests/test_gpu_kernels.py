@@ -1169,6 +1169,15 @@ def test_engine_tile_resident_volume_bitwise():
     assert np.array_equal(tiled, ring)
 
 
+def test_engine_deferred_flow_head_update_bitwise():
+    """An iteration's coordinate update applied by the NEXT iteration's flow-branch kernel (into a second buffer; the
+    default when flow branch and flow head are both fused) against the same update by a kernel of its own (fuse_head = 2):
+    the same sums in the same order -- the same bits."""
+    merged, own = _engine_outputs({"tile_conv": 2}), _engine_outputs({"tile_conv": 2, "fuse_head": 2})
+    assert np.isfinite(merged).all()
+    assert np.array_equal(merged, own)
+
+
 def _tile_layers(arith, tile, ref=False):
     """A few conv GEMMs with the tile shape forced (mftx_conv2d_tile), outputs concatenated."""
     from mft_amd import ops
