@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MFTX_VERSION 304
+#define MFTX_VERSION 305
 
 #define MFTX_E_ARG (-1)      /* null pointer / non-positive size / unsupported shape */
 #define MFTX_E_ALIGN (-2)    /* pointer or leading dimension not 16-byte aligned */
@@ -304,6 +304,16 @@ int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters,
                      int pad_left, int pad_right, int pad_top, int pad_bottom,
                      float *flow, float *occl, float *sigma, float *packed, float *flow_lr,
                      void *workspace, size_t workspace_bytes, void *stream);
+/* The same with the pairs' maps where they lie: fmap1 / fmap2 / net / inp are arrays of P pointers (host memory), pair b's maps
+ * [h*w][256] / [h*w][128] at fmap1[b] etc. -- the P left frames of a tracker step are P cached tensors and its right frame ONE:
+ * no gather copy into batch tensors, and a second map that all pairs share (fmap2[b] all equal) is split once.  P <= 16;
+ * needs the split arithmetic with the stored, tile-resident correlation volume (otherwise MFTX_E_STATE: use mftx_raft_refine).
+ * Same kernels on the same values as mftx_raft_refine on the stacked maps: same bits. */
+int mftx_raft_refine_gather(mftx_raft *r, int P, int h, int w, int iters, const float *const *fmap1,
+                            const float *const *fmap2, const float *const *net, const float *const *inp,
+                            const float *flow_init, int pad_left, int pad_right, int pad_top, int pad_bottom,
+                            float *flow, float *occl, float *sigma, float *packed, float *flow_lr_out,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- a3: feature / context encoder (BasicEncoder, core/extractor.py:118-195) ---------
  * Replaces fnet / cnet of RAFT.forward (core/raft.py:122-149) incl. RAFTWrapper's

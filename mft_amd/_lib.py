@@ -82,6 +82,11 @@ SIGNATURES = {
                                    C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mftx_raft_refine_gather": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          _PP, _PP, _PP, _PP, C.c_void_p,
+                                          C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_size_t, C.c_void_p]),
     "mftx_encoder_create": (C.c_int, [_PP, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mftx_encoder_destroy": (None, [C.c_void_p]),
     "mftx_encoder_set_graph": (C.c_int, [C.c_void_p, C.c_int]),

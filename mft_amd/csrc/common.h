@@ -140,7 +140,13 @@ int launch_corr_pyramid(const float *f1, const float *f2, int P, int C, int h, i
                         float *f2_split = nullptr, int tile_resident = 1);
 // the split-arithmetic volume with the target super-block resident in LDS (csrc/volume_tile.hip); f2s: split form of f2
 bool volume_tile_applicable(int C);
-int launch_volume_tile(const float *f1, const float *f2s, int P, int h, int w, float *const lvl[4], hipStream_t s);
+// per-pair feature pointers (mftx_raft_refine_gather: the pairs' maps need not form one tensor)
+constexpr int MFTX_MAX_GATHER = 16;
+struct PairPtrs { const float *p[MFTX_MAX_GATHER]; };
+// f1p (optional): pair bz's query features at f1p->p[bz] instead of f1 + bz * N * 256; f2_bstride: floats between the pairs'
+// split target maps in f2s (0: every pair correlates against the same map)
+int launch_volume_tile(const float *f1, const float *f2s, int P, int h, int w, float *const lvl[4], hipStream_t s,
+                       const PairPtrs *f1p = nullptr, long long f2_bstride = -1);
 int launch_corr_lookup(const float *const lvl[4], const float *coords, int P, int h, int w,
                        float *out, int ld_out, hipStream_t s);
 // lookup fused into convc1 (csrc/lookup_convc1.hip): out = relu(convc1(lookup(coords)) + bias), [M][ld_out], fp32 or split form

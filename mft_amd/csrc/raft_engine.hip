@@ -19,12 +19,19 @@ namespace mftx {
 // (core/raft.py:146-151; coords_grid core/utils/utils.py:115-118)
 // hf (split arithmetic with split-form activations): hx is written in split form (common.h) and h additionally as
 // fp32 into hf [M][128], the copy the GRU's gate algebra reads
+// gathered != 0: pair b's net / inp maps at netp.p[b] / inpp.p[b] (mftx_raft_refine_gather) instead of net + b N 128
+struct InitGather { int on; PairPtrs netp, inpp; };
 __global__ void init_state_kernel(const float *__restrict__ net, const float *__restrict__ inp,
                                   const float *__restrict__ flow_init, float *hx, float *hf, float *coords1, int M, int h,
-                                  int w) {
+                                  int w, InitGather ga) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over M*64 float4 slots
     if (i >= (long long)M * 64) return;
     const int m = (int)(i >> 6), q = (int)(i & 63);
+    if (ga.on) {                                     // (this pair's maps: the index below becomes the cell inside the pair)
+        const int b = m / (h * w);
+        net = ga.netp.p[b] - (long long)b * h * w * 128;
+        inp = ga.inpp.p[b] - (long long)b * h * w * 128;
+    }
     const float4 v = (q < 32) ? reinterpret_cast<const float4 *>(net)[(long long)m * 32 + q]
                               : reinterpret_cast<const float4 *>(inp)[(long long)m * 32 + (q - 32)];
     if (hf != nullptr) {
@@ -360,14 +367,18 @@ static mftx_conv_desc conv_desc(const float *a0, int lda0, int c0, const float *
     return d;
 }
 
-extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, const float *fmap1,
+// gather (optional): the pairs' maps through per-pair pointers (fmap1 / fmap2 / net / inp are then unused); f2_shared: every
+// pair has the SAME second feature map (gather->f2.p[0])
+struct RefineGather { PairPtrs f1, f2, net, inp; bool f2_shared; };
+static int refine_impl(mftx_raft *r, int P, int h, int w, int iters, const float *fmap1,
                                 const float *fmap2, const float *net, const float *inp, const float *flow_init,
                                 int pad_left,
                                 int pad_right, int pad_top, int pad_bottom, float *flow, float *occl,
                                 float *sigma, float *packed, float *flow_lr_out, void *workspace,
-                                size_t workspace_bytes, void *stream) {
+                                size_t workspace_bytes, void *stream, const RefineGather *gather) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_refine: bad handle");
     const bool planar = flow && occl && sigma;
+    if (gather) { fmap1 = gather->f1.p[0]; fmap2 = gather->f2.p[0]; net = gather->net.p[0]; inp = gather->inp.p[0]; }      // (for the checks below)
     if (!fmap1 || !fmap2 || !net || !inp || !workspace || (!planar && (flow || occl || sigma || !packed)))
         return fail(MFTX_E_ARG, "raft_refine: null pointer (outputs: flow + occl + sigma, or packed, or both)");
     if (P <= 0 || h < 16 || w < 16 || iters < 1)
@@ -409,12 +420,22 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     // correlation volume + pyramid (core/corr.py:14-28)
     const float *f2lv[4] = {fmap2, ws.f2l[0], ws.f2l[1], ws.f2l[2]};
     if (ondemand) TRY(launch_fmap_pyramid(fmap2, P, 256, h, w, ws.f2l, s));   // core/corr.py:78-82 (only fmap2's pyramid is used)
+    else if (gather) {
+        // gathered pairs (split arithmetic, tile-resident volume: checked by the caller): the second maps are split into the
+        // workspace -- once when all pairs share one -- and the volume kernel takes every pair's first map where it lies
+        const long long pair_floats = (long long)N * 256;
+        if (gather->f2_shared) TRY(launch_split_weights(gather->f2.p[0], ws.f2s, pair_floats, s));
+        else for (int b = 0; b < P; ++b) TRY(launch_split_weights(gather->f2.p[b], ws.f2s + b * pair_floats, pair_floats, s));
+        TRY(launch_volume_tile(nullptr, ws.f2s, P, h, w, ws.lvl, s, &gather->f1, gather->f2_shared ? 0 : pair_floats));
+    }
     else TRY(launch_corr_pyramid(fmap1, fmap2, P, 256, h, w, ws.lvl, s, r->arith == MFTX_ARITH_SPLIT ? ws.f2s : nullptr, r->opt[MFTX_RAFT_OPT_TILE_VOLUME]));
     {
         const long long slots = (long long)M * 64;
         ProfScope prof(PC_GLUE, s, 0);
+        InitGather ga{};
+        if (gather) { ga.on = 1; ga.netp = gather->net; ga.inpp = gather->inp; }
         hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, net, inp,
-                           flow_init, ws.hx, SP ? ws.hf : nullptr, ws.coords1, M, h, w);
+                           flow_init, ws.hx, SP ? ws.hf : nullptr, ws.coords1, M, h, w, ga);
         TRY(check_launch("init_state"));
     }
     float *flow_lr = flow_lr_out ? flow_lr_out : ws.flow_lr;
@@ -632,6 +653,37 @@ extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, co
     }
     return launch_convex_upsample(flow_lr, ws.ou, 4, ws.mask, P, h, w, pad_left, pad_right, pad_top, pad_bottom,
                                   flow, occl, sigma, packed, s);
+}
+
+extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, const float *fmap1,
+                                const float *fmap2, const float *net, const float *inp, const float *flow_init,
+                                int pad_left, int pad_right, int pad_top, int pad_bottom, float *flow, float *occl,
+                                float *sigma, float *packed, float *flow_lr_out, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+    return refine_impl(r, P, h, w, iters, fmap1, fmap2, net, inp, flow_init, pad_left, pad_right, pad_top, pad_bottom, flow, occl, sigma,
+                       packed, flow_lr_out, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int mftx_raft_refine_gather(mftx_raft *r, int P, int h, int w, int iters, const float *const *fmap1,
+                                       const float *const *fmap2, const float *const *net, const float *const *inp,
+                                       const float *flow_init, int pad_left, int pad_right, int pad_top, int pad_bottom,
+                                       float *flow, float *occl, float *sigma, float *packed, float *flow_lr_out,
+                                       void *workspace, size_t workspace_bytes, void *stream) {
+    if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_refine_gather: bad handle");
+    if (!fmap1 || !fmap2 || !net || !inp) return fail(MFTX_E_ARG, "raft_refine_gather: null pointer");
+    if (P < 1 || P > MFTX_MAX_GATHER) return fail(MFTX_E_ARG, "raft_refine_gather: 1 .. %d pairs", MFTX_MAX_GATHER);
+    if (r->arith != MFTX_ARITH_SPLIT || r->ondemand || r->opt[MFTX_RAFT_OPT_TILE_VOLUME] == 0)
+        return fail(MFTX_E_STATE, "raft_refine_gather: needs the split arithmetic with the stored, tile-resident correlation volume (use mftx_raft_refine)");
+    RefineGather g{};
+    g.f2_shared = true;
+    for (int b = 0; b < P; ++b) {
+        if (!fmap1[b] || !fmap2[b] || !net[b] || !inp[b]) return fail(MFTX_E_ARG, "raft_refine_gather: pair %d has a null map", b);
+        if (!aligned16(fmap1[b]) || !aligned16(fmap2[b]) || !aligned16(net[b]) || !aligned16(inp[b])) return fail(MFTX_E_ALIGN, "raft_refine_gather: maps must be 16-byte aligned");
+        g.f1.p[b] = fmap1[b]; g.f2.p[b] = fmap2[b]; g.net.p[b] = net[b]; g.inp.p[b] = inp[b];
+        if (fmap2[b] != fmap2[0]) g.f2_shared = false;
+    }
+    return refine_impl(r, P, h, w, iters, nullptr, nullptr, nullptr, nullptr, flow_init, pad_left, pad_right, pad_top, pad_bottom, flow, occl,
+                       sigma, packed, flow_lr_out, workspace, workspace_bytes, stream, &g);
 }
 
 extern "C" int mftx_raft_graph_stats(const mftx_raft *r, unsigned long long *captures, unsigned long long *replays) {

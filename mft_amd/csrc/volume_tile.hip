@@ -38,6 +38,9 @@ struct VolTileArgs {
     float scale;
     int qchunks, blocks_per_chunk;      // query blocks (of 32) per workgroup
     int ablate;                         // tuning builds only (MFTX_VT_ABLATE): 1 no level-0 stores, 2 no pooled stores, 4 no MFMAs
+    int gathered;                       // pair bz's queries at f1p.p[bz] (mftx_raft_refine_gather)
+    long long f2_bstride;               // floats between the pairs' target maps in f2s (0: shared)
+    PairPtrs f1p;
 };
 
 __device__ __forceinline__ vt_f32x16 vt_mfma(const vt_f16x8 &a, const vt_f16x8 &b, const vt_f32x16 &c) {
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void volume_tile_kernel(VolTileArgs p) {
 
     // ---- the super-block's 128 target rows -> LDS: row m = 32 j + 8 y + x is cell (y, x) of block j = (block row, block column) of the 2 x 2
     {
-        const float *f2p = p.f2s + (long long)bz * p.N * VT_C;
+        const float *f2p = p.f2s + (long long)bz * p.f2_bstride;
 #pragma unroll 4
         for (int k = 0; k < 16; ++k) {
             const int q = k * 512 + tid, m = q >> 6, pc = q & 63;
@@ -130,9 +133,10 @@ __global__ __launch_bounds__(512, 2) void volume_tile_kernel(VolTileArgs p) {
     const int l3_src = 4 * ((lane + 16) & 63);
     constexpr int PF = 3;
     vt_f32x4 raw[PF][2];
+    const float *f1base = p.gathered ? p.f1p.p[bz] : p.f1 + qbase * VT_C;
     auto row_of = [&](int qb) {
         const int q = qb * 32 + (lane & 31);
-        return p.f1 + (qbase + (q < p.N ? q : p.N - 1)) * VT_C + 8 * hf;       // (rows past the last query: any row, nothing of them is stored)
+        return f1base + (long long)(q < p.N ? q : p.N - 1) * VT_C + 8 * hf;       // (rows past the last query: any row, nothing of them is stored)
     };
     auto prefetch = [&](const float *src) {
 #pragma unroll
@@ -260,13 +264,17 @@ static int vt_num_cus() {
 bool volume_tile_applicable(int C) { return C == VT_C; }
 
 // f1: raw fp32 features [P][N][256]; f2s: the split form of f2 (launch_split_weights); lvl: the pyramid layout of common.h
-int launch_volume_tile(const float *f1, const float *f2s, int P, int h, int w, float *const lvl[4], hipStream_t s) {
+int launch_volume_tile(const float *f1, const float *f2s, int P, int h, int w, float *const lvl[4], hipStream_t s, const PairPtrs *f1p, long long f2_bstride) {
+    if (f1p && P > MFTX_MAX_GATHER) return fail(MFTX_E_ARG, "corr_pyramid: at most %d gathered pairs", MFTX_MAX_GATHER);
     const PyramidLayout L = pyramid_layout(h, w);
     VolTileArgs a{};
     a.f1 = f1; a.f2s = f2s; a.lvl0 = lvl[0]; a.lvl1 = lvl[1]; a.lvl2 = lvl[2]; a.lvl3 = lvl[3];
     a.s0 = L.stride[0]; a.s1 = L.stride[1]; a.s2 = L.stride[2]; a.s3 = L.stride[3];
     a.P = P; a.N = h * w; a.h = h; a.w = w; a.sbw = L.sbw; a.n_sb = L.sbh * L.sbw; a.wb0 = L.wb[0];
     a.scale = 1.0f / sqrtf((float)VT_C);
+    a.gathered = f1p ? 1 : 0;
+    if (f1p) a.f1p = *f1p;
+    a.f2_bstride = f2_bstride >= 0 ? f2_bstride : (long long)a.N * VT_C;
     // One workgroup per (pair, super-block) walks over ALL query blocks when those workgroups fill at least 3/4 of the CUs (7
     // pairs of 64 x 64 cells: 224; measured 372 us against 397 with three query chunks each); smaller problems split the queries
     // into chunks, at least one query block per wave each, to put ~one workgroup on every CU.

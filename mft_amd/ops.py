@@ -714,7 +714,9 @@ class RaftEngine:
             check(lib.mftx_raft_set_flow_head(self._h, self.wproj.data_ptr()), "mftx_raft_set_flow_head")
         elif self.arith != ARITH_F32:
             raise MftxError(f"unknown arithmetic {arith!r}")
-        for k, v in (options or {}).items():
+        options = dict(options or {})
+        self._gather = bool(options.pop("gather", 1))     # (Python-side: per-pair map lists instead of stacked batch tensors, A/B)
+        for k, v in options.items():
             self.set_option(k, v)
         self.ondemand_corr = bool(ondemand_corr)
         if self.ondemand_corr:                 # raft_params.alternate_corr: no stored correlation volume
@@ -764,6 +766,8 @@ class RaftEngine:
 
     def set_option(self, name, value):
         check(_lib.load().mftx_raft_set_option(self._h, self.OPTIONS[name], int(value)), "mftx_raft_set_option")
+        if name == "tile_volume":
+            self._tile_volume = int(value)
 
     def workspace(self, P, h, w):
         need = _lib.load().mftx_raft_workspace_bytes_for(self._h, P, h, w)
@@ -790,6 +794,14 @@ class RaftEngine:
             return unsplit_activations(raw)[:, :cols]
         return self._ws[off: off + 4 * M * cols].view(torch.float32).reshape(M, cols)
 
+    MAX_GATHER = 16
+
+    def can_gather(self, P):
+        """``refine`` accepts LISTS of per-pair maps (no stacking into batch tensors) -- the split arithmetic with the
+        stored, tile-resident correlation volume, up to 16 pairs."""
+        return (self.arith == ARITH_SPLIT and not self.ondemand_corr and P <= self.MAX_GATHER and
+                getattr(self, "_tile_volume", 1) != 0 and getattr(self, "_gather", True))
+
     def refine(self, fmap1, fmap2, net, inp, h, w, iters, pads=(0, 0, 0, 0), want_flow_lr=False, flow_init=None,
                packed=None, planar=True):
         """fmap1/fmap2 [P, h*w, 256], net/inp [P, h*w, 128] pixel-major ->
@@ -798,7 +810,8 @@ class RaftEngine:
         packed: optional pre-allocated [P,H0,W0,4] that also receives (fx, fy, occl, sigma) per pixel;
         planar=False (with packed): only the packed result is written, flow = occl = sigma = None."""
         lib = _lib.load()
-        P = fmap1.shape[0]
+        gathered = isinstance(fmap1, (list, tuple))      # per-pair maps [h*w, 256] / [h*w, 128] (mftx_raft_refine_gather)
+        P = len(fmap1) if gathered else fmap1.shape[0]
         pl, pr, pt, pb = pads
         H0, W0 = 8 * h - pt - pb, 8 * w - pl - pr
         dev = self.device
@@ -813,6 +826,19 @@ class RaftEngine:
         if packed is not None and tuple(packed.shape) != (P, H0, W0, 4):
             raise MftxError("packed must be [P, H0, W0, 4]")
         ws = self.workspace(P, h, w)
+        if gathered:
+            if not self.can_gather(P) or not (len(fmap2) == len(net) == len(inp) == P):
+                raise MftxError("refine: per-pair map lists need the split arithmetic with the tile-resident volume and P <= 16")
+            arrs = [_lib.ptr_array([_chk(t, "map") for t in lst]) for lst in (fmap1, fmap2, net, inp)]
+            check(lib.mftx_raft_refine_gather(self._h, P, h, w, iters, arrs[0][0], arrs[1][0], arrs[2][0], arrs[3][0],
+                                              _chk(flow_init, "flow_init") if flow_init is not None else None,
+                                              pl, pr, pt, pb,
+                                              flow.data_ptr() if planar else None, occl.data_ptr() if planar else None,
+                                              sigma.data_ptr() if planar else None,
+                                              _chk(packed, "packed") if packed is not None else None,
+                                              flow_lr.data_ptr() if want_flow_lr else None,
+                                              ws.data_ptr(), ws.numel(), _stream()), "mftx_raft_refine_gather")
+            return (flow, occl, sigma, flow_lr) if want_flow_lr else (flow, occl, sigma)
         check(lib.mftx_raft_refine(self._h, P, h, w, iters, _chk(fmap1, "fmap1"), _chk(fmap2, "fmap2"),
                                    _chk(net, "net"), _chk(inp, "inp"),
                                    _chk(flow_init, "flow_init") if flow_init is not None else None,

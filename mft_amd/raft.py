@@ -247,16 +247,21 @@ class RAFTWrapper:
         for f in fls + frs:
             if f.shape != ref.shape:
                 raise ValueError("all frames of a batch must have the same size")
-        fmap1 = torch.stack([f.fmap for f in fls])
-        fmap2 = torch.stack([f.fmap for f in frs])
-        net = torch.stack([f.net for f in fls])
-        inp = torch.stack([f.inp for f in fls])
+        P = len(pairs)
+        gather = self.engine.can_gather(P) and not (self._split_streams > 1 and P >= 6 and init_flow is None)
+        if gather:      # the engine takes the pairs' cached maps where they lie: no batch tensors, a shared right frame split once
+            fmap1, fmap2 = [f.fmap for f in fls], [f.fmap for f in frs]
+            net, inp = [f.net for f in fls], [f.inp for f in fls]
+        else:
+            fmap1 = torch.stack([f.fmap for f in fls])
+            fmap2 = torch.stack([f.fmap for f in frs])
+            net = torch.stack([f.net for f in fls])
+            inp = torch.stack([f.inp for f in fls])
         flow_init = None
         if init_flow is not None:
             flow_init = self._init_flow_lr(init_flow, ref)
         packed = None
         H0, W0 = ref.shape
-        P = len(pairs)
         if packed_out is not None and packed_out is not False:
             packed = packed_out if isinstance(packed_out, torch.Tensor) else \
                 torch.empty(P, H0, W0, 4, dtype=torch.float32, device=self.device)

@@ -1178,6 +1178,31 @@ def test_engine_deferred_flow_head_update_bitwise():
     assert np.array_equal(merged, own)
 
 
+def test_engine_refine_gather_bitwise():
+    """mftx_raft_refine_gather -- the pairs' maps through per-pair pointers, a shared second map split once -- against
+    mftx_raft_refine on the stacked maps: the same kernels on the same values, the same bits (shared and distinct right
+    frames); and its refusals."""
+    from mft_amd import ops
+    from mft_amd.weights import make_weights
+    sd = {k: torch.from_numpy(v).cuda() for k, v in make_weights(7).items()}
+    eng = ops.RaftEngine(sd, "cuda")
+    g = torch.Generator().manual_seed(11)
+    P, h, w = 3, 24, 40
+    f1 = [torch.randn(h * w, 256, generator=g).cuda() for _ in range(P)]
+    f2 = [(f1[0].cpu() + 0.3 * torch.randn(h * w, 256, generator=g)).cuda() for _ in range(P)]
+    net = [torch.tanh(torch.randn(h * w, 128, generator=g)).cuda() for _ in range(P)]
+    inp = [torch.relu(torch.randn(h * w, 128, generator=g)).cuda() for _ in range(P)]
+    for rights in (f2, [f2[0]] * P):
+        a = eng.refine(torch.stack(f1), torch.stack(rights), torch.stack(net), torch.stack(inp), h, w, 3)
+        b = eng.refine(f1, rights, net, inp, h, w, 3)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    eng.set_option("tile_volume", 0)
+    assert not eng.can_gather(P)
+    with pytest.raises(ops.MftxError):
+        eng.refine(f1, f2, net, inp, h, w, 3)
+
+
 def _tile_layers(arith, tile, ref=False):
     """A few conv GEMMs with the tile shape forced (mftx_conv2d_tile), outputs concatenated."""
     from mft_amd import ops
