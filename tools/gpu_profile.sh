@@ -16,7 +16,7 @@ $BENCH > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 # A/B of the round's structural changes, same box, same run (results do not depend on any of them beyond fp32 rounding)
 $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-graphs > $OUT/bench_no_graphs.json 2>/dev/null; echo "bench no-graphs rc=$?"
 $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-fused-lookup > $OUT/bench_no_fused_lookup.json 2>/dev/null; echo "bench no-fused-lookup rc=$?"
-(for o in "" "fuse_head=0" "tile_conv=0" "fuse_flow=0" "fuse_lookup=0" "fuse_head=0 tile_conv=0 fuse_flow=0" "fuse_head=0 tile_conv=0 fuse_flow=0 fuse_lookup=0 graph=0"; do
+(for o in "" "gather=0" "fuse_head=2" "fuse_head=0" "tile_volume=0" "tile_conv=0" "fuse_flow=0" "fuse_lookup=0" "fuse_head=0 tile_conv=0 fuse_flow=0" "gather=0 tile_volume=0 fuse_head=0 tile_conv=0 fuse_flow=0 fuse_lookup=0 graph=0"; do
    args=""; for kv in $o; do args="$args --engine-opt $kv"; done
    for rep in 1 2; do $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-host-io $args 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('engine options [$o]:', round(d['value'],1), 'frames/s, host', round(d['host_enqueue_ms_per_step'],2), 'ms per frame, conv GEMM', round(d['roofline']['frac'],3), 'of the fp16 MFMA peak')"; done
  done) > $OUT/engine_options_ab.txt
