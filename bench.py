@@ -102,7 +102,9 @@ def build_tracker(args, sharded):
     if getattr(args, "no_fused_lookup", False):
         opts["fuse_lookup"] = 0               # lookup and convc1 as two kernels (A/B)
     for kv in getattr(args, "engine_opt", None) or []:
-        k, _, v = kv.partition("=")
+        k, sep, v = kv.partition("=")
+        if not sep or not v.lstrip("-").isdigit():
+            raise SystemExit(f"--engine-opt {kv!r}: expected NAME=INT")
         opts[k] = int(v)                      # A/B of a scheduling option of the refinement engine (mft_amd.ops.RaftEngine.OPTIONS)
     if opts:
         conf.flow_config.raft_params.engine_options = opts

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MFTX_VERSION 305
+#define MFTX_VERSION 400
 
 #define MFTX_E_ARG (-1)      /* null pointer / non-positive size / unsupported shape */
 #define MFTX_E_ALIGN (-2)    /* pointer or leading dimension not 16-byte aligned */
@@ -186,6 +186,11 @@ int mftx_conv2d_tile(const mftx_conv_desc *d, int tile, void *stream);
  * mftx_conv2d packing wpk = [>= N rows][taps][cin_pad] fp32.  d->wpk is ignored. */
 int mftx_pack_tile_conv_weights(const float *wpk, int N, int taps, int cin, int cin_pad, void *wtile, void *stream);
 int mftx_tile_conv2d(const mftx_conv_desc *d, const void *wtile, void *stream);
+/* 1 when the tile-resident kernels' tiles of 128 cells fill the current device for a batch of P pairs of h x w cells (rounds of the
+ * chip at least 5/8 full, all three tile shapes) -- the rule MFTX_RAFT_OPT_TILE_CONV = 1 applies per call.  A caller that
+ * needs a pair's result to be independent of the batch it is computed in (a tracker whose batches ramp up, ranks of a
+ * sharded job) asks ONCE, for its nominal batch, and pins the option to 2 or 0 (mft_amd/raft.py does). */
+int mftx_tile_conv_fills_chip(int P, int h, int w);
 /* The flow head (core/update.py:6-14: delta = conv2(relu(conv1(h))), 3 x 3, 128 -> 256 -> 2) without materialising the 256
  * hidden channels: the tile-resident kernel keeps relu(conv1) of a tile in LDS and multiplies it there with conv2's filter
  * as a [256 x 18] matrix -- T[m][2 tap + o], the partial product of cell m for tap and output o -- and a second small
@@ -279,6 +284,15 @@ int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
 #define MFTX_RAFT_OPT_FUSE_HEAD 7
 #define MFTX_RAFT_OPT_TILE_VOLUME 8
 int mftx_raft_set_option(mftx_raft *r, int option, int value);
+/* A device-resident counter (4 bytes, zeroed by the caller) that the last kernel of every mftx_raft_refine* call increments
+ * by the number of output pixels with a non-finite flow / occlusion / sigma; null switches it off.  The reference has no
+ * such check (MFT/MFT.py:96-107 stores whatever the network returned): with the split arithmetic an activation beyond
+ * the fp16 range surfaces as NaN by design (DESIGN.md "Range of the split arithmetic"), and a tracker must not chain
+ * through it unnoticed.  No host synchronisation: the caller reads the counter whenever it synchronises anyway. */
+int mftx_raft_set_nonfinite_counter(mftx_raft *r, unsigned *counter);
+/* Drop every captured graph of the handle (after draining the streams they were launched on).  Graphs are keyed by the
+ * workspace address: call it before freeing or replacing a workspace the handle has been run with. */
+int mftx_raft_clear_graphs(mftx_raft *r);
 /* graphs captured / graph launches so far (tests, bench) */
 int mftx_raft_graph_stats(const mftx_raft *r, unsigned long long *captures, unsigned long long *replays);
 size_t mftx_raft_workspace_bytes_for(const mftx_raft *r, int P, int h, int w);

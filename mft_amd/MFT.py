@@ -88,6 +88,8 @@ class MFT():
         self.flow_cache = flow_cache
         if hasattr(self.flower, "reset_cache"):
             self.flower.reset_cache()
+        if hasattr(self.flower, "set_nominal_pairs"):      # kernel choices are made for the steady-state batch, not per call
+            self.flower.set_nominal_pairs(len(set(self.C.deltas)) if self.C.deltas else 1)
         # a private copy: the caller may recycle its buffer (a pinned staging ring, mft_amd/video.py: FrameRing), and the
         # template stays in memory for the whole sequence when inf is among the deltas
         self.template_img = img.copy() if hasattr(img, "copy") else img.clone()
@@ -185,9 +187,29 @@ class MFT():
             meta.result = result.clone()       # a copy: the consumer may move it in place (meta.result.cpu())
         else:
             meta.result = result.clone().cpu()
+        self._check_nonfinite(synced=not self.C.keep_result_on_device)
         self.memory[frame_i] = {'img': input_img, 'result': result}
         self.cleanup_memory()
         return meta
+
+    def _check_nonfinite(self, synced):
+        """The flow plugin counts non-finite output pixels on the device (mftx_raft_set_nonfinite_counter).  The count is read --
+        and a FloatingPointError raised -- where the host has synchronised anyway (the result just went to the CPU), otherwise
+        every C.nonfinite_check_every frames (default 32; 0: never -- ResultDrain.collect / check_nonfinite() remain): a NaN
+        must not travel through tracker.memory unnoticed (the reference has no such guard: MFT/MFT.py:96-143)."""
+        if not hasattr(self.flower, "raise_if_nonfinite"):
+            return
+        every = self.C.nonfinite_check_every
+        every = int(every) if isinstance(every, (int, float)) else 32          # (an unset Config attribute is a falsy Config)
+        self._frames_unchecked = getattr(self, "_frames_unchecked", 0) + 1
+        if synced or (every > 0 and self._frames_unchecked >= every):
+            self._frames_unchecked = 0
+            self.flower.raise_if_nonfinite()
+
+    def check_nonfinite(self):
+        """Read the device-side non-finite counter now (synchronises) and raise FloatingPointError if it is not zero."""
+        if hasattr(self.flower, "raise_if_nonfinite"):
+            self.flower.raise_if_nonfinite()
 
     def _flows_for_pairs(self, pairs, packed_out=None, planar=True):
         """[(left_id, left_img, right_id, right_img)] -> [(flow, occl, sigma[, packed])], one batched engine

@@ -66,6 +66,9 @@ SIGNATURES = {
                                    C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "mftx_raft_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mftx_raft_set_coords_trace": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mftx_tile_conv_fills_chip": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "mftx_raft_clear_graphs": (C.c_int, [C.c_void_p]),
+    "mftx_raft_set_nonfinite_counter": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mftx_raft_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     "mftx_pack_lookup_convc1_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mftx_corr_lookup_convc1": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p, C.c_void_p,

@@ -184,6 +184,6 @@ int launch_corr_ondemand(const float *f1, const float *const f2lvl[4], const flo
                          float *out, int ld_out, hipStream_t s);
 int launch_convex_upsample(const float *flow_lr, const float *ou, int ld_ou, const float *mask,
                            int P, int h, int w, int pl, int pr, int pt, int pb,
-                           float *flow, float *occl, float *sigma, float *packed, hipStream_t s);
+                           float *flow, float *occl, float *sigma, float *packed, hipStream_t s, unsigned *nonfinite = nullptr);
 
 }  // namespace mftx

@@ -50,7 +50,12 @@ public:
 };
 
 class GraphCache {
-    struct Entry { GraphKey k; hipGraph_t g; hipGraphExec_t x; unsigned long long stamp; };
+    struct Entry { GraphKey k; hipGraph_t g; hipGraphExec_t x; unsigned long long stamp; hipStream_t last; };
+    // an executable graph is destroyed only after the stream it was last launched on has drained: a replay may still be in flight
+    static void destroy(Entry &e) {
+        if (e.last) (void)hipStreamSynchronize(e.last);
+        (void)hipGraphExecDestroy(e.x); (void)hipGraphDestroy(e.g);
+    }
     std::vector<Entry> entries_;
     std::vector<GraphKey> seen_, refused_;
     unsigned long long clock_ = 0;
@@ -66,7 +71,7 @@ public:
 
     ~GraphCache() { clear(); }
     void clear() {
-        for (auto &e : entries_) { (void)hipGraphExecDestroy(e.x); (void)hipGraphDestroy(e.g); }
+        for (auto &e : entries_) destroy(e);
         entries_.clear(); seen_.clear(); refused_.clear();
     }
 
@@ -79,6 +84,7 @@ public:
         for (auto &e : entries_)
             if (e.k == k) {
                 e.stamp = ++clock_;
+                e.last = s;
                 ++replays;
                 const hipError_t err = hipGraphLaunch(e.x, s);
                 return err == hipSuccess ? 0 : fail((int)err, "hipGraphLaunch: %s", hipGetErrorString(err));
@@ -112,10 +118,10 @@ public:
         if (entries_.size() >= MAX_ENTRIES) {                       // drop the least recently used
             size_t old = 0;
             for (size_t i = 1; i < entries_.size(); ++i) if (entries_[i].stamp < entries_[old].stamp) old = i;
-            (void)hipGraphExecDestroy(entries_[old].x); (void)hipGraphDestroy(entries_[old].g);
+            destroy(entries_[old]);
             entries_.erase(entries_.begin() + (long)old);
         }
-        entries_.push_back(Entry{k, g, x, ++clock_});
+        entries_.push_back(Entry{k, g, x, ++clock_, s});
         ++captures;
         err = hipGraphLaunch(x, s);
         return err == hipSuccess ? 0 : fail((int)err, "hipGraphLaunch: %s", hipGetErrorString(err));

@@ -193,6 +193,7 @@ struct mftx_raft {
     const void *wproj;             // the flow head's last layer as the projection epilogue of its first (csrc/tile_conv.hip: TC_RELU_PROJ), or null
     const void *wt[W_COUNT];       // weight streams of the tile-resident conv kernel (csrc/tile_conv.hip) per slot, or null
     int opt[9];                    // MFTX_RAFT_OPT_*
+    unsigned *nonfinite;           // device counter of non-finite output pixels (mftx_raft_set_nonfinite_counter), or null
 };
 // weights that go through the conv GEMM (the others feed VALU kernels and stay fp32)
 static constexpr int GEMM_SLOTS[] = {W_CONVC1, W_CONVC2, W_CONVF2, W_CONV, W_ZR1_DYN, W_ZR1_INP, W_Q1_DYN, W_Q1_INP,
@@ -217,6 +218,7 @@ extern "C" int mftx_raft_create(const float *const *weights, int n_weights, mftx
     r->wproj = nullptr;
     for (int i = 0; i < W_COUNT; ++i) r->wt[i] = nullptr;
     r->coords_trace = nullptr;
+    r->nonfinite = nullptr;
     r->graphs = new (std::nothrow) GraphCache;
     r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1; r->opt[MFTX_RAFT_OPT_FUSE_FLOW] = 1; r->opt[MFTX_RAFT_OPT_TILE_CONV] = 1; r->opt[MFTX_RAFT_OPT_FUSE_HEAD] = 1; r->opt[MFTX_RAFT_OPT_TILE_VOLUME] = 1;
     for (int i = 0; i < W_COUNT; ++i) r->w[i] = r->wg[i] = weights[i];
@@ -313,6 +315,20 @@ extern "C" int mftx_raft_set_flow_head(mftx_raft *r, const void *wproj) {
 extern "C" int mftx_raft_set_coords_trace(mftx_raft *r, float *trace) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_coords_trace: bad handle");
     r->coords_trace = trace;
+    return 0;
+}
+
+// graphs are keyed by workspace address: a caller that frees or replaces a workspace drops the graphs captured on it
+extern "C" int mftx_raft_clear_graphs(mftx_raft *r) {
+    if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_clear_graphs: bad handle");
+    if (r->graphs) r->graphs->clear();
+    return 0;
+}
+
+extern "C" int mftx_raft_set_nonfinite_counter(mftx_raft *r, unsigned *counter) {
+    if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_nonfinite_counter: bad handle");
+    if (counter && (reinterpret_cast<uintptr_t>(counter) & 3)) return fail(MFTX_E_ALIGN, "raft_set_nonfinite_counter: counter not 4-byte aligned");
+    r->nonfinite = counter;        // (read by the last kernel of a refinement, which is not part of the captured graph)
     return 0;
 }
 
@@ -492,9 +508,9 @@ static int refine_impl(mftx_raft *r, int P, int h, int w, int iters, const float
         // correlation branch and joins in front of `conv` -- 3.67 -> 3.45 ms at one pair, 5.94 -> 5.59 at four
         // (tools/bench_pairs.py).  At seven pairs this used to lose (every kernel filled the chip: 106.7 vs 111.5 frames/s);
         // since convc2 runs as 224 workgroups of the 128 x 192 tile, 32 CUs are free beside it and its 1 x 1 predecessor
-        // for the flow branch's small kernels: 129.2 -> 130.3 frames/s (MFTX_RAFT_FORK=0: in order on one stream, with
+        // for the flow branch's small kernels: 129.2 -> 130.3 frames/s (MFTX_RAFT_OPT_FORK = 0: in order on one stream, with
         // lookup + convf1 as one launch).  fp32 MFMA keeps round 1's grouping (lookup + convf1 in one launch,
-        // convc2 + convf2 in one launch).  The per-kernel timing pass and MFTX_RAFT_NOFUSE run everything in order.
+        // convc2 + convf2 in one launch).  The per-kernel timing pass and MFTX_RAFT_OPT_GROUP = 0 run everything in order.
         const ConvF1Args f1{ccur, W[W_CONVF1], W[B_CONVF1], ws.flo1, ws.hx, h, w, strips, P * h * strips, SP ? 1 : 0};
         const int f1_blocks = cdiv(f1.n_strips, 2);
         const bool nofuse = r->opt[MFTX_RAFT_OPT_GROUP] == 0, nopair = nofuse;
@@ -530,7 +546,7 @@ static int refine_impl(mftx_raft *r, int P, int h, int w, int iters, const float
             if (hipEventRecord(r->ev_join, r->side) != hipSuccess) return fail(MFTX_E_STATE, "raft_refine: join event failed");
         }
         // lookup + convf1 as ONE launch (HBM gathers beside VALU work) whenever the flow branch is not on the side stream:
-        // 113.7 vs 113.2 frames/s with the split arithmetic; the timing pass and MFTX_RAFT_NOFUSE keep them apart
+        // 113.7 vs 113.2 frames/s with the split arithmetic; the timing pass and MFTX_RAFT_OPT_GROUP = 0 keep them apart
         if (fuse_lookup) {
             if (last && !forked) TRY(launch_corr_lookup(lv, ccur, P, h, w, ws.corr, ws.ld_corr, s));
             TRY(launch_lookup_convc1(lv, ccur, P, h, w, r->wfused, W[B_CONVC1], ws.cor1, 256, 1, s));
@@ -652,7 +668,7 @@ static int refine_impl(mftx_raft *r, int P, int h, int w, int iters, const float
         TRY(core());
     }
     return launch_convex_upsample(flow_lr, ws.ou, 4, ws.mask, P, h, w, pad_left, pad_right, pad_top, pad_bottom,
-                                  flow, occl, sigma, packed, s);
+                                  flow, occl, sigma, packed, s, r->nonfinite);
 }
 
 extern "C" int mftx_raft_refine(mftx_raft *r, int P, int h, int w, int iters, const float *fmap1,
@@ -774,6 +790,11 @@ extern "C" int mftx_tile_conv2d(const mftx_conv_desc *d, const void *wtile, void
     t.addend = d->addend; t.ld_addend = d->ld_addend; t.out = d->out; t.ldo = d->ldo; t.out_split = d->out_split;
     t.P = d->P; t.h = d->h; t.w = d->w; t.N = d->N; t.kh = d->kh; t.kw = d->kw; t.epi = d->act;
     return launch_tile_conv(t, (hipStream_t)stream);
+}
+
+extern "C" int mftx_tile_conv_fills_chip(int P, int h, int w) {
+    if (P <= 0 || h <= 0 || w <= 0) return 0;
+    return tile_conv_fills_chip(P, h, w, 3, 3) && tile_conv_fills_chip(P, h, w, 1, 5) && tile_conv_fills_chip(P, h, w, 5, 1) ? 1 : 0;
 }
 
 extern "C" int mftx_pack_flow_head_weights(const float *w2pk, void *wproj, void *stream) {

@@ -40,8 +40,15 @@ enum TcEpi { TC_LINEAR = 0, TC_RELU = 1, TC_GRU_ZR = 2, TC_GRU_Q = 3,
 __device__ unsigned long long tc_trace_buf[8][16];
 #define TC_T(code) do { if (blockIdx.x == 0 && tcount < 16) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
                         if ((threadIdx.x & 63) == 0) tc_trace_buf[threadIdx.x >> 6][tcount] = ((unsigned long long)(code) << 56) | (t_ & 0x00ffffffffffffffull); ++tcount; } } while (0)
+// ... and, for EVERY workgroup, first / last stamps of both clocks: s_memtime counts shader cycles, s_memrealtime the constant
+// 100 MHz reference -- their ratio is the shader clock the workgroup actually ran at (tools/clock_probe.py)
+__device__ unsigned long long tc_clock_buf[4096][4];
+#define TC_CLK(slot) do { if (wv == ((slot) ? 7 : 0) && blockIdx.x < 4096) { unsigned long long t_, r_; \
+                          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_) :: "memory"); \
+                          if (lane == 0) { tc_clock_buf[blockIdx.x][slot] = t_; tc_clock_buf[blockIdx.x][2 + slot] = r_; } } } while (0)
 #else
 #define TC_T(code) do { } while (0)
+#define TC_CLK(slot) do { } while (0)
 #endif
 
 struct TileConvArgs {
@@ -137,6 +144,7 @@ __global__ __launch_bounds__(512, 2) void tile_conv_kernel(TileConvArgs p) {
     int tcount = 0;
 #endif
     TC_T(1);
+    TC_CLK(0);
     // weight fragments of the first steps: in flight while the input tile loads
     constexpr int PF = 3;
     uint4 bq[PF][2];
@@ -292,6 +300,7 @@ __global__ __launch_bounds__(512, 2) void tile_conv_kernel(TileConvArgs p) {
                 p.tout[(img_base + (long long)yy * p.w + xx) * 18 + j] = tp[m * G::PROJ_ROW + j] + tp[(128 + m) * G::PROJ_ROW + j];
         }
         TC_T(8);
+        TC_CLK(1);
         return;
     }
 
@@ -357,9 +366,14 @@ __global__ __launch_bounds__(512, 2) void tile_conv_kernel(TileConvArgs p) {
         }
     }
     TC_T(8);
+    TC_CLK(1);
 }
 
 #ifdef MFTX_LF_TRACE
+extern "C" int mftx_debug_tc_clock(unsigned long long *out, int n_wg) {
+    if (n_wg < 0 || n_wg > 4096) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tc_clock_buf), sizeof(unsigned long long) * 4 * n_wg) == hipSuccess ? 0 : -1;
+}
 extern "C" int mftx_debug_tc_trace(unsigned long long *out) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(tc_trace_buf), sizeof(unsigned long long) * 8 * 16) != hipSuccess) return -1;
     unsigned long long z[8 * 16] = {};

@@ -29,6 +29,7 @@ struct UpArgs {
     int H0, W0;            // unpadded output size
     float *flow, *occl, *sigma;
     float *packed;         // optional [P][H0][W0][4]
+    unsigned *nonfinite;   // optional device counter: += the number of output pixels with a non-finite value (see raft_engine.hip)
     int cells;
 };
 
@@ -93,12 +94,21 @@ __global__ __launch_bounds__(64 * UP_WAVES) void convex_upsample_kernel(UpArgs p
     }
     if (p.packed != nullptr)
         reinterpret_cast<float4 *>(p.packed)[img * plane + pix] = make_float4(fxv, fyv, oc, sg);
+    // A non-finite result (an activation beyond the fp16 range of the split arithmetic reaches the outputs as NaN, by design)
+    // must not enter a tracker's memory unnoticed: counted here, where every output of a refinement passes -- one ballot per
+    // wave, an atomic only when something IS wrong; the host reads the counter when it synchronises anyway.
+    if (p.nonfinite != nullptr) {
+        const bool bad = !(isfinite(fxv) && isfinite(fyv) && isfinite(oc) && isfinite(sg));
+        const unsigned long long b = __ballot(bad);
+        if (b != 0ull && bad && (unsigned)lane == (unsigned)__builtin_ctzll(b)) atomicAdd(p.nonfinite, (unsigned)__builtin_popcountll(b));
+    }
 }
 
 int launch_convex_upsample(const float *flow_lr, const float *ou, int ld_ou, const float *mask, int P, int h,
                            int w, int pl, int pr, int pt, int pb, float *flow, float *occl, float *sigma,
-                           float *packed, hipStream_t s) {
+                           float *packed, hipStream_t s, unsigned *nonfinite) {
     UpArgs a;
+    a.nonfinite = nonfinite;
     a.flow_lr = flow_lr; a.ou = ou; a.ld_ou = ld_ou; a.mask = mask;
     a.P = P; a.h = h; a.w = w; a.pl = pl; a.pt = pt;
     a.H0 = 8 * h - pt - pb; a.W0 = 8 * w - pl - pr;

@@ -714,6 +714,10 @@ class RaftEngine:
             check(lib.mftx_raft_set_flow_head(self._h, self.wproj.data_ptr()), "mftx_raft_set_flow_head")
         elif self.arith != ARITH_F32:
             raise MftxError(f"unknown arithmetic {arith!r}")
+        # device-side count of non-finite output pixels, incremented by the last kernel of every refinement (no host sync;
+        # read by nonfinite_count() when the caller synchronises anyway)
+        self._nonfinite = torch.zeros(1, dtype=torch.int32, device=self.device)
+        check(lib.mftx_raft_set_nonfinite_counter(self._h, self._nonfinite.data_ptr()), "mftx_raft_set_nonfinite_counter")
         options = dict(options or {})
         self._gather = bool(options.pop("gather", 1))     # (Python-side: per-pair map lists instead of stacked batch tensors, A/B)
         for k, v in options.items():
@@ -764,14 +768,27 @@ class RaftEngine:
         check(_lib.load().mftx_raft_graph_stats(self._h, C.byref(c), C.byref(r)), "mftx_raft_graph_stats")
         return int(c.value), int(r.value)
 
+    def nonfinite_count(self, reset=False):
+        """Output pixels with a non-finite flow / occlusion / sigma since the last reset (one 4-byte read: synchronises)."""
+        n = int(self._nonfinite.item())
+        if reset and n:
+            self._nonfinite.zero_()
+        return n
+
     def set_option(self, name, value):
+        if name not in self.OPTIONS:
+            raise MftxError(f"unknown engine option {name!r} (known: {', '.join(sorted(self.OPTIONS))}, gather)")
         check(_lib.load().mftx_raft_set_option(self._h, self.OPTIONS[name], int(value)), "mftx_raft_set_option")
+        if name == "tile_conv":
+            self._tile_conv = int(value)
         if name == "tile_volume":
             self._tile_volume = int(value)
 
     def workspace(self, P, h, w):
         need = _lib.load().mftx_raft_workspace_bytes_for(self._h, P, h, w)
         if self._ws is None or self._ws.numel() < need:
+            if self._ws is not None:      # graphs captured on the old buffer would keep pointing into freed memory
+                check(_lib.load().mftx_raft_clear_graphs(self._h), "mftx_raft_clear_graphs")
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 

@@ -77,6 +77,8 @@ class RAFTWrapper:
             self._arith = ops.ARITH_F32
             self._build_engines()
         self._check_finite = bool(getattr(getattr(config, "raft_params", None), "check_finite", False))
+        # ... and whatever check_finite says, every refinement COUNTS its non-finite output pixels on the device (no host sync;
+        # csrc/upsample.hip): raise_if_nonfinite() is called by the tracker whenever it synchronises anyway
         # C.split_streams (env MFTX_SPLIT_STREAMS overrides): batches of >= 6 pairs run as that many parts on
         # separate HIP streams (see _refine_split); 1 = one stream.  Measured at 7 pairs, 512 x 512
         # (profiles/r2_split_streams.txt): 1 / 2 / 3 / 4 / 7 parts = 63.0 / 64.9 / 59.4 / 60.6 / 49.8 frames/s with fp32 MFMA
@@ -85,6 +87,13 @@ class RAFTWrapper:
         self._split_streams = int(os.environ.get("MFTX_SPLIT_STREAMS", "") or getattr(config, "split_streams", 0) or
                                   (1 if self._arith == ops.ARITH_SPLIT else 2))
         self._engines, self._side = [], []            # part k: engine (own workspace) and stream (None = caller's)
+        # Which GEMM kernels a refinement runs on (tile-resident or ring-buffered: they differ by fp32 rounding of the K sums) must
+        # not depend on the batch a pair happens to ride in -- a tracker's ramp-up frames, a remainder window or one rank's share
+        # of a sharded job would then give other bits than the full batch.  The choice is made ONCE per image size, for the
+        # NOMINAL batch (the tracker's delta count; MFT.init sets it), and pinned on every engine of this plugin
+        # (mftx_tile_conv_fills_chip; an explicit engine_options["tile_conv"] wins).
+        self.nominal_pairs = int(getattr(config, "nominal_pairs", 0) or 7)
+        self._tile_choice = {}
         self._frames = {}
         # Optional (C.async_encode): encode new frames on a side stream.  The encoders of frame t
         # only need the image, so with results kept on the device (no per-frame host sync) their
@@ -98,6 +107,35 @@ class RAFTWrapper:
         self.cnet_engine = ops.EncoderEngine(self.sd, "cnet", False, self.device, arith=self._arith, graph=graph)
         self.engine = ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand, arith=self._arith,
                                      options=self._engine_options)
+
+    def set_nominal_pairs(self, n):
+        """The batch size kernel choices are made for (see __init__); changing it re-decides at the next call."""
+        n = max(1, int(n))
+        if n != self.nominal_pairs:
+            self.nominal_pairs = n
+            self._tile_choice = {}
+
+    def _pin_kernels(self, h, w):
+        if self._arith != ops.ARITH_SPLIT or "tile_conv" in self._engine_options:
+            return
+        v = self._tile_choice.get((h, w))
+        if v is None:
+            v = self._tile_choice[(h, w)] = 2 if ops._lib.load().mftx_tile_conv_fills_chip(self.nominal_pairs, h, w) else 0
+        for e in dict.fromkeys([self.engine] + list(self._engines)):
+            if getattr(e, "_tile_conv", None) != v:
+                e.set_option("tile_conv", v)
+
+    def nonfinite_count(self, reset=False):
+        """Non-finite output pixels counted on the device since the last reset, over all engines of this plugin."""
+        return sum(e.nonfinite_count(reset=reset) for e in dict.fromkeys([self.engine] + list(self._engines)))
+
+    def raise_if_nonfinite(self):
+        bad = self.nonfinite_count(reset=True)
+        if bad:
+            raise FloatingPointError(
+                f"flow network: {bad} output pixels with a non-finite flow / occlusion / sigma" + (
+                    " -- an activation left the fp16 range of the split arithmetic (|x| >= 65504); "
+                    "set raft_params.arith = 'fp32'" if self._arith == ops.ARITH_SPLIT else ""))
 
     @property
     def arith(self):
@@ -266,6 +304,7 @@ class RAFTWrapper:
             packed = packed_out if isinstance(packed_out, torch.Tensor) else \
                 torch.empty(P, H0, W0, 4, dtype=torch.float32, device=self.device)
         want_planar = planar or packed is None
+        self._pin_kernels(ref.h, ref.w)
         if self._split_streams > 1 and P >= 6 and flow_init is None:
             flow, occl, sigma = self._refine_split(fmap1, fmap2, net, inp, ref, iters, packed, want_planar)
         else:
@@ -299,6 +338,7 @@ class RAFTWrapper:
             # part 0 runs on the calling stream, the others on side streams (HIP multiplexes streams onto a handful
             # of hardware queues: every stream saved keeps the copy / encoder streams on queues of their own)
             self._side.append(torch.cuda.Stream(device=self.device) if self._side or len(self._engines) > 1 else None)
+        self._pin_kernels(geom.h, geom.w)             # the parts run the kernels the WHOLE batch would
         dev = self.device
         flow = torch.empty(P, 2, H0, W0, dtype=torch.float32, device=dev) if planar else None
         occl = torch.empty(P, 1, H0, W0, dtype=torch.float32, device=dev) if planar else None
@@ -353,6 +393,7 @@ class RAFTWrapper:
             # coordinates of every iteration, on the CPU
             fl, fr = self._features(None, src_img), self._features(None, dst_img)
             flow_init = self._init_flow_lr(init_flow, fl) if init_flow is not None else None
+            self._pin_kernels(fl.h, fl.w)
             (flow, occl, sigma), debug = self.engine.debug_refine(fl.fmap[None], fr.fmap[None], fl.net[None], fl.inp[None],
                                                                    fl.h, fl.w, int(self.C.flow_iters), pads=fl.pads,
                                                                    flow_init=flow_init)

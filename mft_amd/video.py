@@ -181,9 +181,12 @@ class ResultDrain:
     once): a collected result stays valid until ``depth`` more results have been submitted (``copy=True`` returns
     private copies instead)."""
 
-    def __init__(self, device="cuda", depth=4):
+    def __init__(self, device="cuda", depth=4, check=None):
+        """check: optional callable run by every ``collect`` after its wait (e.g. ``tracker.check_nonfinite``: the host has
+        synchronised with the GPU there anyway, so reading the device-side non-finite counter costs nothing extra)."""
         self.device = torch.device(device)
         self.depth = depth
+        self.check = check
         self._sets, self._queue, self._n = [], [], 0
 
     def prepare(self, result):
@@ -206,7 +209,11 @@ class ResultDrain:
         for h, t in zip(host, planes):
             # a copy KERNEL on the caller's stream, not hipMemcpyAsync: a pinned download in the SDMA queue holds back the
             # pinned uploads submitted behind it until the compute it waits for is done (profiles/r2_io_paths.txt)
-            ops.copy_bytes(t.contiguous(), h)
+            t = t.contiguous()
+            if (t.is_cuda or t.is_pinned()) and t.data_ptr() % 16 == 0 and h.data_ptr() % 16 == 0:
+                ops.copy_bytes(t, h)
+            else:       # pageable host results (keep_result_on_device = False) or a plane view off the 16-byte grid: torch's copy
+                h.copy_(t, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         self._queue.append((ev, host))
@@ -215,6 +222,8 @@ class ResultDrain:
     def collect(self, copy=False):
         ev, host = self._queue.pop(0)
         ev.synchronize()
+        if self.check is not None:
+            self.check()
         return tuple(torch.from_numpy(h.numpy().copy()) for h in host) if copy else tuple(host)      # (numpy: a plain memcpy, see FrameRing)
 
     def __len__(self):

@@ -39,7 +39,7 @@ def test_library_exports_every_header_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mftx_version() == 305
+    assert lib.mftx_version() == 400
     assert lib.mftx_raft_workspace_bytes(7, 64, 64) > 7 * 4096 * 4096 * 4
     assert lib.mftx_raft_workspace_bytes(0, 64, 64) == 0
 

@@ -40,6 +40,9 @@ def main():
     fc.async_encode = False
     fc.split_streams = 1          # one batch on one stream: per-kernel event times must not overlap
     if a.engine_opt:
+        for kv in a.engine_opt:
+            if "=" not in kv or not kv.partition("=")[2].lstrip("-").isdigit():
+                ap.error(f"--engine-opt {kv!r}: expected NAME=INT")
         fc.raft_params.engine_options = {kv.partition("=")[0]: int(kv.partition("=")[2]) for kv in a.engine_opt}
     flower = fc.of_class(fc)
     vid = SyntheticVideo(a.size, a.size, n_frames=8, seed=0)
