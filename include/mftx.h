@@ -186,6 +186,17 @@ int mftx_conv2d_tile(const mftx_conv_desc *d, int tile, void *stream);
  * mftx_conv2d packing wpk = [>= N rows][taps][cin_pad] fp32.  d->wpk is ignored. */
 int mftx_pack_tile_conv_weights(const float *wpk, int N, int taps, int cin, int cin_pad, void *wtile, void *stream);
 int mftx_tile_conv2d(const mftx_conv_desc *d, const void *wtile, void *stream);
+/* One pass of the SepConvGRU (core/update.py:108-123; pass 0: the 1 x 5 convolutions, pass 1: the 5 x 1 ones) as ONE kernel:
+ *     z | r = sigmoid(conv_zr([h | motion]) + pre_zr),  q = tanh(conv_q([r * h | motion]) + pre_q),  h <- (1 - z) h + z q
+ * with the tile's [h | motion] loaded into LDS once and r * h formed there in place (csrc/tile_conv.hip: gru_half_kernel).  The
+ * context features' share of every gate sum and the biases arrive as pre-activation addends (they do not change over the
+ * iterations: core/raft.py:146-149).  h_in / motion: split form, 128 channels each; wzr / wq: mftx_pack_tile_conv_weights
+ * streams of the gates' columns for [h | motion] (N = 256 with z in channels 0..127, r in 128..255; N = 128), cin = 256, 5 taps;
+ * pre_zr [M][256], pre_q [M][128], z [M][128] (scratch), hf [M][128] (h in fp32, updated in place); h_out: the new h in split
+ * form -- a DIFFERENT buffer than h_in (a tile's halo cells are its neighbours' outputs).  Same bits as the two
+ * mftx_tile_conv2d-style launches it replaces. */
+int mftx_gru_half(const float *h_in, int ld_hin, const float *motion, int ld_mo, const void *wzr, const void *wq, const float *pre_zr,
+                  const float *pre_q, float *z, float *hf, float *h_out, int ld_hout, int P, int h, int w, int pass, void *stream);
 /* 1 when the tile-resident kernels' tiles of 128 cells fill the current device for a batch of P pairs of h x w cells (rounds of the
  * chip at least 5/8 full, all three tile shapes) -- the rule MFTX_RAFT_OPT_TILE_CONV = 1 applies per call.  A caller that
  * needs a pair's result to be independent of the batch it is computed in (a tracker whose batches ramp up, ranks of a
@@ -273,7 +284,9 @@ int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
  *                            branch, an iteration's coordinate update is applied by the next iteration's flow-branch kernel instead
  *                            of by a launch of its own), 2 the same with the update always applied by its own kernel, 0 two layers
  *   MFTX_RAFT_OPT_TILE_VOLUME 1 default (split arithmetic: the correlation volume by the tile-resident kernel, csrc/volume_tile.hip),
- *                            0 the ring-buffered GEMM */
+ *                            0 the ring-buffered GEMM
+ *   MFTX_RAFT_OPT_FUSE_GRU   1 default (where the tile-resident layers run: each SepConvGRU pass as ONE kernel, mftx_gru_half), 0 z | r
+ *                            gates and candidate + blend as two tile-resident launches.  Same bits either way. */
 #define MFTX_RAFT_OPT_FORK 0
 #define MFTX_RAFT_OPT_PRESPLIT 1
 #define MFTX_RAFT_OPT_GROUP 2
@@ -283,6 +296,7 @@ int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
 #define MFTX_RAFT_OPT_TILE_CONV 6
 #define MFTX_RAFT_OPT_FUSE_HEAD 7
 #define MFTX_RAFT_OPT_TILE_VOLUME 8
+#define MFTX_RAFT_OPT_FUSE_GRU 9
 int mftx_raft_set_option(mftx_raft *r, int option, int value);
 /* A device-resident counter (4 bytes, zeroed by the caller) that the last kernel of every mftx_raft_refine* call increments
  * by the number of output pixels with a non-finite flow / occlusion / sigma; null switches it off.  The reference has no

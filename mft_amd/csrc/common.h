@@ -172,6 +172,15 @@ struct TileConvLaunch {
     const void *wproj; float *tout;     // epi 4 (flow head: relu, then the next layer's 3 x 3 x 2 filter as [256 x 18] partial products -> tout [M][18])
     int P, h, w, N, kh, kw, epi;
 };
+// one SepConvGRU pass as one kernel (tile_conv.hip: gru_half_kernel); pass 0: 1 x 5, pass 1: 5 x 1
+struct GruHalfLaunch {
+    const float *h_in; int ld_hin; const float *mo; int ld_mo;      // h and the motion features, split form, 128 channels each
+    const void *wzr, *wq;                                           // launch_pack_tile_conv streams (N = 256 / 128, cin = 256)
+    const float *pre_zr, *pre_q;                                    // context parts + bias [M][256] / [M][128]
+    float *z, *hf, *h_out; int ld_hout;                             // z scratch [M][128]; fp32 h [M][128] in place; new h in split form
+    int P, h, w, pass;
+};
+int launch_gru_half(const GruHalfLaunch &d, hipStream_t s);
 int launch_pack_flow_head(const float *w2pk, void *out, hipStream_t s);
 int launch_flow_head_sum(const float *T, const float *b2, float *delta, const float *coords_in, float *coords_out, int P, int h, int w, hipStream_t s);
 bool tile_conv_applicable(int kh, int kw, int cin, int N);

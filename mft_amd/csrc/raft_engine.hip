@@ -134,6 +134,7 @@ struct Workspace {
     float *pre_zr[2], *pre_q[2];   // inp part of the GRU gate convolutions (+ bias), per pass
     float *f2s;                    // split form of fmap2 (B operand of the volume GEMM in split arithmetic)
     float *hf;                     // split arithmetic: fp32 copy of h [M][128] (hx itself is in split form)
+    float *hb;                     // split arithmetic: h between the two passes of the fused GRU kernel [M][128], split form
     int ld_corr;                   // 324: the lookup's features stay fp32 (the lookup is HBM-bound; convc1 splits them in registers)
     size_t bytes;
 };
@@ -169,6 +170,7 @@ static Workspace carve(void *base, int P, int h, int w, bool ondemand = false, b
     for (int pass = 0; pass < 2; ++pass) { ws.pre_zr[pass] = take(M * 256); ws.pre_q[pass] = take(M * 128); }
     ws.f2s = take(ondemand || !split ? 0 : M * 256);
     ws.hf = take(split ? M * 128 : 0);
+    ws.hb = take(split ? M * 128 : 0);
     ws.bytes = off;
     return ws;
 }
@@ -192,7 +194,7 @@ struct mftx_raft {
     const void *wflow;             // convf1's and convf2's weights for the fused flow-branch kernel (csrc/flow_branch.hip), or null
     const void *wproj;             // the flow head's last layer as the projection epilogue of its first (csrc/tile_conv.hip: TC_RELU_PROJ), or null
     const void *wt[W_COUNT];       // weight streams of the tile-resident conv kernel (csrc/tile_conv.hip) per slot, or null
-    int opt[9];                    // MFTX_RAFT_OPT_*
+    int opt[10];                   // MFTX_RAFT_OPT_*
     unsigned *nonfinite;           // device counter of non-finite output pixels (mftx_raft_set_nonfinite_counter), or null
 };
 // weights that go through the conv GEMM (the others feed VALU kernels and stay fp32)
@@ -220,7 +222,7 @@ extern "C" int mftx_raft_create(const float *const *weights, int n_weights, mftx
     r->coords_trace = nullptr;
     r->nonfinite = nullptr;
     r->graphs = new (std::nothrow) GraphCache;
-    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1; r->opt[MFTX_RAFT_OPT_FUSE_FLOW] = 1; r->opt[MFTX_RAFT_OPT_TILE_CONV] = 1; r->opt[MFTX_RAFT_OPT_FUSE_HEAD] = 1; r->opt[MFTX_RAFT_OPT_TILE_VOLUME] = 1;
+    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1; r->opt[MFTX_RAFT_OPT_FUSE_FLOW] = 1; r->opt[MFTX_RAFT_OPT_TILE_CONV] = 1; r->opt[MFTX_RAFT_OPT_FUSE_HEAD] = 1; r->opt[MFTX_RAFT_OPT_TILE_VOLUME] = 1; r->opt[MFTX_RAFT_OPT_FUSE_GRU] = 1;
     for (int i = 0; i < W_COUNT; ++i) r->w[i] = r->wg[i] = weights[i];
     *out = r;
     return 0;
@@ -334,7 +336,7 @@ extern "C" int mftx_raft_set_nonfinite_counter(mftx_raft *r, unsigned *counter) 
 
 extern "C" int mftx_raft_set_option(mftx_raft *r, int option, int value) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_option: bad handle");
-    if (option < 0 || option > MFTX_RAFT_OPT_TILE_VOLUME) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
+    if (option < 0 || option > MFTX_RAFT_OPT_FUSE_GRU) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
     r->opt[option] = value;
     if (r->graphs) r->graphs->clear();
     return 0;
@@ -586,6 +588,16 @@ static int refine_impl(mftx_raft *r, int P, int h, int w, int iters, const float
         for (int pass = 0; pass < 2; ++pass) {
             const int kh = pass ? 5 : 1, kw = pass ? 1 : 5;
             const int szr = pass ? W_ZR2_DYN : W_ZR1_DYN, sq = pass ? W_Q2_DYN : W_Q1_DYN;
+            if (tile_w(szr) && tile_w(sq) && r->opt[MFTX_RAFT_OPT_FUSE_GRU] != 0) {
+                // the whole pass as ONE kernel (tile_conv.hip: gru_half_kernel): the tile is loaded once, r * h stays in LDS; h goes
+                // hx -> hb in the horizontal pass and back in the vertical one (a tile's halo cells are its neighbours' outputs)
+                GruHalfLaunch g{};
+                g.h_in = pass ? ws.hb : ws.hx; g.ld_hin = pass ? 128 : 384; g.h_out = pass ? ws.hx : ws.hb; g.ld_hout = pass ? 384 : 128;
+                g.mo = ws.hx + 256; g.ld_mo = 384; g.wzr = tile_w(szr); g.wq = tile_w(sq); g.pre_zr = ws.pre_zr[pass]; g.pre_q = ws.pre_q[pass];
+                g.z = ws.z; g.hf = ws.hf; g.P = P; g.h = h; g.w = w; g.pass = pass;
+                TRY(launch_gru_half(g, s));
+                continue;
+            }
             if (tile_w(szr)) {
                 TileConvLaunch t = tile_layer(ws.hx, 384, ws.hx + 256, 384, tile_w(szr), nullptr, 256, kh, kw, 2);
                 t.addend = ws.pre_zr[pass]; t.ld_addend = 256; t.z = ws.z; t.rh = ws.rh; t.hf = ws.hf; t.ld_hf = 128;
@@ -790,6 +802,14 @@ extern "C" int mftx_tile_conv2d(const mftx_conv_desc *d, const void *wtile, void
     t.addend = d->addend; t.ld_addend = d->ld_addend; t.out = d->out; t.ldo = d->ldo; t.out_split = d->out_split;
     t.P = d->P; t.h = d->h; t.w = d->w; t.N = d->N; t.kh = d->kh; t.kw = d->kw; t.epi = d->act;
     return launch_tile_conv(t, (hipStream_t)stream);
+}
+
+extern "C" int mftx_gru_half(const float *h_in, int ld_hin, const float *motion, int ld_mo, const void *wzr, const void *wq, const float *pre_zr,
+                             const float *pre_q, float *z, float *hf, float *h_out, int ld_hout, int P, int h, int w, int pass, void *stream) {
+    GruHalfLaunch g{};
+    g.h_in = h_in; g.ld_hin = ld_hin; g.mo = motion; g.ld_mo = ld_mo; g.wzr = wzr; g.wq = wq; g.pre_zr = pre_zr; g.pre_q = pre_q;
+    g.z = z; g.hf = hf; g.h_out = h_out; g.ld_hout = ld_hout; g.P = P; g.h = h; g.w = w; g.pass = pass;
+    return launch_gru_half(g, (hipStream_t)stream);
 }
 
 extern "C" int mftx_tile_conv_fills_chip(int P, int h, int w) {

@@ -381,6 +381,318 @@ extern "C" int mftx_debug_tc_trace(unsigned long long *out) {
 }
 #endif
 
+// ---- one GRU half in ONE kernel (core/update.py:108-123): z | r gates -> r * h -> candidate q -> h <- (1 - z) h + z q -------------
+// The two launches of a SepConvGRU pass share their input: [h | motion] of a tile feeds the z | r gates, [r * h | motion] of the
+// same tile the candidate.  Here the tile is loaded ONCE; the gates' K loop runs as in tile_conv_kernel<..., 256, 256>, r * h
+// replaces h IN PLACE in the LDS tile (the fp32 sums of 8 channels and their split form are the same 32 bytes), the
+// candidate's K loop runs as in tile_conv_kernel<..., 256, 128> over the same tile, and the blend writes the new h: one
+// launch, one load phase, and r * h never leaves the CU.
+//   halo      the candidate at a cell needs r * h at its +- 2 neighbours along the pass: a tile's 128 cells are the "R cells"
+//             where the gates are evaluated; cells within 2 of an R edge that is not an image border are evaluated for their
+//             neighbours' sake only, their own new h comes from the adjacent tile (tiles advance by TW - 4 along the pass; a
+//             tile that spans the whole image width -- 64 cells at 512 x 512 -- recomputes nothing);
+//   h         is read from one buffer and written to another (h_in / h_out): a workgroup's halo cells are its neighbours' outputs;
+//   z         goes through global memory (64 KB per tile, written and read by the same workgroup: L2) -- LDS is full;
+//   sums      every output is the same sequence of products and sums as in the two kernels this replaces: same bits.
+struct GruHalfArgs {
+    const float *h_in; int ld_hin;      // h, split form, 128 channels at h_in + cell * ld_hin floats
+    const float *mo; int ld_mo;         // motion features, split form, 128 channels
+    const void *wzr, *wq;               // mftx_pack_tile_conv_weights streams: [z | r] (N = 256) and q (N = 128), cin = 256
+    const float *pre_zr, *pre_q;        // the gates' context parts + bias (pre-activation addends): [M][256], [M][128]
+    float *z;                           // scratch [M][128]
+    float *hf;                          // h in fp32 [M][128], updated in place
+    float *h_out; int ld_hout;          // new h, split form
+    int P, h, w, tiles_x, tiles_y, step;
+};
+
+template <class G, int KW>
+__device__ __forceinline__ void tc_kloop(const unsigned char *const (&abase)[4], const uint4 *__restrict__ w2, uint4 (&bq)[3][2],
+                                         tc_f32x16 (&acc)[4], tc_f32x16 (&accx)[4]) {
+    constexpr int PF = 3;
+    tc_f16x8 ah[2][4], al[2][4];
+    auto read_a = [&](int s, int set) {
+        const int tap = s / G::GPW, gg = s % G::GPW;
+        const int off = ((tap / KW) * G::HWD + tap % KW) * G::CELLB + gg * 64 * G::KS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[set][i] = *reinterpret_cast<const tc_f16x8 *>(abase[i] + off);
+            al[set][i] = *reinterpret_cast<const tc_f16x8 *>(abase[i] + off + 16);
+        }
+    };
+    read_a(0, 0);
+#pragma unroll
+    for (int s = 0; s < G::STEPS; ++s) {
+        const int set = s & 1;
+        const tc_f16x8 bh = __builtin_bit_cast(tc_f16x8, bq[s % PF][0]), bl = __builtin_bit_cast(tc_f16x8, bq[s % PF][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < G::STEPS) read_a(s + 1, set ^ 1);
+        if (s + PF < G::STEPS) { bq[s % PF][0] = w2[(s + PF) * 128]; bq[s % PF][1] = w2[(s + PF) * 128 + 64]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = tc_mfma(bh, ah[set][i], acc[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accx[i] = tc_mfma(bl, ah[set][i], accx[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accx[i] = tc_mfma(bh, al[set][i], accx[i]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int TH, int TW, int KH, int KW>
+__global__ __launch_bounds__(512, 2) void gru_half_kernel(GruHalfArgs p) {
+    using G1 = TcGeom<TH, TW, KH, KW, 256, 256>;            // the gates: wave = one 32-channel column tile of [z | r], all of K
+    using G2 = TcGeom<TH, TW, KH, KW, 256, 128>;            // the candidate: wave = (column tile, K half)
+    static_assert(G1::CELLB == G2::CELLB && G1::HWD == G2::HWD, "one tile, two GEMMs");
+    constexpr int CELLB = G1::CELLB, HWD = G1::HWD, PF = 3;
+    constexpr bool HORIZ = KW > 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tc_lds[];
+    unsigned char *lds = tc_lds;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = (int)blockIdx.x;
+    const int tx_ = tile % p.tiles_x, ty_ = (tile / p.tiles_x) % p.tiles_y, img = tile / (p.tiles_x * p.tiles_y);
+    // the R cells' origin, and the cells of them whose new h this workgroup writes: [olo, ohi) along the pass
+    const int n_along = HORIZ ? p.tiles_x : p.tiles_y, t_along = HORIZ ? tx_ : ty_, len_along = HORIZ ? p.w : p.h;
+    const int r0 = n_along > 1 ? t_along * p.step - 2 : 0;
+    const int olo = n_along > 1 ? t_along * p.step : 0, ohi = n_along > 1 ? min(len_along, olo + p.step) : len_along;
+    const int x0 = HORIZ ? r0 : tx_ * TW, y0 = HORIZ ? ty_ * TH : r0;
+    const long long img_base = (long long)img * p.h * p.w;
+    const uint4 *__restrict__ w1 = reinterpret_cast<const uint4 *>(p.wzr) + (long long)(wv * G1::STEPS) * 128 + lane;
+    const int nt2 = wv % G2::NT, ks2 = wv / G2::NT;
+    const uint4 *__restrict__ w2 = reinterpret_cast<const uint4 *>(p.wq) + (long long)((nt2 * G2::KS + ks2) * G2::STEPS) * 128 + lane;
+
+#ifdef MFTX_LF_TRACE
+    int tcount = 0;
+#endif
+    TC_T(1);
+    TC_CLK(0);
+    uint4 bq[PF][2];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) { bq[s][0] = w1[s * 128]; bq[s][1] = w1[s * 128 + 64]; }
+
+    // ---- [h | motion] of the tile (halo included) -> LDS, 16-byte pieces, zeros outside the image
+    {
+        constexpr int PPC = 64, TOTAL = G1::HCELLS * PPC, ROUNDS = (TOTAL + 511) / 512, B = 6;
+#pragma unroll 1
+        for (int rr = 0; rr < ROUNDS; rr += B) {
+            uint4 v[B];
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                const int q = (rr + k) * 512 + tid;
+                v[k] = make_uint4(0u, 0u, 0u, 0u);
+                if (rr + k < ROUNDS && q < TOTAL) {
+                    const int c = q / PPC, pc = q - c * PPC;
+                    const int cy = c / HWD, cx = c - cy * HWD;
+                    const int yy = y0 - KH / 2 + cy, xx = x0 - KW / 2 + cx;
+                    if (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w) {
+                        const long long cell = img_base + (long long)yy * p.w + xx;
+                        const float *src = pc >= 32 ? p.mo + cell * p.ld_mo + (pc - 32) * 4 : p.h_in + cell * p.ld_hin + pc * 4;
+                        v[k] = *reinterpret_cast<const uint4 *>(src);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                const int q = (rr + k) * 512 + tid;
+                if (rr + k < ROUNDS && q < TOTAL) {
+                    const int c = q / PPC, pc = q - c * PPC;
+                    *reinterpret_cast<uint4 *>(lds + c * CELLB + pc * 16) = v[k];
+                }
+            }
+        }
+    }
+    TC_T(2);
+    tc_barrier();
+    TC_T(3);
+
+    tc_f32x16 acc[4], accx[4];
+    const unsigned char *abase[4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accx[i][r] = 0.f; }
+    };
+    auto set_abase = [&](int ks) {
+        const int r = lane & 31;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = 32 * i + r;
+            abase[i] = lds + ((m / TW) * HWD + (m % TW)) * CELLB + (lane >> 5) * 32 + ks * 64;
+        }
+    };
+    // an R cell's own slot in the tile: its h part is the first 512 bytes, [8 channels: hi x 8 | lo x 8] x 16
+    auto slot = [&](int m) { return lds + ((m / TW + KH / 2) * HWD + (m % TW + KW / 2)) * CELLB; };
+    const float inv2048 = 1.f / 2048.f;
+    const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));
+    // four waves' sums (channels 32 c .. 32 c + 31 of 128, all R cells) -> the R cells' h slots, fp32 [cell][128]
+    auto park128 = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                tc_f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * b + e] + accx[i][4 * b + e] * inv2048;
+                *reinterpret_cast<tc_f32x4 *>(slot(32 * i + (lane & 31)) + (32 * c + 8 * b + 4 * (lane >> 5)) * 4) = v;
+            }
+    };
+
+    // ---- z | r gates
+    zero_acc();
+    set_abase(0);
+    tc_kloop<G1, KW>(abase, w1, bq, acc, accx);
+    TC_T(4);
+    // (the candidate's first weight fragments: in flight during the gate algebra)
+#pragma unroll
+    for (int s = 0; s < PF; ++s) { bq[s][0] = w2[s * 128]; bq[s][1] = w2[s * 128 + 64]; }
+    tc_barrier();           // every wave is done with the h parts of the tile
+    if (wv < 4) park128(wv);
+    tc_barrier();
+    // z = sigmoid(. + context part): row-wise, 8 consecutive channels of a cell per lane -> global (this workgroup reads it back)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int item = tid + 512 * it, m = item >> 4, n0 = (item & 15) * 8;
+        const int yy = y0 + m / TW, xx = x0 + m % TW, along = HORIZ ? xx : yy;
+        const float *src = reinterpret_cast<const float *>(slot(m)) + n0;
+        tc_f32x4 u = *reinterpret_cast<const tc_f32x4 *>(src), v = *reinterpret_cast<const tc_f32x4 *>(src + 4);
+        if (yy < 0 || yy >= p.h || xx < 0 || xx >= p.w || along < olo || along >= ohi) continue;
+        const long long cell = img_base + (long long)yy * p.w + xx;
+        u += *reinterpret_cast<const tc_f32x4 *>(p.pre_zr + cell * 256 + n0);
+        v += *reinterpret_cast<const tc_f32x4 *>(p.pre_zr + cell * 256 + n0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { u[e] = tc_sigmoid(u[e]); v[e] = tc_sigmoid(v[e]); }
+        *reinterpret_cast<tc_f32x4 *>(p.z + cell * 128 + n0) = u;
+        *reinterpret_cast<tc_f32x4 *>(p.z + cell * 128 + n0 + 4) = v;
+    }
+    tc_barrier();           // the z sums have been read
+    if (wv >= 4) park128(wv - 4);
+    tc_barrier();
+    // r * h, in place: the sums of 8 channels become their split form (zero outside the image: the candidate's zero padding)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int item = tid + 512 * it, m = item >> 4, n0 = (item & 15) * 8;
+        const int yy = y0 + m / TW, xx = x0 + m % TW;
+        float *src = reinterpret_cast<float *>(slot(m)) + n0;
+        tc_f32x4 u = *reinterpret_cast<const tc_f32x4 *>(src), v = *reinterpret_cast<const tc_f32x4 *>(src + 4);
+        tc_u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
+        if (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w) {
+            const long long cell = img_base + (long long)yy * p.w + xx;
+            u += *reinterpret_cast<const tc_f32x4 *>(p.pre_zr + cell * 256 + 128 + n0);
+            v += *reinterpret_cast<const tc_f32x4 *>(p.pre_zr + cell * 256 + 128 + n0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { u[e] = tc_sigmoid(u[e]); v[e] = tc_sigmoid(v[e]); }
+            u *= *reinterpret_cast<const tc_f32x4 *>(p.hf + cell * 128 + n0);
+            v *= *reinterpret_cast<const tc_f32x4 *>(p.hf + cell * 128 + n0 + 4);
+            tc_split8(u, v, k2048, hi, lo);
+        }
+        *reinterpret_cast<tc_u32x4 *>(src) = hi;
+        *reinterpret_cast<tc_u32x4 *>(src + 4) = lo;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (this wave's z stores have reached L2 before anyone reads z back)
+    TC_T(5);
+    tc_barrier();
+    TC_T(6);
+
+    // ---- the candidate over [r * h | motion]
+    zero_acc();
+    set_abase(ks2);
+    tc_kloop<G2, KW>(abase, w2, bq, acc, accx);
+    TC_T(7);
+    tc_barrier();           // every wave is done with the tile: its space takes the sums
+    float *red = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            tc_f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * b + e] + accx[i][4 * b + e] * inv2048;
+            *reinterpret_cast<tc_f32x4 *>(red + (ks2 * 128 + 32 * i + (lane & 31)) * G2::RED_ROW + 32 * nt2 + 8 * b + 4 * (lane >> 5)) = v;
+        }
+    tc_barrier();
+    // q = tanh(. + context part), h <- (1 - z) h + z q (core/update.py:116-117, 122-123): the cells this workgroup owns
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int item = tid + 512 * it, m = item >> 4, n0 = (item & 15) * 8;
+        const int yy = y0 + m / TW, xx = x0 + m % TW, along = HORIZ ? xx : yy;
+        const float *src = red + m * G2::RED_ROW + n0;
+        tc_f32x4 u = *reinterpret_cast<const tc_f32x4 *>(src), v = *reinterpret_cast<const tc_f32x4 *>(src + 4);
+        u += *reinterpret_cast<const tc_f32x4 *>(src + 128 * G2::RED_ROW);
+        v += *reinterpret_cast<const tc_f32x4 *>(src + 128 * G2::RED_ROW + 4);
+        if (yy < 0 || yy >= p.h || xx < 0 || xx >= p.w || along < olo || along >= ohi) continue;
+        const long long cell = img_base + (long long)yy * p.w + xx;
+        u += *reinterpret_cast<const tc_f32x4 *>(p.pre_q + cell * 128 + n0);
+        v += *reinterpret_cast<const tc_f32x4 *>(p.pre_q + cell * 128 + n0 + 4);
+        const tc_f32x4 z0 = *reinterpret_cast<const tc_f32x4 *>(p.z + cell * 128 + n0), z1 = *reinterpret_cast<const tc_f32x4 *>(p.z + cell * 128 + n0 + 4);
+        float *hrow = p.hf + cell * 128 + n0;
+        const tc_f32x4 h0 = *reinterpret_cast<const tc_f32x4 *>(hrow), h1 = *reinterpret_cast<const tc_f32x4 *>(hrow + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { u[e] = tc_blend(z0[e], h0[e], tc_tanh(u[e])); v[e] = tc_blend(z1[e], h1[e], tc_tanh(v[e])); }
+        *reinterpret_cast<tc_f32x4 *>(hrow) = u;
+        *reinterpret_cast<tc_f32x4 *>(hrow + 4) = v;
+        tc_u32x4 hi, lo;
+        tc_split8(u, v, k2048, hi, lo);
+        uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(p.h_out + cell * p.ld_hout) + (n0 >> 3) * 32);
+        dst[0] = __builtin_bit_cast(uint4, hi);
+        dst[1] = __builtin_bit_cast(uint4, lo);
+    }
+    TC_T(8);
+    TC_CLK(1);
+}
+
+template <int TH, int TW, int KH, int KW>
+static int gru_half_launch(GruHalfArgs a, hipStream_t s) {
+    using G1 = TcGeom<TH, TW, KH, KW, 256, 256>;
+    using G2 = TcGeom<TH, TW, KH, KW, 256, 128>;
+    constexpr int lds_bytes = G1::A_BYTES > G2::RED_BYTES ? G1::A_BYTES : G2::RED_BYTES;      // the tile, then the candidate's parked sums
+    static_assert(lds_bytes <= 160 * 1024, "gru_half: LDS");
+    constexpr bool HORIZ = KW > 1;
+    const int along = HORIZ ? a.w : a.h, T = HORIZ ? TW : TH;
+    a.step = T - 4;
+    const int n_along = along <= T ? 1 : cdiv(along, a.step);
+    a.tiles_x = HORIZ ? n_along : cdiv(a.w, TW);
+    a.tiles_y = HORIZ ? cdiv(a.h, TH) : n_along;
+    const long long tiles = (long long)a.P * a.tiles_x * a.tiles_y;
+    if (tiles > 0x7fffffffLL) return fail(MFTX_E_ARG, "gru_half: too many tiles");
+    auto kern = gru_half_kernel<TH, TW, KH, KW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+            return fail(MFTX_E_STATE, "gru_half: cannot reserve %d bytes of LDS", lds_bytes);
+        attr_set = true;
+    }
+    ProfScope prof(PC_CONV_GEMM, s, 2.0 * a.P * a.h * a.w * 384.0 * KH * KW * 256);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds_bytes, s, a);
+    return check_launch("gru_half");
+}
+
+// tiles of the fused kernel for a pass over P maps of h x w cells with R tiles of th x tw cells
+static long long gru_half_tiles(int P, int h, int w, int th, int tw, bool horiz) {
+    const int along = horiz ? w : h, T = horiz ? tw : th;
+    const int n_along = along <= T ? 1 : cdiv(along, T - 4);
+    return (long long)P * (horiz ? n_along * cdiv(h, th) : n_along * cdiv(w, tw));
+}
+
+int launch_gru_half(const GruHalfLaunch &d, hipStream_t s) {
+    if (!d.h_in || !d.mo || !d.wzr || !d.wq || !d.pre_zr || !d.pre_q || !d.z || !d.hf || !d.h_out) return fail(MFTX_E_ARG, "gru_half: null pointer");
+    if (d.P <= 0 || d.h <= 0 || d.w <= 0 || (d.pass != 0 && d.pass != 1)) return fail(MFTX_E_ARG, "gru_half: bad sizes");
+    if (d.h_in == d.h_out) return fail(MFTX_E_ARG, "gru_half: h is read from one buffer and written to another");
+    auto bad_split = [](const float *p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 31) != 0 || (ld % 8) != 0; };
+    if (bad_split(d.h_in, d.ld_hin) || bad_split(d.mo, d.ld_mo) || bad_split(d.h_out, d.ld_hout) || !aligned16(d.wzr) || !aligned16(d.wq) ||
+        !aligned16(d.pre_zr) || !aligned16(d.pre_q) || !aligned16(d.z) || !aligned16(d.hf))
+        return fail(MFTX_E_ALIGN, "gru_half: split-form rows are 32-byte aligned with strides in multiples of 8; the rest 16-byte aligned");
+    GruHalfArgs a{};
+    a.h_in = d.h_in; a.ld_hin = d.ld_hin; a.mo = d.mo; a.ld_mo = d.ld_mo; a.wzr = d.wzr; a.wq = d.wq; a.pre_zr = d.pre_zr; a.pre_q = d.pre_q;
+    a.z = d.z; a.hf = d.hf; a.h_out = d.h_out; a.ld_hout = d.ld_hout; a.P = d.P; a.h = d.h; a.w = d.w;
+    // R tiles of 2 x 64 cells (a 64-wide map is one tile per row pair: nothing is recomputed) or 4 x 32: whichever needs fewer
+    if (d.pass == 0) {
+        if (gru_half_tiles(d.P, d.h, d.w, 2, 64, true) <= gru_half_tiles(d.P, d.h, d.w, 4, 32, true)) return gru_half_launch<2, 64, 1, 5>(a, s);
+        return gru_half_launch<4, 32, 1, 5>(a, s);
+    }
+    if (gru_half_tiles(d.P, d.h, d.w, 64, 2, false) <= gru_half_tiles(d.P, d.h, d.w, 32, 4, false)) return gru_half_launch<64, 2, 5, 1>(a, s);
+    return gru_half_launch<32, 4, 5, 1>(a, s);
+}
+
 // ---- weights: the GEMM's packed form [>= N rows][taps][cin_pad] fp32 -> [nt][ks][step][hi | lo][lane] x 16 bytes
 __global__ void pack_tile_conv_kernel(const float *__restrict__ wpk, int taps, int cin, int cin_pad, int N, uint4 *__restrict__ out, long long pieces) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -942,19 +942,18 @@ def test_lookup_convc1_argument_errors(ops_mod):
 
 
 
-def _engine_outputs(options):
+def _engine_outputs(options, P=3, h=24, w=40, iters=4):
     """One refinement of the RAFT engine on seeded random features with the given per-handle options."""
     from mft_amd import ops
     from mft_amd.weights import make_weights
     sd = {k: torch.from_numpy(v).cuda() for k, v in make_weights(7).items()}
     eng = ops.RaftEngine(sd, "cuda", options=options)
     g = torch.Generator().manual_seed(11)
-    P, h, w = 3, 24, 40
     f1 = torch.randn(P, h * w, 256, generator=g).cuda()
     f2 = (f1.cpu() + 0.3 * torch.randn(P, h * w, 256, generator=g)).cuda()
     net = torch.tanh(torch.randn(P, h * w, 128, generator=g)).cuda()
     inp = torch.relu(torch.randn(P, h * w, 128, generator=g)).cuda()
-    flow, occl, sigma = eng.refine(f1, f2, net, inp, h, w, 4)[:3]
+    flow, occl, sigma = eng.refine(f1, f2, net, inp, h, w, iters)[:3]
     return np.concatenate([t.cpu().numpy().ravel() for t in (flow, occl, sigma)])
 
 
@@ -1126,6 +1125,53 @@ def test_engine_tile_conv_matches_ring_gemm():
     epe = np.sqrt((d ** 2).sum(1)).mean()
     assert epe < 1e-4, epe
     assert np.abs(tiled[n:] - ring[n:]).max() < 1e-3
+
+
+@pytest.mark.parametrize("P,h,w", [(3, 24, 40), (1, 72, 80), (1, 33, 140), (2, 135, 16), (1, 64, 64)])
+def test_engine_fused_gru_bitwise(P, h, w):
+    """Each SepConvGRU pass as ONE kernel (mftx_gru_half: the tile loaded once, r * h formed in LDS in place, h ping-ponging
+    between two buffers) against the two tile-resident launches it replaces: every output is the same sequence of products
+    and sums -- the same bits.  Sizes: one tile across (nothing recomputed), maps wider / taller than a tile (R tiles that
+    overlap by the gates' 2-cell halo, both tile shapes), ragged edges."""
+    fused, apart = _engine_outputs({"tile_conv": 2}, P, h, w, 3), _engine_outputs({"tile_conv": 2, "fuse_gru": 0}, P, h, w, 3)
+    assert np.isfinite(fused).all()
+    assert np.array_equal(fused, apart)
+
+
+@pytest.mark.parametrize("P,h,w,vertical", [(1, 16, 24, False), (1, 16, 24, True), (2, 9, 150, False), (1, 150, 7, True), (1, 64, 64, False)])
+def test_gru_half_vs_fp64(ops_mod, P, h, w, vertical):
+    """mftx_gru_half against the gate algebra of core/update.py:108-123 in fp64: z, the new h (fp32 copy and split form)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5 + h + w)
+    M = P * h * w
+    hf = torch.tanh(torch.randn(M, 128, generator=g))
+    mo = torch.relu(torch.randn(M, 128, generator=g))
+    kh, kw = (5, 1) if vertical else (1, 5)
+    wzr = torch.randn(256, 256, kh, kw, generator=g) * 0.04
+    wq = torch.randn(128, 256, kh, kw, generator=g) * 0.04
+    pre_zr = torch.randn(M, 256, generator=g) * 0.5
+    pre_q = torch.randn(M, 128, generator=g) * 0.5
+    pack = lambda wt, n: ops_mod.pack_tile_conv_weights(ops_mod.pack_conv_weight(wt.cuda()), n, 256)      # noqa: E731
+    hf_dev = hf.cuda()
+    h_out, z = ops_mod.gru_half(ops_mod.split_activations(hf_dev), ops_mod.split_activations(mo.cuda()), pack(wzr, 256), pack(wq, 128),
+                                pre_zr.cuda(), pre_q.cuda(), hf_dev, P, h, w, vertical=vertical)
+    to_map = lambda t: t.double().reshape(P, h, w, -1).permute(0, 3, 1, 2)      # noqa: E731
+    to_rows = lambda t: t.permute(0, 2, 3, 1).reshape(M, -1)                    # noqa: E731
+    pad = (kh // 2, kw // 2)
+    hd, md = to_map(hf), to_map(mo)
+    zr = torch.sigmoid(F.conv2d(torch.cat([hd, md], 1), wzr.double(), padding=pad) + to_map(pre_zr))
+    zz, rr = zr[:, :128], zr[:, 128:]
+    q = torch.tanh(F.conv2d(torch.cat([rr * hd, md], 1), wq.double(), padding=pad) + to_map(pre_q))
+    want = (1 - zz) * hd + zz * q
+    assert (z.cpu().double() - to_rows(zz)).abs().max() < 2e-6
+    assert (hf_dev.cpu().double() - to_rows(want)).abs().max() < 5e-6
+    assert torch.equal(ops_mod.unsplit_activations(h_out), ops_mod.unsplit_activations(ops_mod.split_activations(hf_dev)))
+    with pytest.raises(ops_mod.MftxError):         # h is read from one buffer and written to another
+        from mft_amd import _lib
+        hs = ops_mod.split_activations(hf_dev)
+        ops_mod.check(_lib.load().mftx_gru_half(hs.data_ptr(), 128, hs.data_ptr(), 128, pack(wzr, 256).data_ptr(), pack(wq, 128).data_ptr(),
+                                                pre_zr.cuda().data_ptr(), pre_q.cuda().data_ptr(), z.data_ptr(), hf_dev.data_ptr(),
+                                                hs.data_ptr(), 128, P, h, w, 0, None), "mftx_gru_half")
 
 
 @pytest.mark.parametrize("P,h,w", [(1, 8, 16), (2, 21, 37), (1, 64, 64), (1, 3, 5)])

@@ -69,22 +69,36 @@ def probe(name, cin, cout, kh, kw, P, zeros):
     return run
 
 
+def hwmon_files():
+    out = []
+    for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        p = [f for f in (d + "/power1_average", d + "/power1_input") if Path(f).exists()]
+        f = d + "/freq1_input"
+        if p:
+            out.append((p[0], f if Path(f).exists() else None))
+    return out
+
+
 def sysfs_sampler(stop, rows):
-    power = glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") + glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input")
-    freq = glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")
-    if not power and not freq:
+    """(t, power W, sclk GHz) of the board that draws the most: the box has many DRM cards, the busy one is ours."""
+    files = hwmon_files()
+    if not files:
         rows.append(None)
         return
+    def read(path):
+        try:
+            return int(open(path).read())
+        except (OSError, ValueError):
+            return None
+    # pick the card by one probe round taken while the GPU is already busy
+    time.sleep(0.3)
+    probe = [(read(p) or 0) for p, _ in files]
+    pfile, ffile = files[max(range(len(files)), key=lambda i: probe[i])]
     while not stop.is_set():
         t = time.perf_counter()
-        p = f = None
-        try:
-            if power: p = int(open(power[0]).read()) * 1e-6
-            if freq: f = int(open(freq[0]).read()) * 1e-9
-        except (OSError, ValueError):
-            pass
-        rows.append((t, p, f))
-        time.sleep(0.004)
+        p, f = read(pfile), (read(ffile) if ffile else None)
+        rows.append((t, p * 1e-6 if p is not None else None, f * 1e-9 if f is not None else None))
+        time.sleep(0.002)
 
 
 def power_run(name, run, seconds=2.5):
