@@ -57,8 +57,10 @@ F16_MFMA_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16 /
 SPLIT_PRODUCTS = 3              # split arithmetic: fp16 MFMA products per fp32 product (hi hi + hi lo + lo hi)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak
 CATS = ["corr_volume_gemm", "corr_pool", "corr_lookup", "conv_gemm", "convf1", "glue", "convex_upsample",
-        "chain_select", "conv_small_n", "encoder_instnorm", "lookup_convc1_fused", "flow_branch_fused"]
-FLOP_CATS = {0, 3, 4, 8, 11}
+        "chain_select", "conv_small_n", "encoder_instnorm", "lookup_convc1_fused", "flow_branch_fused",
+        "encoder_conv_gemm", "gru_half_fused"]
+FLOP_CATS = {0, 3, 4, 8, 11, 12, 13}
+GEMM_PARTS = ("conv_gemm", "gru_half_fused", "encoder_conv_gemm")    # every conv GEMM of the step: what `roofline` prices, as in earlier rounds
 VALU_CATS = {4, 8}
 FULL_PAIRS = 7                  # flow pairs per frame once every delta is live
 FIRST_FULL_FRAME = 33           # first frame index with FULL_PAIRS pairs (forward tracking from frame 0)
@@ -145,7 +147,7 @@ def profile_pass(tracker, frames, first, steps, arith="split"):
         if i in FLOP_CATS:
             d.update(unit="TFLOP/s", achieved=work[i] / t / 1e12, peak=FP32_MFMA_PEAK_TFLOPS,
                      bound="valu" if i in VALU_CATS else "mfma", work_per_launch=work[i] / cnt[i])
-            if name in ("conv_gemm", "corr_volume_gemm", "flow_branch_fused") and arith == "split":
+            if name in ("conv_gemm", "corr_volume_gemm", "flow_branch_fused", "encoder_conv_gemm", "gru_half_fused") and arith == "split":
                 # the update block's GEMMs run every fp32 product as three fp16 MFMA products: the matrix work actually
                 # executed is 3 x the algorithmic flops, priced against the fp16 MFMA peak; the algorithmic rate is kept
                 # next to it (it may exceed the fp32 MFMA peak, which this path does not use)
@@ -157,25 +159,51 @@ def profile_pass(tracker, frames, first, steps, arith="split"):
         if "achieved" in d:
             d["frac"] = d["achieved"] / d["peak"]
         out[name] = d
+    # every conv GEMM of the step as one line (update block + OU heads on the ring-buffered and the tile-resident kernels, the fused
+    # GRU passes, the encoders' layers): the dominant kernel family `roofline` reports
+    parts = [CATS.index(n) for n in GEMM_PARTS if cnt[CATS.index(n)]]
+    if parts:
+        t = sum(ms[i] for i in parts) * 1e-3
+        w = sum(work[i] for i in parts)
+        c = sum(cnt[i] for i in parts)
+        mult, peak = (SPLIT_PRODUCTS, F16_MFMA_PEAK_TFLOPS) if arith == "split" else (1, FP32_MFMA_PEAK_TFLOPS)
+        out["conv_gemm_all"] = {"launches": int(c), "avg_us": 1e6 * t / c, "total_ms_per_step": 1e3 * t / steps, "unit": "TFLOP/s",
+                                "achieved": mult * w / t / 1e12, "algorithmic_tflops": w / t / 1e12, "peak": peak, "bound": "mfma",
+                                "work_per_launch": w / c, "frac": mult * w / t / 1e12 / peak, "parts": list(GEMM_PARTS)}
     return out, pairs
 
 
-def profiled_traffic():
-    """HBM bytes per conv-GEMM launch measured offline with rocprofv3 PMC passes on this same
-    command (profiles/*_pmc_hbm_traffic.csv: FETCH_SIZE x2-corrected + WRITE_SIZE, launch-weighted)."""
-    files = sorted((REPO / "profiles").glob("*_pmc_hbm_traffic.csv"))
+def build_hash():
+    """sha256 (first 16 hex digits) of the library this process runs: ties a counter file to the build it was measured on."""
+    import hashlib
+    from mft_amd import _lib
+    path = Path(os.environ.get("MFTX_LIB") or (REPO / "mft_amd" / "libmftx.so"))
+    return hashlib.sha256(path.read_bytes()).hexdigest()[:16] if path.exists() else None
+
+
+def profiled_traffic(profiles_dir=None):
+    """HBM bytes per conv-GEMM launch from rocprofv3 PMC passes on this same command (tools/gpu_profile.sh ->
+    profiles/*_pmc_hbm_traffic.csv: FETCH_SIZE x2-corrected + WRITE_SIZE in separate passes, launch-weighted).  Counters cannot be
+    read in-process, so the file is tied to the build: its `# build:` line must name the library this run loads -- a file measured
+    on another build is refused (traffic null, the reason in traffic_source)."""
+    files = sorted(Path(profiles_dir or REPO / "profiles").glob("*_pmc_hbm_traffic.csv"))
     if not files:
         return None, None
+    text = files[-1].read_text()
+    m = re.search(r"^# build: (\w+)", text, re.M)
+    mine = build_hash()
+    if m is None or mine is None or m.group(1) != mine:
+        return None, f"{files[-1].name} refused: measured on build {m.group(1) if m else 'unknown'}, this run loads {mine}"
     tot = n = 0.0
-    for line in files[-1].read_text().splitlines():
-        if line.startswith("#") or ("conv_gemm" not in line and "tile_conv_kernel" not in line):
+    for line in text.splitlines():
+        if line.startswith("#") or not any(k in line for k in ("conv_gemm", "tile_conv_kernel", "gru_half_kernel")):
             continue
         name, launches, _fetch, fetch_x2, write = line.rsplit(",", 4)     # the kernel name contains commas
         if "volume" in name or re.search(r"<\d+, \d+, \d+, \d+, 4[,>]", name):
             continue                                 # the correlation volume GEMM is its own category
         tot += float(launches) * (float(fetch_x2) + float(write)) * 1e6
         n += float(launches)
-    return (tot / n if n else None), files[-1].name
+    return (tot / n if n else None), f"{files[-1].name} (build {mine})"
 
 
 def cpu_baseline(args, vid):
@@ -232,6 +260,48 @@ def track_parity(args, vid, oracle_meta):
             "track_chosen_delta_agreement": same.float().mean().item(),
             "track_occlusion_max_abs_where_same_delta": (occl - ro).abs()[0][same].max().item(),
             "track_sigma_max_rel_where_same_delta": ((sigma - rs).abs() / rs.clamp_min(1e-6))[0][same].max().item()}
+
+
+def track_parity_real_state(args, vid, n_frames=6):
+    """Full-size parity with a REAL tracker state: `n_frames` consecutive frames from init with deltas {inf, 1, 2, 4} on the HIP
+    tracker and on the oracle tracker -- from frame 2 on every chain samples a non-trivial `memory` result at fractional positions
+    (the state of `track_parity` is the identity).  -> worst frame of the sequence."""
+    from oracle import mft_oracle as O
+    from mft_amd.weights import make_weights
+    torch.set_num_threads(oracle_threads())
+    sd = {k: torch.from_numpy(v) for k, v in make_weights(0).items()}
+    deltas = [np.inf, 1, 2, 4]
+    targs = argparse.Namespace(**vars(args))
+    tracker, conf = build_tracker(targs, sharded=False)
+    conf.deltas = list(deltas)
+    tracker.init(vid[0])
+    ref = O.Tracker(lambda l, r, li, ri: O.compute_flow(sd, li, ri, args.iters), deltas=deltas)
+    ref.init(vid[0])
+    worst = {"epe": 0.0, "epe_same": 0.0, "agree": 1.0, "occl": 0.0, "sigma": 0.0}
+    pairs = 0
+    t0 = time.perf_counter()
+    for i in range(1, n_frames + 1):
+        got = tracker.track(vid[i]).result
+        with torch.no_grad():
+            want = ref.track(vid[i])
+        assert sorted(tracker.last_pairs) == sorted(want.pairs), (i, tracker.last_pairs, want.pairs)
+        pairs += len(want.pairs)
+        rf, ro, rs = want.result
+        flow, occl, sigma = (t.cpu() for t in (got.flow, got.occlusion, got.sigma))
+        same = tracker.last_chosen.cpu().long() == want.chosen.long()
+        epe = (flow - rf).pow(2).sum(0).sqrt()
+        worst["epe"] = max(worst["epe"], epe.mean().item())
+        worst["epe_same"] = max(worst["epe_same"], epe[same].mean().item())
+        worst["agree"] = min(worst["agree"], same.float().mean().item())
+        worst["occl"] = max(worst["occl"], (occl - ro).abs()[0][same].max().item())
+        worst["sigma"] = max(worst["sigma"], ((sigma - rs).abs() / rs.clamp_min(1e-6))[0][same].max().item())
+    return {"real_state_frames": n_frames, "real_state_deltas": "inf,1,2,4", "real_state_pairs": pairs,
+            "real_state_flow_epe_px_worst_frame": worst["epe"],
+            "real_state_flow_epe_px_where_same_delta_worst_frame": worst["epe_same"],
+            "real_state_chosen_delta_agreement_worst_frame": worst["agree"],
+            "real_state_occlusion_max_abs_where_same_delta": worst["occl"],
+            "real_state_sigma_max_rel_where_same_delta": worst["sigma"],
+            "real_state_oracle_seconds": time.perf_counter() - t0}
 
 
 def flow_epe_vs_oracle(args, tracker, vid):
@@ -325,6 +395,9 @@ def main():
     ap.add_argument("--no-fused-lookup", action="store_true", help="A/B: correlation lookup and convc1 as two kernels")
     ap.add_argument("--engine-opt", action="append", metavar="NAME=INT",
                     help="A/B: a scheduling option of the refinement engine, e.g. fork=0 (results do not depend on it)")
+    ap.add_argument("--ab-skip-encoders", action="store_true",
+                    help="A/B upper bound only (the line is marked invalid): every frame reuses the first frame's features, no "
+                         "encoder launches -- what the frame would cost if the encoders were free")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="with --force-sharded on ONE GPU: behave like rank 0 of this many ranks (compute only that rank's "
                          "share of every window; the other ranks' slots of the all-gathers are filled with copies of the "
@@ -367,6 +440,9 @@ def main():
         f"pre-roll {preroll} + warm-up {args.warmup} + {args.steps} timed frames")
     tracker, conf = build_tracker(args, sharded=("force" if args.force_sharded and world == 1 else sharded))
     tracker.init(frames[0])
+    if args.ab_skip_encoders:
+        feats0 = tracker.flower._encode(frames[0])
+        tracker.flower._encode = lambda img, _f=feats0: _f
     if args.emulate_world > 1:
         if not (args.force_sharded and world == 1):
             raise SystemExit("--emulate-world needs --force-sharded on one GPU")
@@ -455,6 +531,7 @@ def main():
                        "frames_resident_in_hbm": True, "preroll_frames": preroll,
                        "first_timed_frame": first},
             "emulated_world": (args.emulate_world or None),
+            **({"invalid_ab": "encoders skipped (--ab-skip-encoders): an upper bound, not a measurement"} if args.ab_skip_encoders else {}),
             "ranks_seen": ranks_seen,          # sum over ranks of 1, by all-reduce (1 without a process group)
             "host_enqueue_ms_per_step": (float(np.mean(host_ms)) if host_ms else None),
             "pairs_per_frame": {"warmup": warm_pairs, "timed_min": min(timed_pairs), "timed_max": max(timed_pairs),
@@ -463,11 +540,12 @@ def main():
                      "pairs": ramp_pairs,
                      "note": "untimed pre-roll, frames 1..P after init: the number of flow pairs grows from 1 to 7"},
         }
-        dom = kernels.get("conv_gemm")
+        dom = kernels.get("conv_gemm_all") or kernels.get("conv_gemm")
         if dom:
             traffic, source = profiled_traffic()
             split = args.arith == "split"
-            result["roofline"] = {"kernel": "conv_gemm_kernel + tile_conv_kernel (%s implicit GEMM, ring-buffered and tile-resident: update block + OU heads)" %
+            result["roofline"] = {"kernel": "conv_gemm_kernel + tile_conv_kernel + gru_half_kernel (%s implicit GEMM, ring-buffered and tile-resident: update block, "
+                                            "OU heads, encoders -- kernels.conv_gemm_all)" %
                                             ("split-fp16 MFMA" if split else "fp32 MFMA"),
                                   "bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"],
                                   "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
@@ -534,6 +612,7 @@ def main():
         torch.set_num_threads(oracle_threads())
         if not args.no_parity:
             result["parity"] = flow_epe_vs_oracle(args, tracker, vid)
+            result["parity"].update(track_parity_real_state(args, vid))
             log(f"parity vs oracle: {result.get('parity')}")
         if not args.no_cpu_baseline:
             result["cpu_baseline"], oracle_meta = cpu_baseline(args, vid)

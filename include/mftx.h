@@ -50,9 +50,10 @@ const char *mftx_last_error_string(void);
  * roofline leg).  Categories: 0 corr volume GEMM, 1 pyramid pooling, 2 lookup,
  * 3 conv implicit GEMM, 4 convf1, 5 glue, 6 convex upsample, 7 chain/select,
  * 8 small-N conv, 9 encoder instance-norm passes, 10 lookup fused into convc1,
- * 11 convf1 + convf2 fused (the flow branch).
- * work[] = algorithmic flops (0, 3, 4, 8, 11) or bytes (1, 2, 6, 7, 9, 10) booked per launch. */
-#define MFTX_PROFILE_CATEGORIES 12
+ * 11 convf1 + convf2 fused (the flow branch), 12 the encoders' conv GEMMs (booked apart from 3), 13 a SepConvGRU pass as one
+ * kernel (mftx_gru_half).
+ * work[] = algorithmic flops (0, 3, 4, 8, 11, 12, 13) or bytes (1, 2, 6, 7, 9, 10) booked per launch. */
+#define MFTX_PROFILE_CATEGORIES 14
 int mftx_profile_begin(void);
 int mftx_profile_end(double *ms, double *work, long long *count, int n);
 

@@ -264,6 +264,7 @@ struct Enc {
         d.act = act; d.out_scale = 1.f;
         d.stride = stride; d.hin = hin; d.win = win;
         if (residual) { d.addend = residual; d.ld_addend = cout; d.residual_mode = 1; }
+        ProfConvCat cat(PC_ENC_GEMM);
         return launch_conv(d, s);
     }
     int norm(float *x, int rows, int C, int mode, const float *res = nullptr) {
@@ -352,6 +353,7 @@ extern "C" int mftx_encoder_forward(mftx_encoder *e, const uint8_t *img, int H0,
         d.out = E.ws.a; d.ldo = 64; d.P = 1; d.h = h1; d.w = w1; d.N = 64; d.kh = 7; d.kw = 1;
         d.act = e->instance_norm ? 0 : 1; d.out_scale = 1.f;
         d.stride = 2; d.hin = Hp; d.win = Wp + 6; d.pad_y = 3; d.pad_x = -1;
+        ProfConvCat cat(PC_ENC_GEMM);
         TRY(launch_conv(d, s));
     }
     if (e->instance_norm) TRY(E.norm(E.ws.a, h1 * w1, 64, 0));

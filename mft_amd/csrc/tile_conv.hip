@@ -661,7 +661,7 @@ static int gru_half_launch(GruHalfArgs a, hipStream_t s) {
             return fail(MFTX_E_STATE, "gru_half: cannot reserve %d bytes of LDS", lds_bytes);
         attr_set = true;
     }
-    ProfScope prof(PC_CONV_GEMM, s, 2.0 * a.P * a.h * a.w * 384.0 * KH * KW * 256);
+    ProfScope prof(PC_GRU_FUSED, s, 2.0 * a.P * a.h * a.w * 384.0 * KH * KW * 256);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds_bytes, s, a);
     return check_launch("gru_half");
 }

@@ -9,14 +9,27 @@ REPO = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(REPO))
 
 
-def test_profiled_traffic_reads_the_committed_pmc_summary():
+def test_profiled_traffic_is_tied_to_the_build(tmp_path):
+    """`roofline.traffic` comes from a rocprofv3 counter pass (tools/gpu_profile.sh -> profiles/*_pmc_hbm_traffic.csv); the file
+    names the build it was measured on and bench.py refuses it for any other (no stale counter files)."""
     import bench
+    mine = bench.build_hash()
+    assert mine and len(mine) == 16
+    body = ("# rocprofv3 ...\nkernel,launches,fetch_MB,fetch_x2_MB,write_MB\n"
+            '"mftx::conv_gemm_kernel<128, 192, 4, 2, 1, 32, 2, 3, 0>",24,20.0,40.0,22.0\n'
+            '"mftx::gru_half_kernel<2, 64, 1, 5>",24,30.0,60.0,18.0\n'
+            '"mftx::volume_tile_kernel",2,200.0,200.0,600.0\n')
+    (tmp_path / "r9z_pmc_hbm_traffic.csv").write_text(f"# build: {mine}  (sha256 ...)\n" + body)
+    traffic, source = bench.profiled_traffic(tmp_path)
+    assert abs(traffic - 70e6) < 1 and source.startswith("r9z_pmc_hbm_traffic.csv") and mine in source
+    (tmp_path / "r9z_pmc_hbm_traffic.csv").write_text("# build: 0123456789abcdef\n" + body)
+    traffic, source = bench.profiled_traffic(tmp_path)
+    assert traffic is None and "refused" in source
+    (tmp_path / "r9z_pmc_hbm_traffic.csv").write_text(body)              # a file from before the rule: no build line
+    assert bench.profiled_traffic(tmp_path)[0] is None
+    # the committed file parses (whether or not it belongs to the library built here)
     traffic, source = bench.profiled_traffic()
-    assert source.endswith("_pmc_hbm_traffic.csv") and (REPO / "profiles" / source).exists()
-    # conv GEMM launches move tens of MB each (fetch x2-corrected + write), never the volume's 0.9 GB
-    assert 2e7 < traffic < 3e8
-    text = (REPO / "profiles" / source).read_text()
-    assert "conv_gemm_kernel" in text and "fetch_x2_MB" in text
+    assert source and (traffic is None or 2e7 < traffic < 3e8)
 
 
 def test_cli_flags_of_the_driver_contract():

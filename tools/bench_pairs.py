@@ -20,7 +20,7 @@ from mft_amd.config import load_config  # noqa: E402
 from mft_amd.synth import SyntheticVideo  # noqa: E402
 
 CATS = ["corr_volume", "corr_pool", "lookup", "conv_gemm", "convf1", "glue", "upsample", "chain", "conv_small", "enc_norm",
-        "lookup_fused", "flow_fused"]
+        "lookup_fused", "flow_fused", "enc_gemm", "gru_fused"]
 
 
 def main():
@@ -70,7 +70,8 @@ def main():
         ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
         _lib.check(lib.mftx_profile_end(ms, work, cnt, n), "mftx_profile_end")
         parts = "  ".join(f"{CATS[i]} {ms[i] / a.reps:.2f}" for i in range(n) if cnt[i])
-        gemm_tf = work[3] / (ms[3] * 1e-3) / 1e12 if ms[3] else 0.0
+        gemm_ms = ms[3] + ms[13]
+        gemm_tf = (work[3] + work[13]) / (gemm_ms * 1e-3) / 1e12 if gemm_ms else 0.0
         launches = sum(cnt[i] for i in range(n)) // a.reps
         print(f"P={P}: wall {wall:.2f} ms ({wall / P:.2f} ms/pair)  kernels {sum(ms) / a.reps:.2f} ms in {launches} launches  "
               f"conv_gemm {gemm_tf:.1f} TFLOP/s\n      {parts}")
