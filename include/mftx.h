@@ -193,15 +193,18 @@ int mftx_tile_conv2d(const mftx_conv_desc *d, const void *wtile, void *stream);
  * context features' share of every gate sum and the biases arrive as pre-activation addends (they do not change over the
  * iterations: core/raft.py:146-149).  h_in / motion: split form, 128 channels each; wzr / wq: mftx_pack_tile_conv_weights
  * streams of the gates' columns for [h | motion] (N = 256 with z in channels 0..127, r in 128..255; N = 128), cin = 256, 5 taps;
- * pre_zr [M][256], pre_q [M][128], z [M][128] (scratch), hf [M][128] (h in fp32, updated in place); h_out: the new h in split
- * form -- a DIFFERENT buffer than h_in (a tile's halo cells are its neighbours' outputs).  Same bits as the two
- * mftx_tile_conv2d-style launches it replaces. */
+ * pre_zr [M][256], pre_q [M][128], z [M][128] (scratch), hf_in [M][128] (h in fp32); hf_out / h_out: the new h in fp32 and in split
+ * form -- DIFFERENT buffers than hf_in / h_in: a tile's halo cells are its neighbours' outputs, and with more tiles than CUs a late
+ * workgroup would otherwise read a halo that is already updated.  Same bits as the two mftx_tile_conv2d-style launches it
+ * replaces. */
 int mftx_gru_half(const float *h_in, int ld_hin, const float *motion, int ld_mo, const void *wzr, const void *wq, const float *pre_zr,
-                  const float *pre_q, float *z, float *hf, float *h_out, int ld_hout, int P, int h, int w, int pass, void *stream);
-/* 1 when the tile-resident kernels' tiles of 128 cells fill the current device for a batch of P pairs of h x w cells (rounds of the
- * chip at least 5/8 full, all three tile shapes) -- the rule MFTX_RAFT_OPT_TILE_CONV = 1 applies per call.  A caller that
- * needs a pair's result to be independent of the batch it is computed in (a tracker whose batches ramp up, ranks of a
- * sharded job) asks ONCE, for its nominal batch, and pins the option to 2 or 0 (mft_amd/raft.py does). */
+                  const float *pre_q, float *z, const float *hf_in, float *hf_out, float *h_out, int ld_hout, int P, int h, int w, int pass,
+                  void *stream);
+/* 1 when the tile-resident kernels fill the current device for a batch of P pairs of h x w cells: whole rounds of 128-cell tiles
+ * at least 5/8 full, or at least half a round of 32-cell tiles (the kernels come with 128, 64 or 32 cells per tile, picked per launch:
+ * the same bits).  The tile-resident and the ring-buffered kernels differ by fp32 rounding of the K sums, so a caller that needs a
+ * pair's result to be independent of the batch it is computed in (a tracker whose batches ramp up, ranks of a sharded job) asks
+ * ONCE, for its nominal batch, and pins MFTX_RAFT_OPT_TILE_CONV to 2 or 0 (mft_amd/raft.py does). */
 int mftx_tile_conv_fills_chip(int P, int h, int w);
 /* The flow head (core/update.py:6-14: delta = conv2(relu(conv1(h))), 3 x 3, 128 -> 256 -> 2) without materialising the 256
  * hidden channels: the tile-resident kernel keeps relu(conv1) of a tile in LDS and multiplies it there with conv2's filter
@@ -287,7 +290,9 @@ int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
  *   MFTX_RAFT_OPT_TILE_VOLUME 1 default (split arithmetic: the correlation volume by the tile-resident kernel, csrc/volume_tile.hip),
  *                            0 the ring-buffered GEMM
  *   MFTX_RAFT_OPT_FUSE_GRU   1 default (where the tile-resident layers run: each SepConvGRU pass as ONE kernel, mftx_gru_half), 0 z | r
- *                            gates and candidate + blend as two tile-resident launches.  Same bits either way. */
+ *                            gates and candidate + blend as two tile-resident launches.  Same bits either way.
+ *   MFTX_RAFT_OPT_TILE_CELLS 0 default (cells per tile of the tile-resident kernels by how the tiles fill the chip: 128, else 64, else
+ *                            32), or 128 / 64 / 32 forced.  Same bits whatever the value: a smaller tile is fewer MFMA row tiles per wave. */
 #define MFTX_RAFT_OPT_FORK 0
 #define MFTX_RAFT_OPT_PRESPLIT 1
 #define MFTX_RAFT_OPT_GROUP 2
@@ -298,6 +303,7 @@ int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
 #define MFTX_RAFT_OPT_FUSE_HEAD 7
 #define MFTX_RAFT_OPT_TILE_VOLUME 8
 #define MFTX_RAFT_OPT_FUSE_GRU 9
+#define MFTX_RAFT_OPT_TILE_CELLS 10
 int mftx_raft_set_option(mftx_raft *r, int option, int value);
 /* A device-resident counter (4 bytes, zeroed by the caller) that the last kernel of every mftx_raft_refine* call increments
  * by the number of output pixels with a non-finite flow / occlusion / sigma; null switches it off.  The reference has no

@@ -67,7 +67,7 @@ SIGNATURES = {
     "mftx_raft_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "mftx_raft_set_coords_trace": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mftx_gru_half": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                                C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mftx_tile_conv_fills_chip": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "mftx_raft_clear_graphs": (C.c_int, [C.c_void_p]),
     "mftx_raft_set_nonfinite_counter": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -171,19 +171,23 @@ struct TileConvLaunch {
     float *z, *rh, *hf, *hx; int ld_hf, ld_hx;      // epi 2 (z | r gates) / 3 (candidate + blend): as GruEpilogue
     const void *wproj; float *tout;     // epi 4 (flow head: relu, then the next layer's 3 x 3 x 2 filter as [256 x 18] partial products -> tout [M][18])
     int P, h, w, N, kh, kw, epi;
+    int cells;                          // cells per tile: 128, 64, 32; 0: by how the tiles fill the chip (same bits either way)
 };
 // one SepConvGRU pass as one kernel (tile_conv.hip: gru_half_kernel); pass 0: 1 x 5, pass 1: 5 x 1
 struct GruHalfLaunch {
     const float *h_in; int ld_hin; const float *mo; int ld_mo;      // h and the motion features, split form, 128 channels each
     const void *wzr, *wq;                                           // launch_pack_tile_conv streams (N = 256 / 128, cin = 256)
     const float *pre_zr, *pre_q;                                    // context parts + bias [M][256] / [M][128]
-    float *z, *hf, *h_out; int ld_hout;                             // z scratch [M][128]; fp32 h [M][128] in place; new h in split form
+    float *z; const float *hf_in; float *hf_out;                    // z scratch [M][128]; h in fp32 [M][128]: read here, written there
+    float *h_out; int ld_hout;                                      // new h in split form (a different buffer than h_in)
     int P, h, w, pass;
+    int cells;                                                      // R cells per tile: 128, 64, 32; 0: by how the tiles fill the chip
 };
 int launch_gru_half(const GruHalfLaunch &d, hipStream_t s);
 int launch_pack_flow_head(const float *w2pk, void *out, hipStream_t s);
 int launch_flow_head_sum(const float *T, const float *b2, float *delta, const float *coords_in, float *coords_out, int P, int h, int w, hipStream_t s);
 bool tile_conv_applicable(int kh, int kw, int cin, int N);
+bool tile_conv_small_tiles_fill(int P, int h, int w);               // at least half a round of the chip in 32-cell tiles
 bool tile_conv_fills_chip(int P, int h, int w, int kh, int kw);     // its tiles come in rounds of the chip that are >= 5/8 full
 int launch_pack_tile_conv(const float *wpk, int N, int taps, int cin, int cin_pad, void *out, hipStream_t s);
 int launch_tile_conv(const TileConvLaunch &d, hipStream_t s);

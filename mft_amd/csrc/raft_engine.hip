@@ -134,7 +134,7 @@ struct Workspace {
     float *pre_zr[2], *pre_q[2];   // inp part of the GRU gate convolutions (+ bias), per pass
     float *f2s;                    // split form of fmap2 (B operand of the volume GEMM in split arithmetic)
     float *hf;                     // split arithmetic: fp32 copy of h [M][128] (hx itself is in split form)
-    float *hb;                     // split arithmetic: h between the two passes of the fused GRU kernel [M][128], split form
+    float *hb, *hfb;               // split arithmetic: h between the two passes of the fused GRU kernel [M][128]: split form, fp32
     int ld_corr;                   // 324: the lookup's features stay fp32 (the lookup is HBM-bound; convc1 splits them in registers)
     size_t bytes;
 };
@@ -171,6 +171,7 @@ static Workspace carve(void *base, int P, int h, int w, bool ondemand = false, b
     ws.f2s = take(ondemand || !split ? 0 : M * 256);
     ws.hf = take(split ? M * 128 : 0);
     ws.hb = take(split ? M * 128 : 0);
+    ws.hfb = take(split ? M * 128 : 0);
     ws.bytes = off;
     return ws;
 }
@@ -194,7 +195,7 @@ struct mftx_raft {
     const void *wflow;             // convf1's and convf2's weights for the fused flow-branch kernel (csrc/flow_branch.hip), or null
     const void *wproj;             // the flow head's last layer as the projection epilogue of its first (csrc/tile_conv.hip: TC_RELU_PROJ), or null
     const void *wt[W_COUNT];       // weight streams of the tile-resident conv kernel (csrc/tile_conv.hip) per slot, or null
-    int opt[10];                   // MFTX_RAFT_OPT_*
+    int opt[11];                   // MFTX_RAFT_OPT_*
     unsigned *nonfinite;           // device counter of non-finite output pixels (mftx_raft_set_nonfinite_counter), or null
 };
 // weights that go through the conv GEMM (the others feed VALU kernels and stay fp32)
@@ -222,7 +223,7 @@ extern "C" int mftx_raft_create(const float *const *weights, int n_weights, mftx
     r->coords_trace = nullptr;
     r->nonfinite = nullptr;
     r->graphs = new (std::nothrow) GraphCache;
-    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1; r->opt[MFTX_RAFT_OPT_FUSE_FLOW] = 1; r->opt[MFTX_RAFT_OPT_TILE_CONV] = 1; r->opt[MFTX_RAFT_OPT_FUSE_HEAD] = 1; r->opt[MFTX_RAFT_OPT_TILE_VOLUME] = 1; r->opt[MFTX_RAFT_OPT_FUSE_GRU] = 1;
+    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1; r->opt[MFTX_RAFT_OPT_FUSE_FLOW] = 1; r->opt[MFTX_RAFT_OPT_TILE_CONV] = 1; r->opt[MFTX_RAFT_OPT_FUSE_HEAD] = 1; r->opt[MFTX_RAFT_OPT_TILE_VOLUME] = 1; r->opt[MFTX_RAFT_OPT_FUSE_GRU] = 1; r->opt[MFTX_RAFT_OPT_TILE_CELLS] = 0;
     for (int i = 0; i < W_COUNT; ++i) r->w[i] = r->wg[i] = weights[i];
     *out = r;
     return 0;
@@ -336,7 +337,7 @@ extern "C" int mftx_raft_set_nonfinite_counter(mftx_raft *r, unsigned *counter) 
 
 extern "C" int mftx_raft_set_option(mftx_raft *r, int option, int value) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_option: bad handle");
-    if (option < 0 || option > MFTX_RAFT_OPT_FUSE_GRU) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
+    if (option < 0 || option > MFTX_RAFT_OPT_TILE_CELLS) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
     r->opt[option] = value;
     if (r->graphs) r->graphs->clear();
     return 0;
@@ -475,6 +476,7 @@ static int refine_impl(mftx_raft *r, int P, int h, int w, int iters, const float
         TileConvLaunch t{};
         t.a0 = a0; t.lda0 = lda0; t.a1 = a1; t.lda1 = lda1; t.cin = a1 ? 256 : 128; t.wf = wf; t.bias = bias;
         t.P = P; t.h = h; t.w = w; t.N = N; t.kh = kh; t.kw = kw; t.epi = epi;
+        t.cells = r->opt[MFTX_RAFT_OPT_TILE_CELLS];
         return t;
     };
     for (int pass = 0; pass < 2; ++pass) {
@@ -594,7 +596,7 @@ static int refine_impl(mftx_raft *r, int P, int h, int w, int iters, const float
                 GruHalfLaunch g{};
                 g.h_in = pass ? ws.hb : ws.hx; g.ld_hin = pass ? 128 : 384; g.h_out = pass ? ws.hx : ws.hb; g.ld_hout = pass ? 384 : 128;
                 g.mo = ws.hx + 256; g.ld_mo = 384; g.wzr = tile_w(szr); g.wq = tile_w(sq); g.pre_zr = ws.pre_zr[pass]; g.pre_q = ws.pre_q[pass];
-                g.z = ws.z; g.hf = ws.hf; g.P = P; g.h = h; g.w = w; g.pass = pass;
+                g.z = ws.z; g.hf_in = pass ? ws.hfb : ws.hf; g.hf_out = pass ? ws.hf : ws.hfb; g.P = P; g.h = h; g.w = w; g.pass = pass; g.cells = r->opt[MFTX_RAFT_OPT_TILE_CELLS];
                 TRY(launch_gru_half(g, s));
                 continue;
             }
@@ -805,16 +807,20 @@ extern "C" int mftx_tile_conv2d(const mftx_conv_desc *d, const void *wtile, void
 }
 
 extern "C" int mftx_gru_half(const float *h_in, int ld_hin, const float *motion, int ld_mo, const void *wzr, const void *wq, const float *pre_zr,
-                             const float *pre_q, float *z, float *hf, float *h_out, int ld_hout, int P, int h, int w, int pass, void *stream) {
+                             const float *pre_q, float *z, const float *hf_in, float *hf_out, float *h_out, int ld_hout, int P, int h, int w, int pass,
+                             void *stream) {
     GruHalfLaunch g{};
     g.h_in = h_in; g.ld_hin = ld_hin; g.mo = motion; g.ld_mo = ld_mo; g.wzr = wzr; g.wq = wq; g.pre_zr = pre_zr; g.pre_q = pre_q;
-    g.z = z; g.hf = hf; g.h_out = h_out; g.ld_hout = ld_hout; g.P = P; g.h = h; g.w = w; g.pass = pass;
+    g.z = z; g.hf_in = hf_in; g.hf_out = hf_out; g.h_out = h_out; g.ld_hout = ld_hout; g.P = P; g.h = h; g.w = w; g.pass = pass;
     return launch_gru_half(g, (hipStream_t)stream);
 }
 
 extern "C" int mftx_tile_conv_fills_chip(int P, int h, int w) {
     if (P <= 0 || h <= 0 || w <= 0) return 0;
-    return tile_conv_fills_chip(P, h, w, 3, 3) && tile_conv_fills_chip(P, h, w, 1, 5) && tile_conv_fills_chip(P, h, w, 5, 1) ? 1 : 0;
+    // (round 4) the tile-resident kernels come with 128, 64 or 32 cells per tile -- the same bits --, so "fills the chip" is asked of the
+    // smallest: at least half a round of 32-cell tiles (7 pairs of 256 x 256 pixels: 224 tiles, + 9 % frames/s over the ring-buffered
+    // kernels; one pair of 512 x 512: 128 tiles, 2.38 vs 2.46 ms per refinement)
+    return tile_conv_fills_chip(P, h, w, 3, 3) || tile_conv_small_tiles_fill(P, h, w) ? 1 : 0;
 }
 
 extern "C" int mftx_pack_flow_head_weights(const float *w2pk, void *wproj, void *stream) {

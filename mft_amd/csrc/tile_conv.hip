@@ -114,16 +114,17 @@ __device__ __forceinline__ float tc_blend(float z, float h, float q) { return __
 
 template <int TH, int TW, int KH, int KW, int CIN, int N>
 struct TcGeom {
+    static constexpr int CELLS = TH * TW, RT = CELLS / 32;  // output cells of a tile: 128, or 64 / 32 where 128-cell tiles would leave the chip empty; MFMA row tiles per wave
     static constexpr int HH = TH + KH - 1, HWD = TW + KW - 1, HCELLS = HH * HWD;
     static constexpr int CELLB = CIN * 4 + 16;              // consecutive cells start an odd number of 16-byte slots apart
     static constexpr int NT = N / 32, KS = 8 / NT;          // column tiles; K splits (waves per column tile)
     static constexpr int CG = CIN / 16, GPW = CG / KS;      // channel groups per tap; of them per wave
     static constexpr int STEPS = KH * KW * GPW;             // 16-wide k groups per wave
     static constexpr int RED_ROW = N + 4;                   // floats per cell of the parked sums
-    static constexpr int A_BYTES = HCELLS * CELLB, RED_BYTES = KS * 128 * RED_ROW * 4;
+    static constexpr int A_BYTES = HCELLS * CELLB, RED_BYTES = KS * CELLS * RED_ROW * 4;
     static constexpr int LDS = A_BYTES > RED_BYTES ? A_BYTES : RED_BYTES;
-    static constexpr int PROJ_ROW = 20, PROJ_BYTES = 2 * 128 * PROJ_ROW * 4;        // TC_RELU_PROJ: two K halves of [cell][18 (+ 2)] behind the parked sums
-    static_assert(TH * TW == 128 && (N == 128 || N == 256) && (CIN == 128 || CIN == 256), "tile_conv: shapes");
+    static constexpr int PROJ_ROW = 20, PROJ_BYTES = 2 * CELLS * PROJ_ROW * 4;        // TC_RELU_PROJ: two K halves of [cell][18 (+ 2)] behind the parked sums
+    static_assert((CELLS == 128 || CELLS == 64 || CELLS == 32) && (N == 128 || N == 256) && (CIN == 128 || CIN == 256), "tile_conv: shapes");
     static_assert(LDS <= 160 * 1024, "tile_conv: the input tile must fit the CU's LDS");
 };
 
@@ -188,26 +189,26 @@ __global__ __launch_bounds__(512, 2) void tile_conv_kernel(TileConvArgs p) {
     TC_T(3);
 
     // ---- the K loop
-    tc_f32x16 acc[4], accx[4];
+    tc_f32x16 acc[G::RT], accx[G::RT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < G::RT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accx[i][r] = 0.f; }
-    const unsigned char *abase[4];
+    const unsigned char *abase[G::RT];
     {
         const int r = lane & 31;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < G::RT; ++i) {
             const int m = 32 * i + r;
             abase[i] = lds + ((m / TW) * G::HWD + (m % TW)) * G::CELLB + (lane >> 5) * 32 + ks * 64;
         }
     }
-    tc_f16x8 ah[2][4], al[2][4];
+    tc_f16x8 ah[2][G::RT], al[2][G::RT];
     auto read_a = [&](int s, int set) {
         const int tap = s / G::GPW, gg = s % G::GPW;
         const int off = ((tap / KW) * G::HWD + tap % KW) * G::CELLB + gg * 64 * G::KS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < G::RT; ++i) {
             ah[set][i] = *reinterpret_cast<const tc_f16x8 *>(abase[i] + off);
             al[set][i] = *reinterpret_cast<const tc_f16x8 *>(abase[i] + off + 16);
         }
@@ -222,11 +223,11 @@ __global__ __launch_bounds__(512, 2) void tile_conv_kernel(TileConvArgs p) {
         if (s + PF < G::STEPS) { bq[s % PF][0] = w2[(s + PF) * 128]; bq[s % PF][1] = w2[(s + PF) * 128 + 64]; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = tc_mfma(bh, ah[set][i], acc[i]);
+        for (int i = 0; i < G::RT; ++i) acc[i] = tc_mfma(bh, ah[set][i], acc[i]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) accx[i] = tc_mfma(bl, ah[set][i], accx[i]);
+        for (int i = 0; i < G::RT; ++i) accx[i] = tc_mfma(bl, ah[set][i], accx[i]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) accx[i] = tc_mfma(bh, al[set][i], accx[i]);
+        for (int i = 0; i < G::RT; ++i) accx[i] = tc_mfma(bh, al[set][i], accx[i]);
         __builtin_amdgcn_sched_barrier(0);
     }
     TC_T(4);
@@ -237,13 +238,13 @@ __global__ __launch_bounds__(512, 2) void tile_conv_kernel(TileConvArgs p) {
     const float inv2048 = 1.f / 2048.f;
     float *red = reinterpret_cast<float *>(lds);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < G::RT; ++i)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             tc_f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * b + e] + accx[i][4 * b + e] * inv2048;
-            *reinterpret_cast<tc_f32x4 *>(red + (ks * 128 + 32 * i + (lane & 31)) * G::RED_ROW + 32 * nt + 8 * b + 4 * (lane >> 5)) = v;
+            *reinterpret_cast<tc_f32x4 *>(red + (ks * G::CELLS + 32 * i + (lane & 31)) * G::RED_ROW + 32 * nt + 8 * b + 4 * (lane >> 5)) = v;
         }
     TC_T(6);
     tc_barrier();
@@ -258,8 +259,10 @@ __global__ __launch_bounds__(512, 2) void tile_conv_kernel(TileConvArgs p) {
         // never stored: the tile's [128 cells x 256] block, parked in LDS, is multiplied here with W2 as a [256 x 18] matrix
         // (split arithmetic; 192 more MFMAs after the layer's 6912) and only T leaves (2 MB); flow_head_sum_kernel adds the
         // nine shifted terms.  Wave (row tile mt, K half kh): 8 k groups; the halves meet in LDS, summed in a fixed order.
-        const int mt = wv & 3, kh = wv >> 2;
+        const int mt = wv & 3, kh = wv >> 2;         // (tiles of fewer than 128 cells: the waves of the missing row tiles only keep the barriers)
         const uint4 *__restrict__ wp = reinterpret_cast<const uint4 *>(p.wproj) + lane;
+        float *tp = reinterpret_cast<float *>(lds + G::RED_BYTES);
+        if (mt < G::RT) {
         tc_f32x16 d, dx;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { d[r] = 0.f; dx[r] = 0.f; }
@@ -281,7 +284,6 @@ __global__ __launch_bounds__(512, 2) void tile_conv_kernel(TileConvArgs p) {
             dx = tc_mfma(wl, xh, dx);
             dx = tc_mfma(wh, xl, dx);
         }
-        float *tp = reinterpret_cast<float *>(lds + G::RED_BYTES);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int j0 = 8 * b + 4 * (lane >> 5);          // this lane's outputs j0 .. j0 + 3 of cell 32 mt + (lane & 31); 18 exist
@@ -289,15 +291,16 @@ __global__ __launch_bounds__(512, 2) void tile_conv_kernel(TileConvArgs p) {
                 tc_f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = d[4 * b + e] + dx[4 * b + e] * inv2048;
-                *reinterpret_cast<tc_f32x4 *>(tp + (kh * 128 + 32 * mt + (lane & 31)) * G::PROJ_ROW + j0) = v;
+                *reinterpret_cast<tc_f32x4 *>(tp + (kh * G::CELLS + 32 * mt + (lane & 31)) * G::PROJ_ROW + j0) = v;
             }
         }
+        }
         tc_barrier();
-        for (int idx = tid; idx < 128 * 18; idx += 512) {
+        for (int idx = tid; idx < G::CELLS * 18; idx += 512) {
             const int m = idx / 18, j = idx - m * 18;
             const int yy = y0 + m / TW, xx = x0 + m % TW;
             if (yy < p.h && xx < p.w)
-                p.tout[(img_base + (long long)yy * p.w + xx) * 18 + j] = tp[m * G::PROJ_ROW + j] + tp[(128 + m) * G::PROJ_ROW + j];
+                p.tout[(img_base + (long long)yy * p.w + xx) * 18 + j] = tp[m * G::PROJ_ROW + j] + tp[(G::CELLS + m) * G::PROJ_ROW + j];
         }
         TC_T(8);
         TC_CLK(1);
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void tile_conv_kernel(TileConvArgs p) {
     }
 
     // ---- row-wise epilogue: 8 consecutive channels of a cell per lane
-    constexpr int GPC = N / 8, ITEMS = 128 * GPC;
+    constexpr int GPC = N / 8, ITEMS = G::CELLS * GPC;
 #pragma unroll
     for (int it = 0; it < ITEMS / 512; ++it) {
         const int item = tid + 512 * it, m = item / GPC, n0 = (item % GPC) * 8;
@@ -313,8 +316,8 @@ __global__ __launch_bounds__(512, 2) void tile_conv_kernel(TileConvArgs p) {
         const float *src = red + m * G::RED_ROW + n0;
         tc_f32x4 u = *reinterpret_cast<const tc_f32x4 *>(src), v = *reinterpret_cast<const tc_f32x4 *>(src + 4);
         if constexpr (G::KS == 2) {
-            u += *reinterpret_cast<const tc_f32x4 *>(src + 128 * G::RED_ROW);
-            v += *reinterpret_cast<const tc_f32x4 *>(src + 128 * G::RED_ROW + 4);
+            u += *reinterpret_cast<const tc_f32x4 *>(src + G::CELLS * G::RED_ROW);
+            v += *reinterpret_cast<const tc_f32x4 *>(src + G::CELLS * G::RED_ROW + 4);
         }
         if (yy >= p.h || xx >= p.w) continue;
         const long long cell = img_base + (long long)yy * p.w + xx;
@@ -391,7 +394,8 @@ extern "C" int mftx_debug_tc_trace(unsigned long long *out) {
 //             where the gates are evaluated; cells within 2 of an R edge that is not an image border are evaluated for their
 //             neighbours' sake only, their own new h comes from the adjacent tile (tiles advance by TW - 4 along the pass; a
 //             tile that spans the whole image width -- 64 cells at 512 x 512 -- recomputes nothing);
-//   h         is read from one buffer and written to another (h_in / h_out): a workgroup's halo cells are its neighbours' outputs;
+//   h         is read from one buffer and written to another (h_in / h_out, hf_in / hf_out): a workgroup's halo cells are its neighbours'
+//             outputs, and with more tiles than CUs a late workgroup would find its halo already updated;
 //   z         goes through global memory (64 KB per tile, written and read by the same workgroup: L2) -- LDS is full;
 //   sums      every output is the same sequence of products and sums as in the two kernels this replaces: same bits.
 struct GruHalfArgs {
@@ -400,21 +404,21 @@ struct GruHalfArgs {
     const void *wzr, *wq;               // mftx_pack_tile_conv_weights streams: [z | r] (N = 256) and q (N = 128), cin = 256
     const float *pre_zr, *pre_q;        // the gates' context parts + bias (pre-activation addends): [M][256], [M][128]
     float *z;                           // scratch [M][128]
-    float *hf;                          // h in fp32 [M][128], updated in place
+    const float *hf_in; float *hf_out;  // h in fp32 [M][128]: read from one buffer, written to another, like the split form
     float *h_out; int ld_hout;          // new h, split form
     int P, h, w, tiles_x, tiles_y, step;
 };
 
 template <class G, int KW>
-__device__ __forceinline__ void tc_kloop(const unsigned char *const (&abase)[4], const uint4 *__restrict__ w2, uint4 (&bq)[3][2],
-                                         tc_f32x16 (&acc)[4], tc_f32x16 (&accx)[4]) {
+__device__ __forceinline__ void tc_kloop(const unsigned char *const (&abase)[G::RT], const uint4 *__restrict__ w2, uint4 (&bq)[3][2],
+                                         tc_f32x16 (&acc)[G::RT], tc_f32x16 (&accx)[G::RT]) {
     constexpr int PF = 3;
-    tc_f16x8 ah[2][4], al[2][4];
+    tc_f16x8 ah[2][G::RT], al[2][G::RT];
     auto read_a = [&](int s, int set) {
         const int tap = s / G::GPW, gg = s % G::GPW;
         const int off = ((tap / KW) * G::HWD + tap % KW) * G::CELLB + gg * 64 * G::KS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < G::RT; ++i) {
             ah[set][i] = *reinterpret_cast<const tc_f16x8 *>(abase[i] + off);
             al[set][i] = *reinterpret_cast<const tc_f16x8 *>(abase[i] + off + 16);
         }
@@ -429,11 +433,11 @@ __device__ __forceinline__ void tc_kloop(const unsigned char *const (&abase)[4],
         if (s + PF < G::STEPS) { bq[s % PF][0] = w2[(s + PF) * 128]; bq[s % PF][1] = w2[(s + PF) * 128 + 64]; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = tc_mfma(bh, ah[set][i], acc[i]);
+        for (int i = 0; i < G::RT; ++i) acc[i] = tc_mfma(bh, ah[set][i], acc[i]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) accx[i] = tc_mfma(bl, ah[set][i], accx[i]);
+        for (int i = 0; i < G::RT; ++i) accx[i] = tc_mfma(bl, ah[set][i], accx[i]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) accx[i] = tc_mfma(bh, al[set][i], accx[i]);
+        for (int i = 0; i < G::RT; ++i) accx[i] = tc_mfma(bh, al[set][i], accx[i]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(512, 2) void gru_half_kernel(GruHalfArgs p) {
     using G1 = TcGeom<TH, TW, KH, KW, 256, 256>;            // the gates: wave = one 32-channel column tile of [z | r], all of K
     using G2 = TcGeom<TH, TW, KH, KW, 256, 128>;            // the candidate: wave = (column tile, K half)
     static_assert(G1::CELLB == G2::CELLB && G1::HWD == G2::HWD, "one tile, two GEMMs");
-    constexpr int CELLB = G1::CELLB, HWD = G1::HWD, PF = 3;
+    constexpr int CELLB = G1::CELLB, HWD = G1::HWD, PF = 3, RT = G1::RT, CELLS = G1::CELLS;
     constexpr bool HORIZ = KW > 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char tc_lds[];
     unsigned char *lds = tc_lds;
@@ -504,18 +508,18 @@ __global__ __launch_bounds__(512, 2) void gru_half_kernel(GruHalfArgs p) {
     tc_barrier();
     TC_T(3);
 
-    tc_f32x16 acc[4], accx[4];
-    const unsigned char *abase[4];
+    tc_f32x16 acc[RT], accx[RT];
+    const unsigned char *abase[RT];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accx[i][r] = 0.f; }
     };
     auto set_abase = [&](int ks) {
         const int r = lane & 31;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < RT; ++i) {
             const int m = 32 * i + r;
             abase[i] = lds + ((m / TW) * HWD + (m % TW)) * CELLB + (lane >> 5) * 32 + ks * 64;
         }
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void gru_half_kernel(GruHalfArgs p) {
     // four waves' sums (channels 32 c .. 32 c + 31 of 128, all R cells) -> the R cells' h slots, fp32 [cell][128]
     auto park128 = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < RT; ++i)
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 tc_f32x4 v;
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(512, 2) void gru_half_kernel(GruHalfArgs p) {
     tc_barrier();
     // z = sigmoid(. + context part): row-wise, 8 consecutive channels of a cell per lane -> global (this workgroup reads it back)
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < RT; ++it) {
         const int item = tid + 512 * it, m = item >> 4, n0 = (item & 15) * 8;
         const int yy = y0 + m / TW, xx = x0 + m % TW, along = HORIZ ? xx : yy;
         const float *src = reinterpret_cast<const float *>(slot(m)) + n0;
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(512, 2) void gru_half_kernel(GruHalfArgs p) {
     tc_barrier();
     // r * h, in place: the sums of 8 channels become their split form (zero outside the image: the candidate's zero padding)
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < RT; ++it) {
         const int item = tid + 512 * it, m = item >> 4, n0 = (item & 15) * 8;
         const int yy = y0 + m / TW, xx = x0 + m % TW;
         float *src = reinterpret_cast<float *>(slot(m)) + n0;
@@ -581,8 +585,8 @@ __global__ __launch_bounds__(512, 2) void gru_half_kernel(GruHalfArgs p) {
             v += *reinterpret_cast<const tc_f32x4 *>(p.pre_zr + cell * 256 + 128 + n0 + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { u[e] = tc_sigmoid(u[e]); v[e] = tc_sigmoid(v[e]); }
-            u *= *reinterpret_cast<const tc_f32x4 *>(p.hf + cell * 128 + n0);
-            v *= *reinterpret_cast<const tc_f32x4 *>(p.hf + cell * 128 + n0 + 4);
+            u *= *reinterpret_cast<const tc_f32x4 *>(p.hf_in + cell * 128 + n0);
+            v *= *reinterpret_cast<const tc_f32x4 *>(p.hf_in + cell * 128 + n0 + 4);
             tc_split8(u, v, k2048, hi, lo);
         }
         *reinterpret_cast<tc_u32x4 *>(src) = hi;
@@ -601,35 +605,35 @@ __global__ __launch_bounds__(512, 2) void gru_half_kernel(GruHalfArgs p) {
     tc_barrier();           // every wave is done with the tile: its space takes the sums
     float *red = reinterpret_cast<float *>(lds);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             tc_f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * b + e] + accx[i][4 * b + e] * inv2048;
-            *reinterpret_cast<tc_f32x4 *>(red + (ks2 * 128 + 32 * i + (lane & 31)) * G2::RED_ROW + 32 * nt2 + 8 * b + 4 * (lane >> 5)) = v;
+            *reinterpret_cast<tc_f32x4 *>(red + (ks2 * CELLS + 32 * i + (lane & 31)) * G2::RED_ROW + 32 * nt2 + 8 * b + 4 * (lane >> 5)) = v;
         }
     tc_barrier();
     // q = tanh(. + context part), h <- (1 - z) h + z q (core/update.py:116-117, 122-123): the cells this workgroup owns
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < RT; ++it) {
         const int item = tid + 512 * it, m = item >> 4, n0 = (item & 15) * 8;
         const int yy = y0 + m / TW, xx = x0 + m % TW, along = HORIZ ? xx : yy;
         const float *src = red + m * G2::RED_ROW + n0;
         tc_f32x4 u = *reinterpret_cast<const tc_f32x4 *>(src), v = *reinterpret_cast<const tc_f32x4 *>(src + 4);
-        u += *reinterpret_cast<const tc_f32x4 *>(src + 128 * G2::RED_ROW);
-        v += *reinterpret_cast<const tc_f32x4 *>(src + 128 * G2::RED_ROW + 4);
+        u += *reinterpret_cast<const tc_f32x4 *>(src + CELLS * G2::RED_ROW);
+        v += *reinterpret_cast<const tc_f32x4 *>(src + CELLS * G2::RED_ROW + 4);
         if (yy < 0 || yy >= p.h || xx < 0 || xx >= p.w || along < olo || along >= ohi) continue;
         const long long cell = img_base + (long long)yy * p.w + xx;
         u += *reinterpret_cast<const tc_f32x4 *>(p.pre_q + cell * 128 + n0);
         v += *reinterpret_cast<const tc_f32x4 *>(p.pre_q + cell * 128 + n0 + 4);
         const tc_f32x4 z0 = *reinterpret_cast<const tc_f32x4 *>(p.z + cell * 128 + n0), z1 = *reinterpret_cast<const tc_f32x4 *>(p.z + cell * 128 + n0 + 4);
-        float *hrow = p.hf + cell * 128 + n0;
+        const float *hrow = p.hf_in + cell * 128 + n0;
         const tc_f32x4 h0 = *reinterpret_cast<const tc_f32x4 *>(hrow), h1 = *reinterpret_cast<const tc_f32x4 *>(hrow + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { u[e] = tc_blend(z0[e], h0[e], tc_tanh(u[e])); v[e] = tc_blend(z1[e], h1[e], tc_tanh(v[e])); }
-        *reinterpret_cast<tc_f32x4 *>(hrow) = u;
-        *reinterpret_cast<tc_f32x4 *>(hrow + 4) = v;
+        *reinterpret_cast<tc_f32x4 *>(p.hf_out + cell * 128 + n0) = u;
+        *reinterpret_cast<tc_f32x4 *>(p.hf_out + cell * 128 + n0 + 4) = v;
         tc_u32x4 hi, lo;
         tc_split8(u, v, k2048, hi, lo);
         uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(p.h_out + cell * p.ld_hout) + (n0 >> 3) * 32);
@@ -666,31 +670,49 @@ static int gru_half_launch(GruHalfArgs a, hipStream_t s) {
     return check_launch("gru_half");
 }
 
+static int tc_num_cus();
+static bool tc_fills(long long tiles);
 // tiles of the fused kernel for a pass over P maps of h x w cells with R tiles of th x tw cells
-static long long gru_half_tiles(int P, int h, int w, int th, int tw, bool horiz) {
+long long gru_half_tiles(int P, int h, int w, int th, int tw, bool horiz) {
     const int along = horiz ? w : h, T = horiz ? tw : th;
     const int n_along = along <= T ? 1 : cdiv(along, T - 4);
     return (long long)P * (horiz ? n_along * cdiv(h, th) : n_along * cdiv(w, tw));
 }
 
 int launch_gru_half(const GruHalfLaunch &d, hipStream_t s) {
-    if (!d.h_in || !d.mo || !d.wzr || !d.wq || !d.pre_zr || !d.pre_q || !d.z || !d.hf || !d.h_out) return fail(MFTX_E_ARG, "gru_half: null pointer");
+    if (!d.h_in || !d.mo || !d.wzr || !d.wq || !d.pre_zr || !d.pre_q || !d.z || !d.hf_in || !d.hf_out || !d.h_out) return fail(MFTX_E_ARG, "gru_half: null pointer");
     if (d.P <= 0 || d.h <= 0 || d.w <= 0 || (d.pass != 0 && d.pass != 1)) return fail(MFTX_E_ARG, "gru_half: bad sizes");
-    if (d.h_in == d.h_out) return fail(MFTX_E_ARG, "gru_half: h is read from one buffer and written to another");
+    if (d.h_in == d.h_out || d.hf_in == d.hf_out) return fail(MFTX_E_ARG, "gru_half: h is read from one buffer and written to another");
     auto bad_split = [](const float *p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 31) != 0 || (ld % 8) != 0; };
     if (bad_split(d.h_in, d.ld_hin) || bad_split(d.mo, d.ld_mo) || bad_split(d.h_out, d.ld_hout) || !aligned16(d.wzr) || !aligned16(d.wq) ||
-        !aligned16(d.pre_zr) || !aligned16(d.pre_q) || !aligned16(d.z) || !aligned16(d.hf))
+        !aligned16(d.pre_zr) || !aligned16(d.pre_q) || !aligned16(d.z) || !aligned16(d.hf_in) || !aligned16(d.hf_out))
         return fail(MFTX_E_ALIGN, "gru_half: split-form rows are 32-byte aligned with strides in multiples of 8; the rest 16-byte aligned");
     GruHalfArgs a{};
     a.h_in = d.h_in; a.ld_hin = d.ld_hin; a.mo = d.mo; a.ld_mo = d.ld_mo; a.wzr = d.wzr; a.wq = d.wq; a.pre_zr = d.pre_zr; a.pre_q = d.pre_q;
-    a.z = d.z; a.hf = d.hf; a.h_out = d.h_out; a.ld_hout = d.ld_hout; a.P = d.P; a.h = d.h; a.w = d.w;
-    // R tiles of 2 x 64 cells (a 64-wide map is one tile per row pair: nothing is recomputed) or 4 x 32: whichever needs fewer
-    if (d.pass == 0) {
-        if (gru_half_tiles(d.P, d.h, d.w, 2, 64, true) <= gru_half_tiles(d.P, d.h, d.w, 4, 32, true)) return gru_half_launch<2, 64, 1, 5>(a, s);
-        return gru_half_launch<4, 32, 1, 5>(a, s);
+    a.z = d.z; a.hf_in = d.hf_in; a.hf_out = d.hf_out; a.h_out = d.h_out; a.ld_hout = d.ld_hout; a.P = d.P; a.h = d.h; a.w = d.w;
+    // R tiles of 128 cells where they fill the chip -- 2 x 64 (a 64-wide map is one tile per row pair: nothing is recomputed) or
+    // 4 x 32, whichever needs fewer workgroups --, else of 64 or 32 cells: the same kernel with fewer row tiles per wave, the same bits
+    const bool hz = d.pass == 0;
+    auto best = [&](int cells, int &th, int &tw) {
+        const int ta = hz ? cells / 64 : 64, tb = hz ? 64 : cells / 64;          // long tiles: 2 x 64, 1 x 64 | 64 x 2, 64 x 1
+        const int sa = hz ? cells / 32 : 32, sb = hz ? 32 : cells / 32;          // short tiles: 4 x 32, 2 x 32, 1 x 32 | 32 x 4, 32 x 2, 32 x 1
+        const long long nl = cells >= 64 ? gru_half_tiles(d.P, d.h, d.w, ta, tb, hz) : (1ll << 62), ns = gru_half_tiles(d.P, d.h, d.w, sa, sb, hz);
+        if (nl <= ns) { th = ta; tw = tb; return nl; }
+        th = sa; tw = sb; return ns;
+    };
+    int th = 0, tw = 0, cells = d.cells;
+    if (!cells) {
+        cells = 128;
+        if (!tc_fills(best(128, th, tw))) cells = 64;
     }
-    if (gru_half_tiles(d.P, d.h, d.w, 64, 2, false) <= gru_half_tiles(d.P, d.h, d.w, 32, 4, false)) return gru_half_launch<64, 2, 5, 1>(a, s);
-    return gru_half_launch<32, 4, 5, 1>(a, s);
+    if (cells != 128 && cells != 64 && cells != 32) return fail(MFTX_E_ARG, "gru_half: 128, 64 or 32 cells per tile");
+    if (cells == 32) cells = 64;         // (the 32-cell instances of this kernel spill -- the compiler's doing, not the algorithm's; 64 is the smallest built)
+    best(cells, th, tw);
+#define GH(TH, TW, KH, KW) if (th == TH && tw == TW) return gru_half_launch<TH, TW, KH, KW>(a, s)
+    if (hz) { GH(2, 64, 1, 5); GH(4, 32, 1, 5); GH(1, 64, 1, 5); GH(2, 32, 1, 5); }
+    else { GH(64, 2, 5, 1); GH(32, 4, 5, 1); GH(64, 1, 5, 1); GH(32, 2, 5, 1); }
+#undef GH
+    return fail(MFTX_E_STATE, "gru_half: no kernel for tiles of %d x %d cells", th, tw);
 }
 
 // ---- weights: the GEMM's packed form [>= N rows][taps][cin_pad] fp32 -> [nt][ks][step][hi | lo][lane] x 16 bytes
@@ -744,9 +766,10 @@ static int tc_launch(TileConvArgs a, hipStream_t s) {
     return check_launch("tile_conv");
 }
 
-template <int KH, int KW, int CIN, int N>
+// tile shapes by filter and cells per tile: 3 x 3: 8 x 16 / 4 x 16 / 2 x 16; 1 x 5: 4 x 32 / 2 x 32 / 1 x 32; 5 x 1: 32 x 4 / 32 x 2 / 32 x 1
+template <int KH, int KW, int CIN, int N, int CELLS>
 static int tc_dispatch_epi(const TileConvArgs &a, int epi, hipStream_t s) {
-    constexpr int TH = KH == 3 ? 8 : (KH == 1 ? 4 : 32), TW = 128 / TH;
+    constexpr int TH = KH == 3 ? CELLS / 16 : (KH == 1 ? CELLS / 32 : 32), TW = CELLS / TH;
     switch (epi) {
         case TC_LINEAR: return tc_launch<TH, TW, KH, KW, CIN, N, TC_LINEAR>(a, s);
         case TC_RELU: return tc_launch<TH, TW, KH, KW, CIN, N, TC_RELU>(a, s);
@@ -768,17 +791,32 @@ bool tile_conv_applicable(int kh, int kw, int cin, int N) {
 // The kernel takes the time of ONE tile's K loop however few tiles there are (one workgroup per tile, one per CU): it pays
 // only when its tiles come in nearly whole rounds of the chip (>= 5/8 full) -- 7 pairs of 64 x 64 cells are 224 tiles on 256 CUs, at
 // 256 x 256 pixels (56 tiles) the ring-buffered kernel's 64 x 64 tiles are 30 % faster (bench.py, 332 vs 254 frames/s)
-bool tile_conv_fills_chip(int P, int h, int w, int kh, int kw) {
+static int tc_num_cus() {
     static const int cus = [] {
         int dev = 0, n = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
         return n;
     }();
-    const int th = kh == 3 ? 8 : (kh == 1 ? 4 : 32), tw = 128 / th;
-    const long long tiles = (long long)P * cdiv(h, th) * cdiv(w, tw);
-    const long long rounds = (tiles + cus - 1) / cus;
+    return cus;
+}
+static bool tc_fills(long long tiles) {
+    const long long cus = tc_num_cus(), rounds = (tiles + cus - 1) / cus;
     return tiles * 8 >= rounds * cus * 5;      // >= 5/8: one refinement of 5 / 6 / 7 pairs of 64 x 64 cells is 2 / 8 / 7 % faster with them, of 4 pairs 8 % slower (tools/bench_pairs.py)
+}
+static long long tc_tiles(int P, int h, int w, int kh, int cells) {
+    const int th = kh == 3 ? cells / 16 : (kh == 1 ? cells / 32 : 32), tw = cells / th;
+    return (long long)P * cdiv(h, th) * cdiv(w, tw);
+}
+bool tile_conv_fills_chip(int P, int h, int w, int kh, int kw) { (void)kw; return tc_fills(tc_tiles(P, h, w, kh, 128)); }
+bool tile_conv_small_tiles_fill(int P, int h, int w) { return tc_tiles(P, h, w, 3, 32) * 2 >= tc_num_cus(); }
+// Cells per tile (round 4): 128 where such tiles fill the chip; else 64, else 32 -- a smaller tile is the same kernel with fewer
+// MFMA row tiles per wave: every output is the same sequence of products and sums, THE SAME BITS, so the choice may follow the
+// batch (one pair per rank of a sharded frame, a ramp-up frame, a 256 x 256 video) without a pair's result depending on it.
+int tile_conv_cells(int P, int h, int w, int kh) {
+    if (tc_fills(tc_tiles(P, h, w, kh, 128))) return 128;
+    if (tc_fills(tc_tiles(P, h, w, kh, 64)) || tc_tiles(P, h, w, kh, 64) >= tc_num_cus()) return 64;
+    return 32;
 }
 
 int launch_tile_conv(const TileConvLaunch &d, hipStream_t s) {
@@ -805,13 +843,17 @@ int launch_tile_conv(const TileConvLaunch &d, hipStream_t s) {
     } else if (d.epi == TC_RELU_PROJ) {
         if (!d.wproj || !d.tout || !d.bias || !aligned16(d.wproj) || !aligned16(d.tout)) return fail(MFTX_E_ARG, "tile_conv: projection epilogue operands");
     } else return fail(MFTX_E_ARG, "tile_conv: unknown epilogue");
-    if (d.kh == 3) return d.N == 256 ? tc_dispatch_epi<3, 3, 128, 256>(a, d.epi, s) : tc_dispatch_epi<3, 3, 128, 128>(a, d.epi, s);
+    const int cells = d.cells ? d.cells : tile_conv_cells(d.P, d.h, d.w, d.kh);
+    if (cells != 128 && cells != 64 && cells != 32) return fail(MFTX_E_ARG, "tile_conv: 128, 64 or 32 cells per tile");
+#define TC_BY_CELLS(KH, KW, CIN, N) (cells == 128 ? tc_dispatch_epi<KH, KW, CIN, N, 128>(a, d.epi, s) : cells == 64 ? tc_dispatch_epi<KH, KW, CIN, N, 64>(a, d.epi, s) : tc_dispatch_epi<KH, KW, CIN, N, 32>(a, d.epi, s))
+    if (d.kh == 3) return d.N == 256 ? TC_BY_CELLS(3, 3, 128, 256) : TC_BY_CELLS(3, 3, 128, 128);
     if (d.kh == 1) {
-        if (d.cin == 128) return d.N == 256 ? tc_dispatch_epi<1, 5, 128, 256>(a, d.epi, s) : tc_dispatch_epi<1, 5, 128, 128>(a, d.epi, s);
-        return d.N == 256 ? tc_dispatch_epi<1, 5, 256, 256>(a, d.epi, s) : tc_dispatch_epi<1, 5, 256, 128>(a, d.epi, s);
+        if (d.cin == 128) return d.N == 256 ? TC_BY_CELLS(1, 5, 128, 256) : TC_BY_CELLS(1, 5, 128, 128);
+        return d.N == 256 ? TC_BY_CELLS(1, 5, 256, 256) : TC_BY_CELLS(1, 5, 256, 128);
     }
-    if (d.cin == 128) return d.N == 256 ? tc_dispatch_epi<5, 1, 128, 256>(a, d.epi, s) : tc_dispatch_epi<5, 1, 128, 128>(a, d.epi, s);
-    return d.N == 256 ? tc_dispatch_epi<5, 1, 256, 256>(a, d.epi, s) : tc_dispatch_epi<5, 1, 256, 128>(a, d.epi, s);
+    if (d.cin == 128) return d.N == 256 ? TC_BY_CELLS(5, 1, 128, 256) : TC_BY_CELLS(5, 1, 128, 128);
+    return d.N == 256 ? TC_BY_CELLS(5, 1, 256, 256) : TC_BY_CELLS(5, 1, 256, 128);
+#undef TC_BY_CELLS
 }
 
 // ---- the flow head's second layer, in two pieces (see TC_RELU_PROJ) -----------------------------------------------------

@@ -402,15 +402,16 @@ def tile_conv2d(x: torch.Tensor, wtile: torch.Tensor, bias, P, h, w, N, kh, kw, 
 def gru_half(h_split, motion_split, wzr_tile, wq_tile, pre_zr, pre_q, hf, P, h, w, vertical=False):
     """One SepConvGRU pass as one kernel (``mftx_gru_half``): h_split / motion_split [M, 128] in split form, the gates' weights
     as ``pack_tile_conv_weights`` streams (cin = 256), pre_zr [M, 256] / pre_q [M, 128] the pre-activation addends, hf [M, 128]
-    the fp32 h (updated in place) -> (new h in split form [M, 128], z [M, 128])."""
+    the fp32 h -> (new h in fp32 [M, 128], new h in split form [M, 128], z [M, 128])."""
     M = P * h * w
     z = torch.empty(M, 128, dtype=torch.float32, device=hf.device)
     h_out = torch.empty(M, 128, dtype=torch.float32, device=hf.device)
+    hf_out = torch.empty(M, 128, dtype=torch.float32, device=hf.device)
     check(_lib.load().mftx_gru_half(_chk(h_split, "h"), h_split.shape[1], _chk(motion_split, "motion"), motion_split.shape[1],
                                     _chk(wzr_tile, "wzr", torch.uint8), _chk(wq_tile, "wq", torch.uint8), _chk(pre_zr, "pre_zr"),
-                                    _chk(pre_q, "pre_q"), _chk(z, "z"), _chk(hf, "hf"), _chk(h_out, "h_out"), 128, P, h, w,
+                                    _chk(pre_q, "pre_q"), _chk(z, "z"), _chk(hf, "hf"), _chk(hf_out, "hf_out"), _chk(h_out, "h_out"), 128, P, h, w,
                                     1 if vertical else 0, _stream()), "mftx_gru_half")
-    return h_out, z
+    return hf_out, h_out, z
 
 
 def pack_flow_head_weights(w2pk: torch.Tensor, check_range: bool = True) -> torch.Tensor:
@@ -690,7 +691,7 @@ class RaftEngine:
     # WeightSlot indices (csrc/raft_engine.hip) of the weights that feed GEMM layers
     GEMM_SLOTS = (0, 2, 6, 8, 10, 11, 13, 14, 16, 17, 19, 20, 22, 26, 28, 30)
 
-    OPTIONS = {"fork": 0, "presplit": 1, "group": 2, "fuse_lookup": 3, "graph": 4, "fuse_flow": 5, "tile_conv": 6, "fuse_head": 7, "tile_volume": 8, "fuse_gru": 9}      # MFTX_RAFT_OPT_*
+    OPTIONS = {"fork": 0, "presplit": 1, "group": 2, "fuse_lookup": 3, "graph": 4, "fuse_flow": 5, "tile_conv": 6, "fuse_head": 7, "tile_volume": 8, "fuse_gru": 9, "tile_cells": 10}      # MFTX_RAFT_OPT_*
     # WeightSlot -> (N, cin) of the layers with a tile-resident kernel (csrc/tile_conv.hip): GRU gates (per-iteration and
     # context parts, both passes), flow head and mask head first layers
     TILE_SLOTS = {10: (256, 256), 11: (256, 128), 13: (128, 256), 14: (128, 128), 16: (256, 256), 17: (256, 128),

@@ -499,14 +499,29 @@ def test_pair_bits_independent_of_batch_512(weights_np):
     for m, p_ in zip(many, parts):
         for a, b in zip(m, p_):
             assert torch.equal(a, b)
-    # a nominal batch of one pair (a tracker with a single delta): ring-buffered kernels, whatever the batch
+    # a nominal batch of one pair (a tracker with a single delta): 128 tiles of 32 cells still fill half the chip -- the same kernels
+    # with smaller tiles, the same bits
     fl.set_nominal_pairs(1)
     one = fl.compute_flow_many([lefts[0]], (None, vid[8]))
-    assert fl.engine._tile_conv == 0
-    seven = fl.compute_flow_many(lefts, (None, vid[8]))
-    for a, b in zip(one[0], seven[0]):
+    assert fl.engine._tile_conv == 2
+    for a, b in zip(one[0], many[0]):
         assert torch.equal(a, b)
-    assert epe(one[0][0].cpu(), many[0][0].cpu()).max() < 1e-4             # the two kernel families: fp32 rounding of the K sums
+    # a small video (128 x 160: 320 cells per pair): the ring-buffered kernels, pinned for every batch size alike
+    small = SyntheticVideo(128, 160, n_frames=9, seed=4)
+    fl.set_nominal_pairs(7)
+    sl = [(None, small[i]) for i in range(7)]
+    sm = fl.compute_flow_many(sl, (None, small[8]))
+    assert fl.engine._tile_conv == 0 and fl._tile_choice[(16, 20)] == 0
+    (s1,) = fl.compute_flow_many([sl[2]], (None, small[8]))
+    for a, b in zip(sm[2], s1):
+        assert torch.equal(a, b)
+    # the two kernel families agree to fp32 rounding of the K sums
+    c3 = Config()
+    c3.flow_iters = 3
+    from mft_amd.config import AttrDict
+    c3.raft_params = AttrDict(engine_options={"tile_conv": 0})
+    ring = RAFTWrapper(c3, state_dict=weights_np).compute_flow_many([lefts[0]], (None, vid[8]))
+    assert epe(ring[0][0].cpu(), many[0][0].cpu()).max() < 1e-4
 
 
 def test_nonfinite_results_are_counted_and_raise(weights_np):

@@ -1127,15 +1127,30 @@ def test_engine_tile_conv_matches_ring_gemm():
     assert np.abs(tiled[n:] - ring[n:]).max() < 1e-3
 
 
-@pytest.mark.parametrize("P,h,w", [(3, 24, 40), (1, 72, 80), (1, 33, 140), (2, 135, 16), (1, 64, 64)])
+@pytest.mark.parametrize("P,h,w", [(3, 24, 40), (1, 72, 80), (1, 33, 140), (2, 135, 16), (1, 64, 64), (1, 135, 240)])
 def test_engine_fused_gru_bitwise(P, h, w):
     """Each SepConvGRU pass as ONE kernel (mftx_gru_half: the tile loaded once, r * h formed in LDS in place, h ping-ponging
     between two buffers) against the two tile-resident launches it replaces: every output is the same sequence of products
     and sums -- the same bits.  Sizes: one tile across (nothing recomputed), maps wider / taller than a tile (R tiles that
-    overlap by the gates' 2-cell halo, both tile shapes), ragged edges."""
+    overlap by the gates' 2-cell halo, both tile shapes), ragged edges, and MORE TILES THAN CUs (135 x 240: workgroups of a
+    second round start when their neighbours of the first have already written the new state -- the round-4 bug this size
+    caught: the fp32 copy of h was updated in place)."""
     fused, apart = _engine_outputs({"tile_conv": 2}, P, h, w, 3), _engine_outputs({"tile_conv": 2, "fuse_gru": 0}, P, h, w, 3)
     assert np.isfinite(fused).all()
     assert np.array_equal(fused, apart)
+
+
+@pytest.mark.parametrize("P,h,w", [(3, 24, 40), (1, 72, 80), (2, 33, 47), (1, 135, 240)])
+def test_engine_tile_cells_bitwise(P, h, w):
+    """The tile-resident kernels with 128, 64 or 32 cells per tile (round 4: the small-batch path -- one pair per rank of a
+    sharded frame, ramp-up frames, 256 x 256 videos): a smaller tile is the same kernel with fewer MFMA row tiles per wave,
+    every output the same sequence of products and sums.  Same bits, so the engine may pick the tile by the batch."""
+    base = _engine_outputs({"tile_conv": 2, "tile_cells": 128}, P, h, w, 3)
+    assert np.isfinite(base).all()
+    for cells in (64, 32, 0):
+        assert np.array_equal(_engine_outputs({"tile_conv": 2, "tile_cells": cells}, P, h, w, 3), base), cells
+    assert np.array_equal(_engine_outputs({"tile_conv": 2, "tile_cells": 64, "fuse_gru": 0, "fuse_head": 0}, P, h, w, 3),
+                          _engine_outputs({"tile_conv": 2, "tile_cells": 128, "fuse_gru": 0, "fuse_head": 0}, P, h, w, 3))
 
 
 @pytest.mark.parametrize("P,h,w,vertical", [(1, 16, 24, False), (1, 16, 24, True), (2, 9, 150, False), (1, 150, 7, True), (1, 64, 64, False)])
@@ -1153,7 +1168,7 @@ def test_gru_half_vs_fp64(ops_mod, P, h, w, vertical):
     pre_q = torch.randn(M, 128, generator=g) * 0.5
     pack = lambda wt, n: ops_mod.pack_tile_conv_weights(ops_mod.pack_conv_weight(wt.cuda()), n, 256)      # noqa: E731
     hf_dev = hf.cuda()
-    h_out, z = ops_mod.gru_half(ops_mod.split_activations(hf_dev), ops_mod.split_activations(mo.cuda()), pack(wzr, 256), pack(wq, 128),
+    hf_new, h_out, z = ops_mod.gru_half(ops_mod.split_activations(hf_dev), ops_mod.split_activations(mo.cuda()), pack(wzr, 256), pack(wq, 128),
                                 pre_zr.cuda(), pre_q.cuda(), hf_dev, P, h, w, vertical=vertical)
     to_map = lambda t: t.double().reshape(P, h, w, -1).permute(0, 3, 1, 2)      # noqa: E731
     to_rows = lambda t: t.permute(0, 2, 3, 1).reshape(M, -1)                    # noqa: E731
@@ -1164,13 +1179,14 @@ def test_gru_half_vs_fp64(ops_mod, P, h, w, vertical):
     q = torch.tanh(F.conv2d(torch.cat([rr * hd, md], 1), wq.double(), padding=pad) + to_map(pre_q))
     want = (1 - zz) * hd + zz * q
     assert (z.cpu().double() - to_rows(zz)).abs().max() < 2e-6
-    assert (hf_dev.cpu().double() - to_rows(want)).abs().max() < 5e-6
-    assert torch.equal(ops_mod.unsplit_activations(h_out), ops_mod.unsplit_activations(ops_mod.split_activations(hf_dev)))
+    assert (hf_new.cpu().double() - to_rows(want)).abs().max() < 5e-6
+    assert torch.equal(hf_dev.cpu(), hf)                                        # the input state is left alone
+    assert torch.equal(ops_mod.unsplit_activations(h_out), ops_mod.unsplit_activations(ops_mod.split_activations(hf_new)))
     with pytest.raises(ops_mod.MftxError):         # h is read from one buffer and written to another
         from mft_amd import _lib
         hs = ops_mod.split_activations(hf_dev)
         ops_mod.check(_lib.load().mftx_gru_half(hs.data_ptr(), 128, hs.data_ptr(), 128, pack(wzr, 256).data_ptr(), pack(wq, 128).data_ptr(),
-                                                pre_zr.cuda().data_ptr(), pre_q.cuda().data_ptr(), z.data_ptr(), hf_dev.data_ptr(),
+                                                pre_zr.cuda().data_ptr(), pre_q.cuda().data_ptr(), z.data_ptr(), hf_dev.data_ptr(), hf_new.data_ptr(),
                                                 hs.data_ptr(), 128, P, h, w, 0, None), "mftx_gru_half")
 
 
