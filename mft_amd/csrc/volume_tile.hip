@@ -196,6 +196,17 @@ __global__ __launch_bounds__(512, 2) void volume_tile_kernel(VolTileArgs p) {
         const int m = lane & 31;
         const int q0 = qb * 32;
         const long long blk0 = ((long long)(2 * sby) * p.wb0 + 2 * sbx) * 32 + m;          // + (j >> 1) wb0 * 32 + (j & 1) * 32
+        // Levels 0 and 1 (every lane stores) leave as raw BUFFER stores: one descriptor per query block and level -- base = the block's
+        // first query row, records = its valid rows, so rows past the last query fall out of range by themselves --, the lane's offset
+        // inside a row in ONE 32-bit register for all 80 stores, the row in a scalar offset.  Half the address traffic of a
+        // global store (64-bit address per lane) on the CU's store path, which is what this epilogue is bound by.  Levels 2 and 3
+        // (a few lanes each) stay global stores under EXEC: an out-of-range lane of a buffer store still takes its turn in the
+        // address unit (round 3's all-buffer variant: 430 instead of 360 us).
+        const int rows_ok = p.N - q0 < 32 ? p.N - q0 : 32;
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(p.lvl0 + (qbase + q0) * p.s0, 0, (unsigned)((long long)rows_ok * p.s0 * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(p.lvl1 + (qbase + q0) * p.s1, 0, (unsigned)((long long)rows_ok * p.s1 * 4), 0x00020000);
+        const unsigned v0off = (unsigned)((4 * hf * p.s0 + blk0) * 4), v1off = (unsigned)((4 * hf * p.s1 + ((long long)sby * p.sbw + sbx) * 32 + m) * 4);
+        const unsigned s0b = (unsigned)(p.s0 * 4), s1b = (unsigned)(p.s1 * 4), jrow = (unsigned)(p.wb0 * 128);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qrow = q0 + 8 * (r >> 2) + 4 * hf + (r & 3);
@@ -206,12 +217,11 @@ __global__ __launch_bounds__(512, 2) void volume_tile_kernel(VolTileArgs p) {
             const bool st0 = row_ok, st1 = row_ok;
 #endif
             const long long qr = qbase + qrow;
-            float *o0 = p.lvl0 + qr * p.s0 + blk0;
             float merged = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float v = (acc[j][r] + accx[j][r] * inv2048) * p.scale;
-                if (st0) o0[((long long)(j >> 1) * p.wb0 + (j & 1)) * 32] = v;
+                if (st0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r0, v0off + (j >> 1) * jrow + (j & 1) * 128u, (unsigned)(8 * (r >> 2) + (r & 3)) * s0b, 0);
                 // level 1: the 2 x 2 cells (y, x), (y, x + 1), (y + 1, x), (y + 1, x + 1) are lanes m, m + 1, m + 8, m + 9 of one 16-lane row
                 // (valid where x and y are even), summed in ATen's order
                 float t = v + vt_shl<1>(v);
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void volume_tile_kernel(VolTileArgs p) {
             // merged lane 2 xx + 16 yy + (j & 1) + 8 (j >> 1) = level-1 cell (y1, x1) = (2 (j >> 1) + yy, 4 (j & 1) + xx): pull into
             // position p = 8 y1 + x1 -- one 128-byte line of level 1 per half-wave
             const float l1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(l1_src, __builtin_bit_cast(int, merged)));
-            if (st1) p.lvl1[qr * p.s1 + ((long long)sby * p.sbw + sbx) * 32 + m] = l1;
+            if (st1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, l1), r1, v1off, (unsigned)(8 * (r >> 2) + (r & 3)) * s1b, 0);
             // level 2 from the level-1 line (8 wide, 4 tall: the same lane pattern), valid at even x1, even y1: cell (y1 >> 1, x1 >> 1)
             float t2 = l1 + vt_shl<1>(l1);
             t2 = t2 + vt_shl<8>(l1);
