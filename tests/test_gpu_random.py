@@ -214,3 +214,36 @@ def test_corr_pyramid_tile_resident_random(h, w, P, seed):
         else:
             got = lv[l].reshape(P * h * w, -1)[:, :hl * wl].reshape(P * h * w, 1, hl, wl).cpu()
         assert torch.equal(got, cur), l
+
+
+@SET
+@given(h=st.integers(1, 70), w=st.integers(1, 70), P=st.integers(1, 2), vertical=st.booleans(), seed=st.integers(0, 10_000))
+def test_gru_half_random(h, w, P, vertical, seed):
+    """One SepConvGRU pass as one kernel (mftx_gru_half) against the gate algebra of core/update.py:108-123 in fp64, over ragged
+    maps: narrower / shorter than a tile, wider / taller (tiles that overlap by the candidate's halo), one cell."""
+    import torch.nn.functional as F
+    from mft_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    M = P * h * w
+    hf = torch.tanh(torch.randn(M, 128, generator=g))
+    mo = torch.relu(torch.randn(M, 128, generator=g))
+    kh, kw = (5, 1) if vertical else (1, 5)
+    wzr = torch.randn(256, 256, kh, kw, generator=g) * 0.04
+    wq = torch.randn(128, 256, kh, kw, generator=g) * 0.04
+    pre_zr = torch.randn(M, 256, generator=g) * 0.5
+    pre_q = torch.randn(M, 128, generator=g) * 0.5
+    pack = lambda wt, n: ops.pack_tile_conv_weights(ops.pack_conv_weight(wt.to(DEV)), n, 256)      # noqa: E731
+    hf_dev = hf.to(DEV)
+    hf_new, h_out, z = ops.gru_half(ops.split_activations(hf_dev), ops.split_activations(mo.to(DEV)), pack(wzr, 256), pack(wq, 128),
+                                    pre_zr.to(DEV), pre_q.to(DEV), hf_dev, P, h, w, vertical=vertical)
+    to_map = lambda t: t.double().reshape(P, h, w, -1).permute(0, 3, 1, 2)      # noqa: E731
+    to_rows = lambda t: t.permute(0, 2, 3, 1).reshape(M, -1)                    # noqa: E731
+    pad = (kh // 2, kw // 2)
+    hd, md = to_map(hf), to_map(mo)
+    zr = torch.sigmoid(F.conv2d(torch.cat([hd, md], 1), wzr.double(), padding=pad) + to_map(pre_zr))
+    zz, rr = zr[:, :128], zr[:, 128:]
+    q = torch.tanh(F.conv2d(torch.cat([rr * hd, md], 1), wq.double(), padding=pad) + to_map(pre_q))
+    want = (1 - zz) * hd + zz * q
+    assert (z.cpu().double() - to_rows(zz)).abs().max() < 2e-6
+    assert (hf_new.cpu().double() - to_rows(want)).abs().max() < 5e-6
+    assert torch.equal(ops.unsplit_activations(h_out), ops.unsplit_activations(ops.split_activations(hf_new)))
