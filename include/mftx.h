@@ -187,6 +187,20 @@ int mftx_conv2d_tile(const mftx_conv_desc *d, int tile, void *stream);
  * mftx_conv2d packing wpk = [>= N rows][taps][cin_pad] fp32.  d->wpk is ignored. */
 int mftx_pack_tile_conv_weights(const float *wpk, int N, int taps, int cin, int cin_pad, void *wtile, void *stream);
 int mftx_tile_conv2d(const mftx_conv_desc *d, const void *wtile, void *stream);
+/* The occlusion and uncertainty heads (core/update.py:177-214, 17-75: per head conv3x3 712 -> 128, relu, conv3x3 128 -> 2 | 1; the
+ * two first layers stacked into one 712 -> 256 layer, the two second layers into one block-diagonal 256 -> 3 layer) as ONE
+ * tile-resident kernel + a stencil sum: the 712-channel input tile goes through LDS in five channel passes of 144 with the
+ * accumulators kept, relu(. + b1) stays in LDS and is multiplied there with the second layers as a [256 x 27] matrix (T[m][3 tap
+ * + o]); out[m][o] = b2[o] + sum_tap T[m + offset(tap)][3 tap + o] (zero padding), o = 0, 1: occlusion logits, 2: log-variance.
+ * a_split: the heads' input in split form, 712 channels at a_split + m * lda floats (the concatenation of core/update.py:197);
+ * w1pk: the stacked first layers in the mftx_conv2d packing [>= 256 rows][9][cin_pad >= 712]; w2pk: the second layers
+ * [>= 3 rows][9][256]; wtile: MFTX_OU_HEADS_WTILE_BYTES, wproj: MFTX_FLOW_HEAD_WEIGHT_BYTES, both 16-byte aligned; b1: 256 floats,
+ * b2: 3; T: [P*h*w][27] floats of scratch; out: [P*h*w][ld_out >= 3].  Agrees with mftx_conv2d + the small-N kernel to fp32
+ * rounding of the K sums (the channel passes reorder them). */
+#define MFTX_OU_HEADS_WTILE_BYTES 6635520
+int mftx_pack_ou_heads_weights(const float *w1pk, int cin_pad, const float *w2pk, void *wtile, void *wproj, void *stream);
+int mftx_ou_heads(const float *a_split, int lda, int P, int h, int w, const void *wtile, const float *b1, const void *wproj, const float *b2,
+                  float *T, float *out, int ld_out, void *stream);
 /* One pass of the SepConvGRU (core/update.py:108-123; pass 0: the 1 x 5 convolutions, pass 1: the 5 x 1 ones) as ONE kernel:
  *     z | r = sigmoid(conv_zr([h | motion]) + pre_zr),  q = tanh(conv_q([r * h | motion]) + pre_q),  h <- (1 - z) h + z q
  * with the tile's [h | motion] loaded into LDS once and r * h formed there in place (csrc/tile_conv.hip: gru_half_kernel).  The
@@ -267,6 +281,8 @@ int mftx_raft_set_tile_weights(mftx_raft *r, const void *const *tile, int n);
 /* wproj (mftx_pack_flow_head_weights of the engine's flow_head.conv2 weight; kept): with the flow head's first layer on the
  * tile-resident kernel, both layers run as mftx_flow_head does.  NULL: off. */
 int mftx_raft_set_flow_head(mftx_raft *r, const void *wproj);
+/* the weight streams of mftx_ou_heads (mftx_pack_ou_heads_weights) for the occlusion + uncertainty heads of the handle; NULL, NULL: off */
+int mftx_raft_set_ou_heads(mftx_raft *r, const void *wtile, const void *wproj);
 /* Debug payload of RAFT.forward(vis_debug=True) (core/raft.py:159-176, 255-257): trace = (iters + 1) x [P*h*w][2] floats
  * (device, kept) receives coords1 as every iteration finds it and, last, as the final iteration leaves it; NULL: off.  The
  * cost-volume pyramid of the same call stays in the workspace (mftx_raft_workspace_layout_for: lvl0..3). */
@@ -292,7 +308,9 @@ int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
  *   MFTX_RAFT_OPT_FUSE_GRU   1 default (where the tile-resident layers run: each SepConvGRU pass as ONE kernel, mftx_gru_half), 0 z | r
  *                            gates and candidate + blend as two tile-resident launches.  Same bits either way.
  *   MFTX_RAFT_OPT_TILE_CELLS 0 default (cells per tile of the tile-resident kernels by how the tiles fill the chip: 128, else 64, else
- *                            32), or 128 / 64 / 32 forced.  Same bits whatever the value: a smaller tile is fewer MFMA row tiles per wave. */
+ *                            32), or 128 / 64 / 32 forced.  Same bits whatever the value: a smaller tile is fewer MFMA row tiles per wave.
+ *   MFTX_RAFT_OPT_FUSE_OU    1 default (where the tile-resident layers run and mftx_raft_set_ou_heads has been called: the occlusion and
+ *                            uncertainty heads as mftx_ou_heads), 0 the 712 -> 256 GEMM on mftx_conv2d + the small-N kernel */
 #define MFTX_RAFT_OPT_FORK 0
 #define MFTX_RAFT_OPT_PRESPLIT 1
 #define MFTX_RAFT_OPT_GROUP 2
@@ -304,6 +322,7 @@ int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
 #define MFTX_RAFT_OPT_TILE_VOLUME 8
 #define MFTX_RAFT_OPT_FUSE_GRU 9
 #define MFTX_RAFT_OPT_TILE_CELLS 10
+#define MFTX_RAFT_OPT_FUSE_OU 11
 int mftx_raft_set_option(mftx_raft *r, int option, int value);
 /* A device-resident counter (4 bytes, zeroed by the caller) that the last kernel of every mftx_raft_refine* call increments
  * by the number of output pixels with a non-finite flow / occlusion / sigma; null switches it off.  The reference has no

@@ -14,6 +14,7 @@ NUM_RAFT_WEIGHTS = 34
 LOOKUP_CONVC1_WEIGHT_BYTES = 393216
 FLOW_BRANCH_WEIGHT_BYTES = 352256
 FLOW_HEAD_WEIGHT_BYTES = 32768
+OU_HEADS_WTILE_BYTES = 6635520     # MFTX_OU_HEADS_WTILE_BYTES
 SPLIT_LIMIT = 65504.0      # MFTX_SPLIT_LIMIT: operands of the split arithmetic must stay below it in magnitude
 
 
@@ -57,6 +58,10 @@ SIGNATURES = {
     "mftx_raft_set_flow_fused": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mftx_raft_set_tile_weights": (C.c_int, [C.c_void_p, _PP, C.c_int]),
     "mftx_raft_set_flow_head": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mftx_raft_set_ou_heads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mftx_pack_ou_heads_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mftx_ou_heads": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int, C.c_void_p]),
     "mftx_pack_flow_head_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mftx_flow_head": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 8),
     "mftx_pack_tile_conv_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -185,6 +185,12 @@ struct GruHalfLaunch {
 };
 int launch_gru_half(const GruHalfLaunch &d, hipStream_t s);
 int launch_pack_flow_head(const float *w2pk, void *out, hipStream_t s);
+// the occlusion + uncertainty heads as one tile-resident kernel + a stencil sum (tile_conv.hip: ou_head_kernel)
+constexpr size_t OU_HEAD_WTILE_BYTES = 8ull * 5 * 9 * 9 * 128 * 16, OU_HEAD_WPROJ_BYTES = 32768;
+int launch_pack_ou_head(const float *w1pk, int cin_pad, const float *w2pk, void *wtile, void *wproj, hipStream_t s);
+struct OuGather { const float *hx, *corr; int ld_corr; const float *coords1, *delta; float *flow_lr; };     // the parts of the heads' input (hx: [M][384] split form)
+int launch_ou_heads(const float *a, int lda, int P, int h, int w, const void *wtile, const float *b1, const void *wproj, const float *b2, float *T,
+                    float *out, int ld_out, int cells, hipStream_t s, const OuGather *ga = nullptr);
 int launch_flow_head_sum(const float *T, const float *b2, float *delta, const float *coords_in, float *coords_out, int P, int h, int w, hipStream_t s);
 bool tile_conv_applicable(int kh, int kw, int cin, int N);
 bool tile_conv_small_tiles_fill(int P, int h, int w);               // at least half a round of the chip in 32-cell tiles

@@ -195,7 +195,8 @@ struct mftx_raft {
     const void *wflow;             // convf1's and convf2's weights for the fused flow-branch kernel (csrc/flow_branch.hip), or null
     const void *wproj;             // the flow head's last layer as the projection epilogue of its first (csrc/tile_conv.hip: TC_RELU_PROJ), or null
     const void *wt[W_COUNT];       // weight streams of the tile-resident conv kernel (csrc/tile_conv.hip) per slot, or null
-    int opt[11];                   // MFTX_RAFT_OPT_*
+    const void *wou, *wouproj;     // the occlusion + uncertainty heads as one tile-resident kernel (csrc/tile_conv.hip: ou_head_kernel), or null
+    int opt[12];                   // MFTX_RAFT_OPT_*
     unsigned *nonfinite;           // device counter of non-finite output pixels (mftx_raft_set_nonfinite_counter), or null
 };
 // weights that go through the conv GEMM (the others feed VALU kernels and stay fp32)
@@ -219,11 +220,12 @@ extern "C" int mftx_raft_create(const float *const *weights, int n_weights, mftx
     r->wfused = nullptr;
     r->wflow = nullptr;
     r->wproj = nullptr;
+    r->wou = nullptr; r->wouproj = nullptr;
     for (int i = 0; i < W_COUNT; ++i) r->wt[i] = nullptr;
     r->coords_trace = nullptr;
     r->nonfinite = nullptr;
     r->graphs = new (std::nothrow) GraphCache;
-    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1; r->opt[MFTX_RAFT_OPT_FUSE_FLOW] = 1; r->opt[MFTX_RAFT_OPT_TILE_CONV] = 1; r->opt[MFTX_RAFT_OPT_FUSE_HEAD] = 1; r->opt[MFTX_RAFT_OPT_TILE_VOLUME] = 1; r->opt[MFTX_RAFT_OPT_FUSE_GRU] = 1; r->opt[MFTX_RAFT_OPT_TILE_CELLS] = 0;
+    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1; r->opt[MFTX_RAFT_OPT_FUSE_FLOW] = 1; r->opt[MFTX_RAFT_OPT_TILE_CONV] = 1; r->opt[MFTX_RAFT_OPT_FUSE_HEAD] = 1; r->opt[MFTX_RAFT_OPT_TILE_VOLUME] = 1; r->opt[MFTX_RAFT_OPT_FUSE_GRU] = 1; r->opt[MFTX_RAFT_OPT_TILE_CELLS] = 0; r->opt[MFTX_RAFT_OPT_FUSE_OU] = 1;
     for (int i = 0; i < W_COUNT; ++i) r->w[i] = r->wg[i] = weights[i];
     *out = r;
     return 0;
@@ -315,6 +317,15 @@ extern "C" int mftx_raft_set_flow_head(mftx_raft *r, const void *wproj) {
     return 0;
 }
 
+extern "C" int mftx_raft_set_ou_heads(mftx_raft *r, const void *wtile, const void *wproj) {
+    if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_ou_heads: bad handle");
+    if ((wtile == nullptr) != (wproj == nullptr)) return fail(MFTX_E_ARG, "raft_set_ou_heads: both weight streams, or neither");
+    if (wtile && (!aligned16(wtile) || !aligned16(wproj))) return fail(MFTX_E_ALIGN, "raft_set_ou_heads: weights not 16-byte aligned");
+    r->wou = wtile; r->wouproj = wproj;
+    if (r->graphs) r->graphs->clear();
+    return 0;
+}
+
 extern "C" int mftx_raft_set_coords_trace(mftx_raft *r, float *trace) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_coords_trace: bad handle");
     r->coords_trace = trace;
@@ -337,7 +348,7 @@ extern "C" int mftx_raft_set_nonfinite_counter(mftx_raft *r, unsigned *counter) 
 
 extern "C" int mftx_raft_set_option(mftx_raft *r, int option, int value) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_option: bad handle");
-    if (option < 0 || option > MFTX_RAFT_OPT_TILE_CELLS) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
+    if (option < 0 || option > MFTX_RAFT_OPT_FUSE_OU) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
     r->opt[option] = value;
     if (r->graphs) r->graphs->clear();
     return 0;
@@ -658,15 +669,25 @@ static int refine_impl(mftx_raft *r, int P, int h, int w, int iters, const float
         } else TRY(launch_conv(gemm(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, G[W_MASK0], W[B_MASK0], ws.fh, 256, P, h, w, 256, 3, 3, 1), true, false), s));
         TRY(launch_conv(gemm(conv_desc(ws.fh, 256, 256, nullptr, 0, 0, G[W_MASK2], W[B_MASK2], ws.mask, 576, P, h, w, 576, 1, 1, 0, 0.25f), false, false), s));
         // occlusion + uncertainty heads (core/update.py:196-214)
-        {
+        const bool ou_fused = tiles_on && r->wou != nullptr && r->opt[MFTX_RAFT_OPT_FUSE_OU] != 0;
+        if (!ou_fused || r->opt[MFTX_RAFT_OPT_FUSE_OU] == 2) {         // (2: the fused kernel on the materialised input -- A/B, tests)
             const long long slots = (long long)M * 178;
             ProfScope prof(PC_GLUE, s, 0);
             hipLaunchKernelGGL(ou_gather_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, ws.hx,
                                ws.corr, ws.ld_corr, ccur, ws.delta, ws.ouin, flow_lr, M, h, w, SP ? 1 : 0);
             TRY(check_launch("ou_gather"));
         }
-        TRY(launch_conv(gemm(conv_desc(ws.ouin, 712, 712, nullptr, 0, 0, G[W_OU1], W[B_OU1], ws.ouh, 256, P, h, w, 256, 3, 3, 1), true, false), s));
-        TRY(launch_conv(conv_desc(ws.ouh, 256, 256, nullptr, 0, 0, W[W_OU2], W[B_OU2], ws.ou, 4, P, h, w, 3, 3, 3, 0), s));
+        if (ou_fused) {
+            // both layers of both heads as ONE tile-resident kernel (five channel passes over the 712-channel input, the 3 x 3 x 3 second
+            // layers as a projection epilogue; T -> ws.ouh) + a stencil sum; the input is gathered from its parts by the kernel's loader
+            const OuGather ga{ws.hx, ws.corr, ws.ld_corr, ccur, ws.delta, flow_lr};
+            const bool mat = r->opt[MFTX_RAFT_OPT_FUSE_OU] == 2;
+            TRY(launch_ou_heads(mat ? ws.ouin : nullptr, 712, P, h, w, r->wou, W[B_OU1], r->wouproj, W[B_OU2], ws.ouh, ws.ou, 4, r->opt[MFTX_RAFT_OPT_TILE_CELLS], s,
+                                mat ? nullptr : &ga));
+        } else {
+            TRY(launch_conv(gemm(conv_desc(ws.ouin, 712, 712, nullptr, 0, 0, G[W_OU1], W[B_OU1], ws.ouh, 256, P, h, w, 256, 3, 3, 1), true, false), s));
+            TRY(launch_conv(conv_desc(ws.ouh, 256, 256, nullptr, 0, 0, W[W_OU2], W[B_OU2], ws.ou, 4, P, h, w, 3, 3, 3, 0), s));
+        }
     }
     return 0;
     };   // core
@@ -677,6 +698,7 @@ static int refine_impl(mftx_raft *r, int P, int h, int w, int iters, const float
         key.v[4] = reinterpret_cast<uintptr_t>(workspace); key.v[5] = reinterpret_cast<uintptr_t>(flow_lr_out);
         key.v[6] = (uintptr_t)AR; key.v[7] = reinterpret_cast<uintptr_t>(r->wfused); key.v[8] = reinterpret_cast<uintptr_t>(s);
         key.v[9] = reinterpret_cast<uintptr_t>(r->wflow); key.v[10] = reinterpret_cast<uintptr_t>(r->wt[W_ZR1_DYN]); key.v[11] = reinterpret_cast<uintptr_t>(r->wproj);
+        key.v[12] = reinterpret_cast<uintptr_t>(r->wou);
         TRY(r->graphs->run(key, s, core));
     } else {
         TRY(core());
@@ -821,6 +843,15 @@ extern "C" int mftx_tile_conv_fills_chip(int P, int h, int w) {
     // smallest: at least half a round of 32-cell tiles (7 pairs of 256 x 256 pixels: 224 tiles, + 9 % frames/s over the ring-buffered
     // kernels; one pair of 512 x 512: 128 tiles, 2.38 vs 2.46 ms per refinement)
     return tile_conv_fills_chip(P, h, w, 3, 3) || tile_conv_small_tiles_fill(P, h, w) ? 1 : 0;
+}
+
+extern "C" int mftx_pack_ou_heads_weights(const float *w1pk, int cin_pad, const float *w2pk, void *wtile, void *wproj, void *stream) {
+    return launch_pack_ou_head(w1pk, cin_pad, w2pk, wtile, wproj, (hipStream_t)stream);
+}
+
+extern "C" int mftx_ou_heads(const float *a_split, int lda, int P, int h, int w, const void *wtile, const float *b1, const void *wproj, const float *b2,
+                             float *T, float *out, int ld_out, void *stream) {
+    return launch_ou_heads(a_split, lda, P, h, w, wtile, b1, wproj, b2, T, out, ld_out, 0, (hipStream_t)stream);
 }
 
 extern "C" int mftx_pack_flow_head_weights(const float *w2pk, void *wproj, void *stream) {

@@ -124,7 +124,7 @@ struct TcGeom {
     static constexpr int A_BYTES = HCELLS * CELLB, RED_BYTES = KS * CELLS * RED_ROW * 4;
     static constexpr int LDS = A_BYTES > RED_BYTES ? A_BYTES : RED_BYTES;
     static constexpr int PROJ_ROW = 20, PROJ_BYTES = 2 * CELLS * PROJ_ROW * 4;        // TC_RELU_PROJ: two K halves of [cell][18 (+ 2)] behind the parked sums
-    static_assert((CELLS == 128 || CELLS == 64 || CELLS == 32) && (N == 128 || N == 256) && (CIN == 128 || CIN == 256), "tile_conv: shapes");
+    static_assert((CELLS == 128 || CELLS == 64 || CELLS == 32) && (N == 128 || N == 256) && (CIN == 128 || CIN == 256 || CIN == 144), "tile_conv: shapes");
     static_assert(LDS <= 160 * 1024, "tile_conv: the input tile must fit the CU's LDS");
 };
 
@@ -672,6 +672,7 @@ static int gru_half_launch(GruHalfArgs a, hipStream_t s) {
 
 static int tc_num_cus();
 static bool tc_fills(long long tiles);
+int tile_conv_cells(int P, int h, int w, int kh);
 // tiles of the fused kernel for a pass over P maps of h x w cells with R tiles of th x tw cells
 long long gru_half_tiles(int P, int h, int w, int th, int tw, bool horiz) {
     const int along = horiz ? w : h, T = horiz ? tw : th;
@@ -713,6 +714,322 @@ int launch_gru_half(const GruHalfLaunch &d, hipStream_t s) {
     else { GH(64, 2, 5, 1); GH(32, 4, 5, 1); GH(64, 1, 5, 1); GH(32, 2, 5, 1); }
 #undef GH
     return fail(MFTX_E_STATE, "gru_half: no kernel for tiles of %d x %d cells", th, tw);
+}
+
+// ---- the occlusion + uncertainty heads in ONE kernel (core/update.py:177-214: two heads of conv3x3 712 -> 128, relu, conv3x3 -> 2 | 1) ----
+// Their first layers share the 712-channel input and are one 712 -> 256 GEMM; on the ring-buffered kernel that GEMM re-read its
+// 82 MB input nine times through L2 (360-720 MB fetched per launch) and a VALU kernel then read the 29 MB of hidden channels
+// back for the 3 x 3 x 3 second layers.  Here: 712 channels do not fit LDS at once (180 halo cells x 2.8 KB), so the tile is
+// loaded in FIVE channel passes of 144 (720 = 712 + 8 zero channels; 104 KB each), the accumulators live across the passes,
+// and the second layers are a projection epilogue like the flow head's (TC_RELU_PROJ): relu(. + bias), parked in LDS, times the
+// [256 x 27] matrix W2'[k][3 tap + o], 27 numbers per cell out -- ou_heads_sum_kernel adds the nine shifted terms.
+struct OuHeadArgs {
+    const float *a; int lda;        // the heads' input, split form, 712 channels at a + cell * lda floats -- or null: gathered from its parts
+    // gather mode (the engine): [net128 | inp128] = hx[0:256] and motion128 = hx[256:384] (split form), corr324 (fp32), flow = coords1 - grid,
+    // delta (core/update.py:197, core/raft.py:199-206) -- the concatenation is never materialised; flow_lr (the upsampler's input) is
+    // written for the tile's own cells on the way
+    const float *hx; const float *corr; int ld_corr; const float *coords1; const float *delta; float *flow_lr;
+    const void *wf;                 // launch_pack_ou_head: [nt][pass][tap][group][hi | lo][lane] x 16 bytes
+    const float *bias;              // [256]
+    const void *wproj; float *tout; // launch_pack_proj27; [M][27]
+    int P, h, w, tiles_x, tiles_y;
+};
+constexpr int OU_C = 712, OU_PASSES = 5, OU_CP = 144, OU_PROJ_ROW = 28;
+
+template <int TH, int TW, bool GATHER>
+__global__ __launch_bounds__(512, 2) void ou_head_kernel(OuHeadArgs p) {
+    using G = TcGeom<TH, TW, 3, 3, OU_CP, 256>;
+    constexpr int RT = G::RT, CELLS = G::CELLS, PF = 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tc_lds[];
+    unsigned char *lds = tc_lds;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = (int)blockIdx.x;
+    const int tx_ = tile % p.tiles_x, ty_ = (tile / p.tiles_x) % p.tiles_y, img = tile / (p.tiles_x * p.tiles_y);
+    const int x0 = tx_ * TW, y0 = ty_ * TH;
+    const long long img_base = (long long)img * p.h * p.w;
+    const uint4 *__restrict__ w2 = reinterpret_cast<const uint4 *>(p.wf) + (long long)(wv * OU_PASSES * G::STEPS) * 128 + lane;
+    tc_f32x16 acc[RT], accx[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accx[i][r] = 0.f; }
+    const unsigned char *abase[RT];
+    {
+        const int r = lane & 31;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int m = 32 * i + r;
+            abase[i] = lds + ((m / TW) * G::HWD + (m % TW)) * G::CELLB + (lane >> 5) * 32;
+        }
+    }
+#pragma unroll 1
+    for (int pass = 0; pass < OU_PASSES; ++pass) {
+        uint4 bq[PF][2];
+        const uint4 *__restrict__ wp = w2 + (long long)pass * G::STEPS * 128;
+#pragma unroll
+        for (int s = 0; s < PF; ++s) { bq[s][0] = wp[s * 128]; bq[s][1] = wp[s * 128 + 64]; }
+        if (pass) tc_barrier();          // every wave is done with the previous pass's channels
+        // ---- channels [144 pass, 144 pass + 144) of the tile (halo included) -> LDS; zeros outside the image and past channel 712
+        if constexpr (!GATHER) {
+            constexpr int PPC = OU_CP / 4, TOTAL = G::HCELLS * PPC, ROUNDS = (TOTAL + 511) / 512, B = 7;
+            const int pc_valid = pass == OU_PASSES - 1 ? (OU_C - (OU_PASSES - 1) * OU_CP) / 4 : PPC;        // 16-byte pieces that exist in this pass
+#pragma unroll 1
+            for (int rr = 0; rr < ROUNDS; rr += B) {
+                uint4 v[B];
+#pragma unroll
+                for (int k = 0; k < B; ++k) {
+                    const int q = (rr + k) * 512 + tid;
+                    v[k] = make_uint4(0u, 0u, 0u, 0u);
+                    if (rr + k < ROUNDS && q < TOTAL) {
+                        const int c = q / PPC, pc = q - c * PPC;
+                        const int cy = c / G::HWD, cx = c - cy * G::HWD;
+                        const int yy = y0 - 1 + cy, xx = x0 - 1 + cx;
+                        if (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w && pc < pc_valid)
+                            v[k] = *reinterpret_cast<const uint4 *>(p.a + (img_base + (long long)yy * p.w + xx) * p.lda + pass * OU_CP + pc * 4);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < B; ++k) {
+                    const int q = (rr + k) * 512 + tid;
+                    if (rr + k < ROUNDS && q < TOTAL) {
+                        const int c = q / PPC, pc = q - c * PPC;
+                        *reinterpret_cast<uint4 *>(lds + c * G::CELLB + pc * 16) = v[k];
+                    }
+                }
+            }
+        } else {
+            // by groups of 8 channels (32 bytes of split form): group Gi = 18 pass + gl of the 90 is
+            //   Gi < 32: hx[8 Gi ..] (split) | 32 <= Gi < 72: corr[8 (Gi - 32) ..] (fp32: split here) | Gi = 72: corr[320..323], flow, delta |
+            //   73 <= Gi < 89: hx[256 + 8 (Gi - 73) ..] (split) | Gi = 89: the zero pad
+            constexpr int GPC = OU_CP / 8, TOTAL = G::HCELLS * GPC, ROUNDS = (TOTAL + 511) / 512, B = 4;
+            const float k2048l = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));
+#pragma unroll 1
+            for (int rr = 0; rr < ROUNDS; rr += B) {
+                tc_f32x4 v0[B], v1[B];
+                int kind[B];                                   // 0 zeros, 1 split form as is, 2 fp32 to be split
+#pragma unroll
+                for (int k = 0; k < B; ++k) {
+                    const int q = (rr + k) * 512 + tid;
+                    v0[k] = tc_f32x4{0.f, 0.f, 0.f, 0.f}; v1[k] = v0[k]; kind[k] = 0;
+                    if (rr + k < ROUNDS && q < TOTAL) {
+                        const int c = q / GPC, gl = q - c * GPC, Gi = GPC * pass + gl;
+                        const int cy = c / G::HWD, cx = c - cy * G::HWD;
+                        const int yy = y0 - 1 + cy, xx = x0 - 1 + cx;
+                        if (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w && Gi < 89) {
+                            const long long cell = img_base + (long long)yy * p.w + xx;
+                            if (Gi < 32 || Gi >= 73) {
+                                const float *src = p.hx + cell * 384 + (Gi < 32 ? 8 * Gi : 256 + 8 * (Gi - 73));
+                                v0[k] = *reinterpret_cast<const tc_f32x4 *>(src); v1[k] = *reinterpret_cast<const tc_f32x4 *>(src + 4); kind[k] = 1;
+                            } else if (Gi < 72) {
+                                const float *src = p.corr + cell * p.ld_corr + 8 * (Gi - 32);
+                                v0[k] = *reinterpret_cast<const tc_f32x4 *>(src); v1[k] = *reinterpret_cast<const tc_f32x4 *>(src + 4); kind[k] = 2;
+                            } else {
+                                v0[k] = *reinterpret_cast<const tc_f32x4 *>(p.corr + cell * p.ld_corr + 320);
+                                const float2 cc = reinterpret_cast<const float2 *>(p.coords1)[cell], dd = reinterpret_cast<const float2 *>(p.delta)[cell];
+                                const float fx = cc.x - (float)xx, fy = cc.y - (float)yy;
+                                v1[k] = tc_f32x4{fx, fy, dd.x, dd.y}; kind[k] = 2;
+                                if (cy >= 1 && cy <= TH && cx >= 1 && cx <= TW) reinterpret_cast<float2 *>(p.flow_lr)[cell] = make_float2(fx, fy);    // the tile's own cells
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < B; ++k) {
+                    const int q = (rr + k) * 512 + tid;
+                    if (rr + k < ROUNDS && q < TOTAL) {
+                        const int c = q / GPC, gl = q - c * GPC;
+                        tc_u32x4 hi = __builtin_bit_cast(tc_u32x4, v0[k]), lo = __builtin_bit_cast(tc_u32x4, v1[k]);
+                        if (kind[k] == 2) tc_split8(v0[k], v1[k], k2048l, hi, lo);
+                        *reinterpret_cast<tc_u32x4 *>(lds + c * G::CELLB + gl * 32) = hi;
+                        *reinterpret_cast<tc_u32x4 *>(lds + c * G::CELLB + gl * 32 + 16) = lo;
+                    }
+                }
+            }
+        }
+        tc_barrier();
+        tc_kloop<G, 3>(abase, wp, bq, acc, accx);
+    }
+    tc_barrier();           // every wave is done with the input tile: its space takes the sums
+
+    // ---- relu(. + bias), parked [cell][256]; then the second layers as the [256 x 27] projection (as TC_RELU_PROJ)
+    const float inv2048 = 1.f / 2048.f;
+    float *red = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            tc_f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * b + e] + accx[i][4 * b + e] * inv2048;
+            *reinterpret_cast<tc_f32x4 *>(red + (32 * i + (lane & 31)) * G::RED_ROW + 32 * wv + 8 * b + 4 * (lane >> 5)) = v;
+        }
+    tc_barrier();
+    const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));
+    const int mt = wv & 3, kh = wv >> 2;
+    const uint4 *__restrict__ wpj = reinterpret_cast<const uint4 *>(p.wproj) + lane;
+    float *tp = reinterpret_cast<float *>(lds + G::RED_BYTES);
+    if (mt < RT) {
+        tc_f32x16 d, dx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { d[r] = 0.f; dx[r] = 0.f; }
+        const float *xrow = red + (32 * mt + (lane & 31)) * G::RED_ROW + 8 * (lane >> 5);
+#pragma unroll
+        for (int gg = 0; gg < 8; ++gg) {
+            const int g = 8 * kh + gg;
+            tc_f32x4 u = *reinterpret_cast<const tc_f32x4 *>(xrow + 16 * g), v = *reinterpret_cast<const tc_f32x4 *>(xrow + 16 * g + 4);
+            u += *reinterpret_cast<const tc_f32x4 *>(p.bias + 16 * g + 8 * (lane >> 5));
+            v += *reinterpret_cast<const tc_f32x4 *>(p.bias + 16 * g + 8 * (lane >> 5) + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { u[e] = relu_keep_nan(u[e]); v[e] = relu_keep_nan(v[e]); }
+            tc_u32x4 hi, lo;
+            tc_split8(u, v, k2048, hi, lo);
+            const tc_f16x8 wh = __builtin_bit_cast(tc_f16x8, wpj[(g * 2) * 64]), wl = __builtin_bit_cast(tc_f16x8, wpj[(g * 2 + 1) * 64]);
+            asm volatile("s_nop 1" : "+v"(hi), "+v"(lo));
+            const tc_f16x8 xh = __builtin_bit_cast(tc_f16x8, hi), xl = __builtin_bit_cast(tc_f16x8, lo);
+            d = tc_mfma(wh, xh, d);
+            dx = tc_mfma(wl, xh, dx);
+            dx = tc_mfma(wh, xl, dx);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int j0 = 8 * b + 4 * (lane >> 5);          // this lane's outputs j0 .. j0 + 3 of cell 32 mt + (lane & 31); 27 exist
+            if (j0 < OU_PROJ_ROW) {
+                tc_f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = d[4 * b + e] + dx[4 * b + e] * inv2048;
+                *reinterpret_cast<tc_f32x4 *>(tp + (kh * CELLS + 32 * mt + (lane & 31)) * OU_PROJ_ROW + j0) = v;
+            }
+        }
+    }
+    tc_barrier();
+    for (int idx = tid; idx < CELLS * 27; idx += 512) {
+        const int m = idx / 27, j = idx - m * 27;
+        const int yy = y0 + m / TW, xx = x0 + m % TW;
+        if (yy < p.h && xx < p.w)
+            p.tout[(img_base + (long long)yy * p.w + xx) * 27 + j] = tp[m * OU_PROJ_ROW + j] + tp[(CELLS + m) * OU_PROJ_ROW + j];
+    }
+}
+
+// the first layers' weight in the GEMM's packed form [>= 256 rows][9 taps][cin_pad >= 712] fp32 -> the kernel's stream
+__global__ void pack_ou_head_kernel(const float *__restrict__ wpk, int cin_pad, uint4 *__restrict__ out, long long pieces) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= pieces) return;
+    constexpr int GP = OU_CP / 16, STEPS = 9 * GP;
+    const int lane = (int)(idx & 63), part = (int)((idx >> 6) & 1);
+    const long long t = idx >> 7;
+    const int step = (int)(t % STEPS), pass = (int)((t / STEPS) % OU_PASSES), nt = (int)(t / STEPS / OU_PASSES);
+    const int tap = step / GP, g = step % GP;
+    const int n = 32 * nt + (lane & 31);
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = OU_CP * pass + 16 * g + 8 * (lane >> 5) + 2 * e;
+        const long long base = ((long long)n * 9 + tap) * cin_pad + c;
+        const unsigned a = split_halves(c < OU_C ? wpk[base] : 0.f), b = split_halves(c + 1 < OU_C ? wpk[base + 1] : 0.f);
+        w[e] = part ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+    }
+    out[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// the second layers' weight [>= 3 rows][9 taps][256] fp32 -> MFMA A fragments of the [27 (+ 5 zero rows) x 256] matrix W2'[j = 3 tap + o][k]
+__global__ void pack_proj27_kernel(const float *__restrict__ w2pk, uint4 *__restrict__ out) {
+    const int idx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (idx >= 16 * 2 * 64) return;
+    const int lane = idx & 63, part = (idx >> 6) & 1, g = idx >> 7;
+    const int j = lane & 31;
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = 16 * g + 8 * (lane >> 5) + 2 * e;
+        const float v0 = j < 27 ? w2pk[((long long)(j % 3) * 9 + (j / 3)) * 256 + k] : 0.f;
+        const float v1 = j < 27 ? w2pk[((long long)(j % 3) * 9 + (j / 3)) * 256 + k + 1] : 0.f;
+        const unsigned a = split_halves(v0), b = split_halves(v1);
+        w[e] = part ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+    }
+    out[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// out[c][o] = b2[o] + sum over the 9 taps of T[c + (dy - 1, dx - 1)][3 (3 dy + dx) + o], neighbours outside the image contributing nothing
+__global__ __launch_bounds__(256) void ou_heads_sum_kernel(const float *__restrict__ T, const float *__restrict__ b2, float *__restrict__ out, int ld_out,
+                                                           int P, int h, int w) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over cells x 4 (3 used)
+    if (i >= (long long)P * h * w * 4) return;
+    const int o = (int)(i & 3);
+    if (o == 3) return;
+    const long long cell = i >> 2;
+    const int rem = (int)(cell % ((long long)h * w)), y = rem / w, x = rem - y * w;
+    float sum = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int yy = y + dy - 1, xx = x + dx - 1;
+            if (yy >= 0 && yy < h && xx >= 0 && xx < w) sum += T[(cell + (long long)(dy - 1) * w + (dx - 1)) * 27 + 3 * (3 * dy + dx) + o];
+        }
+    out[cell * ld_out + o] = sum + b2[o];
+}
+
+int launch_pack_ou_head(const float *w1pk, int cin_pad, const float *w2pk, void *wtile, void *wproj, hipStream_t s) {
+    if (!w1pk || !w2pk || !wtile || !wproj) return fail(MFTX_E_ARG, "pack_ou_head_weights: null pointer");
+    if (cin_pad < OU_C) return fail(MFTX_E_ARG, "pack_ou_head_weights: the first layers have 712 input channels");
+    if (!aligned16(wtile) || !aligned16(wproj)) return fail(MFTX_E_ALIGN, "pack_ou_head_weights: outputs not 16-byte aligned");
+    const long long pieces = 8ll * OU_PASSES * 9 * (OU_CP / 16) * 128;
+    hipLaunchKernelGGL(pack_ou_head_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, w1pk, cin_pad, reinterpret_cast<uint4 *>(wtile), pieces);
+    hipLaunchKernelGGL(pack_proj27_kernel, dim3(8), dim3(256), 0, s, w2pk, reinterpret_cast<uint4 *>(wproj));
+    return check_launch("pack_ou_head");
+}
+
+template <int TH, int TW, bool GATHER>
+static int ou_head_launch(OuHeadArgs a, hipStream_t s) {
+    using G = TcGeom<TH, TW, 3, 3, OU_CP, 256>;
+    constexpr int lds_bytes = (G::A_BYTES > G::RED_BYTES ? G::A_BYTES : G::RED_BYTES) + 2 * G::CELLS * OU_PROJ_ROW * 4;
+    static_assert(G::RED_BYTES + 2 * G::CELLS * OU_PROJ_ROW * 4 <= 160 * 1024 && lds_bytes <= 160 * 1024, "ou_head: LDS");
+    a.tiles_x = cdiv(a.w, TW); a.tiles_y = cdiv(a.h, TH);
+    const long long tiles = (long long)a.P * a.tiles_x * a.tiles_y;
+    if (tiles > 0x7fffffffLL) return fail(MFTX_E_ARG, "ou_heads: too many tiles");
+    auto kern = ou_head_kernel<TH, TW, GATHER>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+            return fail(MFTX_E_STATE, "ou_heads: cannot reserve %d bytes of LDS", lds_bytes);
+        attr_set = true;
+    }
+    ProfScope prof(PC_CONV_GEMM, s, 2.0 * a.P * a.h * a.w * (256.0 * 9 * OU_C + 256.0 * 27));
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds_bytes, s, a);
+    return check_launch("ou_heads");
+}
+
+// a: the heads' input [M][lda] in split form (712 channels), or null with its parts in `ga` (the engine); T: [M][27] scratch;
+// out[M][ld_out]: occlusion logits 0, 1 and log-variance
+int launch_ou_heads(const float *a, int lda, int P, int h, int w, const void *wtile, const float *b1, const void *wproj, const float *b2, float *T,
+                    float *out, int ld_out, int cells, hipStream_t s, const OuGather *ga) {
+    if ((!a && !ga) || !wtile || !b1 || !wproj || !b2 || !T || !out) return fail(MFTX_E_ARG, "ou_heads: null pointer");
+    if (P <= 0 || h <= 0 || w <= 0 || ld_out < 3) return fail(MFTX_E_ARG, "ou_heads: bad sizes");
+    if (!aligned16(wtile) || !aligned16(wproj) || !aligned16(b1) || !aligned16(T))
+        return fail(MFTX_E_ALIGN, "ou_heads: weights, bias and scratch 16-byte aligned");
+    OuHeadArgs k{};
+    k.wf = wtile; k.bias = b1; k.wproj = wproj; k.tout = T; k.P = P; k.h = h; k.w = w;
+    if (ga) {
+        if (!ga->hx || !ga->corr || !ga->coords1 || !ga->delta || !ga->flow_lr) return fail(MFTX_E_ARG, "ou_heads: null pointer among the input's parts");
+        if ((reinterpret_cast<uintptr_t>(ga->hx) & 31) || !aligned16(ga->corr) || ga->ld_corr % 4 || ga->ld_corr < 324 || (reinterpret_cast<uintptr_t>(ga->coords1) & 7) ||
+            (reinterpret_cast<uintptr_t>(ga->delta) & 7) || (reinterpret_cast<uintptr_t>(ga->flow_lr) & 7))
+            return fail(MFTX_E_ALIGN, "ou_heads: hx 32-byte, corr 16-byte (row stride a multiple of 4), coordinates 8-byte aligned");
+        k.hx = ga->hx; k.corr = ga->corr; k.ld_corr = ga->ld_corr; k.coords1 = ga->coords1; k.delta = ga->delta; k.flow_lr = ga->flow_lr;
+    } else {
+        if ((reinterpret_cast<uintptr_t>(a) & 31) || lda % 8 || lda < OU_C) return fail(MFTX_E_ALIGN, "ou_heads: split-form rows are 32-byte aligned with strides in multiples of 8");
+        k.a = a; k.lda = lda;
+    }
+    if (!cells) cells = tile_conv_cells(P, h, w, 3);
+    int e;
+    if (cells == 128) e = ga ? ou_head_launch<8, 16, true>(k, s) : ou_head_launch<8, 16, false>(k, s);
+    else if (cells == 64) e = ga ? ou_head_launch<4, 16, true>(k, s) : ou_head_launch<4, 16, false>(k, s);
+    else if (cells == 32) e = ga ? ou_head_launch<2, 16, true>(k, s) : ou_head_launch<2, 16, false>(k, s);
+    else return fail(MFTX_E_ARG, "ou_heads: 128, 64 or 32 cells per tile");
+    if (e) return e;
+    const long long n = (long long)P * h * w * 4;
+    ProfScope prof(PC_CONV_SMALL, s, 2.0 * P * h * w * 3 * 9);
+    hipLaunchKernelGGL(ou_heads_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, T, b2, out, ld_out, P, h, w);
+    return check_launch("ou_heads_sum");
 }
 
 // ---- weights: the GEMM's packed form [>= N rows][taps][cin_pad] fp32 -> [nt][ks][step][hi | lo][lane] x 16 bytes

@@ -427,6 +427,36 @@ def pack_flow_head_weights(w2pk: torch.Tensor, check_range: bool = True) -> torc
     return out
 
 
+def pack_ou_heads_weights(w1pk: torch.Tensor, w2pk: torch.Tensor, check_range: bool = True):
+    """The occlusion + uncertainty heads' layers in the ``pack_conv_weight`` form -- first layers stacked [>= 256, 9, cin_pad >= 712],
+    second layers block-diagonal [>= 3, 9, 256] -> (wtile, wproj) of ``mftx_ou_heads`` (opaque bytes)."""
+    lib = _lib.load()
+    if w1pk.dim() != 3 or w1pk.shape[0] < 256 or w1pk.shape[1] != 9 or w1pk.shape[2] < 712:
+        raise MftxError("pack_ou_heads_weights: expected the packed first layers [>= 256, 9, >= 712]")
+    if w2pk.dim() != 3 or w2pk.shape[0] < 3 or tuple(w2pk.shape[1:]) != (9, 256):
+        raise MftxError("pack_ou_heads_weights: expected the packed second layers [>= 3, 9, 256]")
+    if check_range and (count_not_below(w1pk, _lib.SPLIT_LIMIT) or count_not_below(w2pk, _lib.SPLIT_LIMIT)):
+        raise SplitRangeError(f"pack_ou_heads_weights: weights not below {_lib.SPLIT_LIMIT} in magnitude")
+    wtile = torch.empty(_lib.OU_HEADS_WTILE_BYTES, dtype=torch.uint8, device=w1pk.device)
+    wproj = torch.empty(_lib.FLOW_HEAD_WEIGHT_BYTES, dtype=torch.uint8, device=w1pk.device)
+    check(lib.mftx_pack_ou_heads_weights(_chk(w1pk, "w1pk"), w1pk.shape[2], _chk(w2pk, "w2pk"), wtile.data_ptr(), wproj.data_ptr(), _stream()),
+          "mftx_pack_ou_heads_weights")
+    return wtile, wproj
+
+
+def ou_heads(a_split: torch.Tensor, h: int, w: int, wtile: torch.Tensor, b1, wproj: torch.Tensor, b2):
+    """Both layers of the occlusion and uncertainty heads (``mftx_ou_heads``): a_split [P*h*w, 712] split-form rows ->
+    [P*h*w, 4] = occlusion logits 0, 1, log-variance, (unused)."""
+    lib = _lib.load()
+    M = a_split.shape[0]
+    P = M // (h * w)
+    T = torch.empty(M, 27, dtype=torch.float32, device=a_split.device)
+    out = torch.zeros(M, 4, dtype=torch.float32, device=a_split.device)
+    check(lib.mftx_ou_heads(_chk(a_split, "a"), a_split.shape[1], P, h, w, _chk(wtile, "wtile", torch.uint8), _chk(b1, "b1"),
+                            _chk(wproj, "wproj", torch.uint8), _chk(b2, "b2"), T.data_ptr(), out.data_ptr(), 4, _stream()), "mftx_ou_heads")
+    return out
+
+
 def flow_head(hsplit: torch.Tensor, h: int, w: int, wtile: torch.Tensor, b1, wproj: torch.Tensor, b2, coords=None):
     """delta = conv2(relu(conv1(h))) of the flow head without materialising the 256 hidden channels (``mftx_flow_head``):
     hsplit [P*h*w, >= 128] split-form rows -> delta [P*h*w, 2]; coords (optional, [P*h*w, 2]) += delta in place."""
@@ -691,7 +721,7 @@ class RaftEngine:
     # WeightSlot indices (csrc/raft_engine.hip) of the weights that feed GEMM layers
     GEMM_SLOTS = (0, 2, 6, 8, 10, 11, 13, 14, 16, 17, 19, 20, 22, 26, 28, 30)
 
-    OPTIONS = {"fork": 0, "presplit": 1, "group": 2, "fuse_lookup": 3, "graph": 4, "fuse_flow": 5, "tile_conv": 6, "fuse_head": 7, "tile_volume": 8, "fuse_gru": 9, "tile_cells": 10}      # MFTX_RAFT_OPT_*
+    OPTIONS = {"fork": 0, "presplit": 1, "group": 2, "fuse_lookup": 3, "graph": 4, "fuse_flow": 5, "tile_conv": 6, "fuse_head": 7, "tile_volume": 8, "fuse_gru": 9, "tile_cells": 10, "fuse_ou": 11}      # MFTX_RAFT_OPT_*
     # WeightSlot -> (N, cin) of the layers with a tile-resident kernel (csrc/tile_conv.hip): GRU gates (per-iteration and
     # context parts, both passes), flow head and mask head first layers
     TILE_SLOTS = {10: (256, 256), 11: (256, 128), 13: (128, 256), 14: (128, 128), 16: (256, 256), 17: (256, 128),
@@ -727,6 +757,9 @@ class RaftEngine:
             # ... and the flow head's last layer as the projection epilogue of its first (the 256 hidden channels stay in LDS)
             self.wproj = pack_flow_head_weights(self.weights[24])
             check(lib.mftx_raft_set_flow_head(self._h, self.wproj.data_ptr()), "mftx_raft_set_flow_head")
+            # ... and the occlusion + uncertainty heads as one tile-resident kernel (five channel passes, projection epilogue)
+            self.wou, self.wouproj = pack_ou_heads_weights(self.weights[30], self.weights[32])
+            check(lib.mftx_raft_set_ou_heads(self._h, self.wou.data_ptr(), self.wouproj.data_ptr()), "mftx_raft_set_ou_heads")
         elif self.arith != ARITH_F32:
             raise MftxError(f"unknown arithmetic {arith!r}")
         # device-side count of non-finite output pixels, incremented by the last kernel of every refinement (no host sync;

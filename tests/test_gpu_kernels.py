@@ -1190,6 +1190,58 @@ def test_gru_half_vs_fp64(ops_mod, P, h, w, vertical):
                                                 hs.data_ptr(), 128, P, h, w, 0, None), "mftx_gru_half")
 
 
+@pytest.mark.parametrize("P,h,w", [(1, 16, 24), (2, 21, 37), (1, 64, 64), (1, 5, 3)])
+def test_ou_heads_fused_vs_fp64(ops_mod, P, h, w):
+    """Both layers of the occlusion and uncertainty heads as one tile-resident kernel (five channel passes over the 712-channel
+    input, projection epilogue) + the stencil sum (mftx_ou_heads) against the four convolutions in fp64 (core/update.py:177-214)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(17 + h)
+    M = P * h * w
+    x = torch.randn(M, 712, generator=g) * torch.exp(0.5 * torch.randn(M, 712, generator=g))
+    wo1, wu1 = torch.randn(128, 712, 3, 3, generator=g) * 0.02, torch.randn(128, 712, 3, 3, generator=g) * 0.02
+    bo1, bu1 = torch.randn(128, generator=g) * 0.1, torch.randn(128, generator=g) * 0.1
+    wo2, wu2 = torch.randn(2, 128, 3, 3, generator=g) * 0.05, torch.randn(1, 128, 3, 3, generator=g) * 0.05
+    bo2, bu2 = torch.randn(2, generator=g), torch.randn(1, generator=g)
+    w1 = torch.cat([wo1, wu1], 0)
+    w2 = torch.zeros(3, 256, 3, 3)
+    w2[0:2, 0:128] = wo2
+    w2[2:3, 128:256] = wu2
+    wtile, wproj = ops_mod.pack_ou_heads_weights(ops_mod.pack_conv_weight(w1.cuda()), ops_mod.pack_conv_weight(w2.cuda()))
+    got = ops_mod.ou_heads(ops_mod.split_activations(x.cuda()), h, w, wtile, torch.cat([bo1, bu1]).cuda(), wproj, torch.cat([bo2, bu2]).cuda())
+    xm = x.double().reshape(P, h, w, 712).permute(0, 3, 1, 2)
+    occ = F.conv2d(torch.relu(F.conv2d(xm, wo1.double(), bo1.double(), padding=1)), wo2.double(), bo2.double(), padding=1)
+    unc = F.conv2d(torch.relu(F.conv2d(xm, wu1.double(), bu1.double(), padding=1)), wu2.double(), bu2.double(), padding=1)
+    want = torch.cat([occ, unc], 1).permute(0, 2, 3, 1).reshape(M, 3)
+    scale = max(float(want.abs().max()), 1.0)
+    assert float((got[:, :3].cpu().double() - want).abs().max()) < 5e-6 * scale
+    # ... and against the two launches it replaces (ring-buffered GEMM + small-N kernel): fp32 rounding of the K sums
+    hid = ops_mod.conv2d(ops_mod.split_activations(x.cuda()), ops_mod.split_weights(ops_mod.pack_conv_weight(w1.cuda())), torch.cat([bo1, bu1]).cuda(),
+                         P, h, w, 256, 3, 3, act="relu", arith=ops_mod.ARITH_SPLIT, a_split=True)
+    two = ops_mod.conv2d(hid, ops_mod.pack_conv_weight(w2.cuda()), torch.cat([bo2, bu2]).cuda(), P, h, w, 3, 3, 3)
+    assert float((got[:, :3] - two[:, :3]).abs().max()) < 5e-6 * scale
+
+
+def test_engine_fused_ou_heads_matches_two_kernels():
+    """The engine with the occlusion / uncertainty heads as one tile-resident kernel (the default where the tile-resident layers
+    run) against the 712 -> 256 GEMM + small-N kernel: the flow is untouched (the heads come after the last update), occlusion and
+    sigma agree to fp32 rounding."""
+    fused, apart = _engine_outputs({"tile_conv": 2}), _engine_outputs({"tile_conv": 2, "fuse_ou": 0})
+    assert np.isfinite(fused).all()
+    n = 3 * 2 * 192 * 320
+    assert np.array_equal(fused[:n], apart[:n])
+    assert np.abs(fused[n:] - apart[n:]).max() < 1e-4
+    cells = [_engine_outputs({"tile_conv": 2, "tile_cells": c}) for c in (64, 32)]
+    assert np.array_equal(cells[0], fused) and np.array_equal(cells[1], fused)
+    # the heads' 712-channel input gathered from its parts by the kernel's loader (the default) or materialised first (2).  Not bit for
+    # bit: ou_gather decodes the split-form state (hi + lo / 2048) and splits it again, which lands on another pair of halves in rare
+    # rounding ties; the loader copies the halves as they are -- an ulp in a few inputs
+    for args in ((3, 24, 40, 4), (1, 33, 47, 2)):
+        mat, gat = _engine_outputs({"tile_conv": 2, "fuse_ou": 2}, *args), _engine_outputs({"tile_conv": 2}, *args)
+        nn = args[0] * 2 * 64 * args[1] * args[2]
+        assert np.array_equal(mat[:nn], gat[:nn])            # the flow (flow_lr written by the loader) is the same
+        assert np.abs(mat[nn:] - gat[nn:]).max() < 1e-5
+
+
 @pytest.mark.parametrize("P,h,w", [(1, 8, 16), (2, 21, 37), (1, 64, 64), (1, 3, 5)])
 def test_flow_head_fused_vs_fp64(ops_mod, P, h, w):
     """Both layers of the flow head as the tile-resident kernel with the projection epilogue + the stencil sum
