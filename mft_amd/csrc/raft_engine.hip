@@ -662,12 +662,14 @@ static int refine_impl(mftx_raft *r, int P, int h, int w, int iters, const float
             return fail(MFTX_E_STATE, "raft_refine: coords trace copy failed");
         // The upsampling mask is consumed only after the last iteration in test
         // mode (core/raft.py:190-196,234-239), so it is computed once.
+        // (the hidden 256 channels go to the 1 x 1 layer in split form: a GEMM that splits its A operand in registers runs at half the
+        // matrix utilisation of one that finds it split -- profiles/r4h_pmc_mfma_util.csv: 0.18 against 0.35)
         if (tile_w(W_MASK0)) {
             TileConvLaunch t = tile_layer(ws.hx, 384, nullptr, 0, tile_w(W_MASK0), W[B_MASK0], 256, 3, 3, 1);
-            t.out = ws.fh; t.ldo = 256;
+            t.out = ws.fh; t.ldo = 256; t.out_split = SP ? 1 : 0;
             TRY(launch_tile_conv(t, s));
-        } else TRY(launch_conv(gemm(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, G[W_MASK0], W[B_MASK0], ws.fh, 256, P, h, w, 256, 3, 3, 1), true, false), s));
-        TRY(launch_conv(gemm(conv_desc(ws.fh, 256, 256, nullptr, 0, 0, G[W_MASK2], W[B_MASK2], ws.mask, 576, P, h, w, 576, 1, 1, 0, 0.25f), false, false), s));
+        } else TRY(launch_conv(gemm(conv_desc(ws.hx, 384, 128, nullptr, 0, 0, G[W_MASK0], W[B_MASK0], ws.fh, 256, P, h, w, 256, 3, 3, 1), true, true), s));
+        TRY(launch_conv(gemm(conv_desc(ws.fh, 256, 256, nullptr, 0, 0, G[W_MASK2], W[B_MASK2], ws.mask, 576, P, h, w, 576, 1, 1, 0, 0.25f), true, false), s));
         // occlusion + uncertainty heads (core/update.py:196-214)
         const bool ou_fused = tiles_on && r->wou != nullptr && r->opt[MFTX_RAFT_OPT_FUSE_OU] != 0;
         if (!ou_fused || r->opt[MFTX_RAFT_OPT_FUSE_OU] == 2) {         // (2: the fused kernel on the materialised input -- A/B, tests)
