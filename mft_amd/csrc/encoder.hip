@@ -118,30 +118,42 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const double *__
 // y = relu((x - mean) * rstd)            [mode 0]
 // y = relu(res + relu((x - mean)*rstd))  [mode 1: residual block tail]
 // y = (x - mean) * rstd                  [mode 2: shortcut branch, no activation]
+// split != 0 (split arithmetic, round 4): y is written IN SPLIT FORM (common.h) -- the convolution that reads it then finds its A
+// operand split instead of splitting it in registers for every output tile -- and `res`, an earlier output of this kernel, is read
+// from it.  A thread owns 8 consecutive channels: the 32 bytes of the group it reads are the 32 bytes it writes (in place).
 __global__ __launch_bounds__(256) void instnorm_apply_kernel(float *__restrict__ x, int rows, int C,
                                                              const float *__restrict__ stat,
-                                                             const float *__restrict__ res, int mode) {
+                                                             const float *__restrict__ res, int mode, int split) {
     __shared__ float mean_s[256], rstd_s[256];
     for (int c = threadIdx.x; c < C; c += blockDim.x) { mean_s[c] = stat[2 * c]; rstd_s[c] = stat[2 * c + 1]; }
     __syncthreads();
-    const long long n4 = (long long)rows * C / 4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 4) % C);
-        float4 v = reinterpret_cast<float4 *>(x)[i];
-        float o[4] = {v.x, v.y, v.z, v.w};
-        float rr[4] = {0.f, 0.f, 0.f, 0.f};
+    const long long n8 = (long long)rows * C / 8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const long long e = i * 8, r = e / C;
+        const int c = (int)(e - r * C);
+        const float4 va = reinterpret_cast<const float4 *>(x)[2 * i], vb = reinterpret_cast<const float4 *>(x)[2 * i + 1];
+        float o[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        float rr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (mode == 1) {
-            const float4 rv = reinterpret_cast<const float4 *>(res)[i];
-            rr[0] = rv.x; rr[1] = rv.y; rr[2] = rv.z; rr[3] = rv.w;
+            float4 ra, rb;
+            if (split) { ra = load_split4(res + r * C, c); rb = load_split4(res + r * C, c + 4); }
+            else { ra = reinterpret_cast<const float4 *>(res)[2 * i]; rb = reinterpret_cast<const float4 *>(res)[2 * i + 1]; }
+            rr[0] = ra.x; rr[1] = ra.y; rr[2] = ra.z; rr[3] = ra.w; rr[4] = rb.x; rr[5] = rb.y; rr[6] = rb.z; rr[7] = rb.w;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 8; ++k) {
             float t = (o[k] - mean_s[c + k]) * rstd_s[c + k];
             if (mode != 2) t = relu_keep_nan(t);
             if (mode == 1) t = relu_keep_nan(rr[k] + t);
             o[k] = t;
         }
-        reinterpret_cast<float4 *>(x)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        if (split) {
+            store_split4v(x + r * C, c, make_float4(o[0], o[1], o[2], o[3]));
+            store_split4v(x + r * C, c + 4, make_float4(o[4], o[5], o[6], o[7]));
+        } else {
+            reinterpret_cast<float4 *>(x)[2 * i] = make_float4(o[0], o[1], o[2], o[3]);
+            reinterpret_cast<float4 *>(x)[2 * i + 1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
     }
 }
 
@@ -254,12 +266,13 @@ struct Enc {
     EncWs ws;
     hipStream_t s;
 
+    // a_split / out_split (split arithmetic only): the input is / the output is written in split form
     int conv(int slot, const float *in, int cin, int lda, int hin, int win, float *out, int cout, int ldo, int h,
-             int w, int k, int stride, int act, const float *residual = nullptr, int w_row0 = 0) {
+             int w, int k, int stride, int act, const float *residual = nullptr, bool a_split = false, bool out_split = false) {
         mftx_conv_desc d{};
         d.a0 = in; d.lda0 = lda; d.c0 = cin;
         d.wpk = e->wg[slot]; d.bias = e->b[slot]; d.arith = e->arith;
-        (void)w_row0;
+        d.a_split = SP() && a_split; d.out_split = SP() && out_split;
         d.out = out; d.ldo = ldo; d.P = 1; d.h = h; d.w = w; d.N = cout; d.kh = k; d.kw = k;
         d.act = act; d.out_scale = 1.f;
         d.stride = stride; d.hin = hin; d.win = win;
@@ -267,6 +280,7 @@ struct Enc {
         ProfConvCat cat(PC_ENC_GEMM);
         return launch_conv(d, s);
     }
+    bool SP() const { return e->arith == MFTX_ARITH_SPLIT; }
     int norm(float *x, int rows, int C, int mode, const float *res = nullptr) {
         {
             ProfScope prof(PC_ENC_NORM, s, 4.0 * rows * C);
@@ -278,11 +292,11 @@ struct Enc {
             hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, s, ws.part, rows, C, ws.stat);
         }
         TRY(check_launch("instnorm_finalize"));
-        const long long n4 = (long long)rows * C / 4;
-        const int blocks = (int)std::min<long long>((n4 + 255) / 256, 4096);
+        const long long n8 = (long long)rows * C / 8;
+        const int blocks = (int)std::min<long long>((n8 + 255) / 256, 4096);
         {
             ProfScope prof(PC_ENC_NORM, s, (mode == 1 ? 12.0 : 8.0) * rows * C);
-            hipLaunchKernelGGL(instnorm_apply_kernel, dim3(blocks), dim3(256), 0, s, x, rows, C, ws.stat, res, mode);
+            hipLaunchKernelGGL(instnorm_apply_kernel, dim3(blocks), dim3(256), 0, s, x, rows, C, ws.stat, res, mode, SP() ? 1 : 0);
         }
         return check_launch("instnorm_apply");
     }
@@ -291,25 +305,28 @@ struct Enc {
               int planes, int h, int w, int stride) {
         const int rows = h * w;
         if (e->instance_norm) {
-            TRY(conv(c1, x, cin, cin, hin, win, tmp, planes, planes, h, w, 3, stride, 0));
+            // (split arithmetic: every normalised map is in split form -- written so by instnorm_apply -- and every convolution here
+            // reads such a map; the convolutions' own outputs stay fp32 for the statistics)
+            TRY(conv(c1, x, cin, cin, hin, win, tmp, planes, planes, h, w, 3, stride, 0, nullptr, true));
             TRY(norm(tmp, rows, planes, 0));
-            TRY(conv(c2, tmp, planes, planes, h, w, out, planes, planes, h, w, 3, 1, 0));
+            TRY(conv(c2, tmp, planes, planes, h, w, out, planes, planes, h, w, 3, 1, 0, nullptr, true));
             const float *shortcut = x;
             if (stride != 1) {
-                TRY(conv(ds, x, cin, cin, hin, win, sc, planes, planes, h, w, 1, stride, 0));
+                TRY(conv(ds, x, cin, cin, hin, win, sc, planes, planes, h, w, 1, stride, 0, nullptr, true));
                 TRY(norm(sc, rows, planes, 2));
                 shortcut = sc;
             }
             return norm(out, rows, planes, 1, shortcut);
         }
-        // batch norm folded: conv+bias+relu, then relu(x + relu(conv+bias))
-        TRY(conv(c1, x, cin, cin, hin, win, tmp, planes, planes, h, w, 3, stride, 1));
+        // batch norm folded: conv+bias+relu, then relu(x + relu(conv+bias)); the block's inner map goes to its second convolution in
+        // split form (its outputs stay fp32: the next block adds them as they are)
+        TRY(conv(c1, x, cin, cin, hin, win, tmp, planes, planes, h, w, 3, stride, 1, nullptr, false, true));
         const float *shortcut = x;
         if (stride != 1) {
             TRY(conv(ds, x, cin, cin, hin, win, sc, planes, planes, h, w, 1, stride, 0));
             shortcut = sc;
         }
-        return conv(c2, tmp, planes, planes, h, w, out, planes, planes, h, w, 3, 1, 1, shortcut);
+        return conv(c2, tmp, planes, planes, h, w, out, planes, planes, h, w, 3, 1, 1, shortcut, true);
     }
 };
 }  // namespace
@@ -379,7 +396,7 @@ extern "C" int mftx_encoder_forward(mftx_encoder *e, const uint8_t *img, int H0,
         TRY(body());
     }
     // head
-    if (e->instance_norm) return E.conv(EC_HEAD, E.ws.a, 128, 128, h3, w3, out0, 256, 256, h3, w3, 1, 1, 0);
+    if (e->instance_norm) return E.conv(EC_HEAD, E.ws.a, 128, 128, h3, w3, out0, 256, 256, h3, w3, 1, 1, 0, nullptr, true);
     TRY(E.conv(EC_HEAD, E.ws.a, 128, 128, h3, w3, out0, 128, 128, h3, w3, 1, 1, 3));   // net = tanh(first 128)
     return E.conv(EC_HEAD2, E.ws.a, 128, 128, h3, w3, out1, 128, 128, h3, w3, 1, 1, 1);  // inp = relu(last 128)
 }

@@ -587,9 +587,9 @@ int launch_lookup_convc1(const float *const lvl[4], const float *coords, int P, 
         if (e != hipSuccess) return fail((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    // booked as algorithmic BYTES of the lookup it replaces (unique taps + coordinates + the 324 features
-    // that are no longer written); the flops of convc1 ride along
-    ProfScope prof(PC_LOOKUP_FUSED, s, (double)a.cells * (4 * 100 * 4 + 8 + 324 * 4));
+    // booked as the algorithmic BYTES the fused kernel really moves: the unique taps (10 x 10 per level), the coordinates and
+    // convc1's 256 output channels -- not the 324-feature tensor it no longer writes; the flops of convc1 ride along
+    ProfScope prof(PC_LOOKUP_FUSED, s, (double)a.cells * (4 * 100 * 4 + 8 + 256 * 4));
     const dim3 grid(a.n_tiles < cus ? a.n_tiles : cus);
     if (out_split) hipLaunchKernelGGL(lookup_convc1_kernel<true>, grid, dim3(512), LF_LDS, s, a);
     else hipLaunchKernelGGL(lookup_convc1_kernel<false>, grid, dim3(512), LF_LDS, s, a);
