@@ -16,7 +16,7 @@ $BENCH > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 # A/B of the round's structural changes, same box, same run (results do not depend on any of them beyond fp32 rounding)
 $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-graphs > $OUT/bench_no_graphs.json 2>/dev/null; echo "bench no-graphs rc=$?"
 $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-fused-lookup > $OUT/bench_no_fused_lookup.json 2>/dev/null; echo "bench no-fused-lookup rc=$?"
-(for o in "" "fuse_gru=0" "gather=0" "fuse_head=2" "fuse_head=0" "tile_volume=0" "tile_conv=0" "fuse_flow=0" "fuse_lookup=0" "fuse_head=0 tile_conv=0 fuse_flow=0" "gather=0 tile_volume=0 fuse_head=0 tile_conv=0 fuse_flow=0 fuse_lookup=0 fuse_gru=0 graph=0"; do
+(for o in "" "fuse_gru=0" "fuse_ou=0" "gather=0" "fuse_head=2" "fuse_head=0" "tile_volume=0" "tile_conv=0" "fuse_flow=0" "fuse_lookup=0" "fuse_head=0 tile_conv=0 fuse_flow=0" "gather=0 tile_volume=0 fuse_head=0 tile_conv=0 fuse_flow=0 fuse_lookup=0 fuse_gru=0 fuse_ou=0 graph=0"; do
    args=""; for kv in $o; do args="$args --engine-opt $kv"; done
    for rep in 1 2; do $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-host-io $args 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('engine options [$o]:', round(d['value'],1), 'frames/s, host', round(d['host_enqueue_ms_per_step'],2), 'ms per frame, conv GEMM', round(d['roofline']['frac'],3), 'of the fp16 MFMA peak')"; done
  done) > $OUT/engine_options_ab.txt
@@ -34,6 +34,7 @@ timeout 300 python tools/bench_tile_conv.py 2>&1 | grep -v amdgpu.ids > $OUT/til
 (timeout 200 tools/micro/mfma_power; timeout 200 tools/micro/mfma_energy) > $OUT/mfma_power_energy.txt 2>&1
 if [ -f build_tune/libmftx_tune.so ]; then
   MFTX_LIB=$PWD/build_tune/libmftx_tune.so timeout 400 python tools/clock_probe.py 2>&1 | grep -v amdgpu.ids | cut -c1-320 > $OUT/clock.txt
+  (echo "# tools/gru_trace.py: s_memtime stamps of workgroup 0 of gru_half_kernel (kilo-cycles), 30th launch of a back-to-back loop"; for a in "7" "7 1" "1"; do MFTX_LIB=$PWD/build_tune/libmftx_tune.so timeout 200 python tools/gru_trace.py $a 2>&1 | grep -v amdgpu.ids; done) > $OUT/gru_trace.txt
   (echo "# tools/lf_trace.py on a -DMFTX_TUNING -DMFTX_LF_TRACE build (tools/build_tuning.sh): s_memtime stamps of workgroup 0, P = 7, 64 x 64"
    MFTX_LIB=$PWD/build_tune/libmftx_tune.so timeout 200 python tools/lf_trace.py 2>&1 | grep -v amdgpu.ids
    for a in 1 2 8 10 32 64 128 512 1024; do echo "== MFTX_LF_ABLATE=$a"; MFTX_LIB=$PWD/build_tune/libmftx_tune.so MFTX_LF_ABLATE=$a timeout 200 python tools/lf_trace.py 2>&1 | tail -4; done) > $OUT/lf_trace.txt
