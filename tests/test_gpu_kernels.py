@@ -1421,3 +1421,51 @@ def test_encoder_graph_replay_bitwise(weights_np):
                 for x, y in zip(a, b):
                     assert (x is None and y is None) or torch.equal(x, y), (prefix, call)
     s.synchronize()
+
+
+def test_round4_entry_points_argument_errors(ops_mod):
+    """Error behaviour of the round-4 C-ABI entry points, called raw: null pointers, misaligned split-form rows, in-place state,
+    bad sizes and unknown options are refused with a negative code and a message; nothing is launched."""
+    from mft_amd import _lib
+    lib = _lib.load()
+    M, h, w = 16 * 16, 16, 16
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(M, 128, generator=g).to(DEV)
+    xs = ops_mod.split_activations(x)
+    wz = ops_mod.pack_tile_conv_weights(ops_mod.pack_conv_weight((torch.randn(256, 256, 1, 5, generator=g) * 0.05).to(DEV)), 256, 256)
+    wq = ops_mod.pack_tile_conv_weights(ops_mod.pack_conv_weight((torch.randn(128, 256, 1, 5, generator=g) * 0.05).to(DEV)), 128, 256)
+    pz, pq = torch.zeros(M, 256, device=DEV), torch.zeros(M, 128, device=DEV)
+    z, hf2, ho = torch.empty(M, 128, device=DEV), torch.empty(M, 128, device=DEV), torch.empty(M, 128, device=DEV)
+    args = [xs.data_ptr(), 128, xs.data_ptr(), 128, wz.data_ptr(), wq.data_ptr(), pz.data_ptr(), pq.data_ptr(), z.data_ptr(), x.data_ptr(),
+            hf2.data_ptr(), ho.data_ptr(), 128, 1, h, w, 0, None]
+    assert lib.mftx_gru_half(*args) == 0
+    for i, bad, code in ((0, None, -1), (4, None, -1), (9, hf2.data_ptr(), -1), (0, xs.data_ptr() + 16, -2), (1, 130, -2), (13, 0, -1), (16, 2, -1)):
+        a = list(args)
+        a[i] = bad
+        assert lib.mftx_gru_half(*a) == code, (i, lib.mftx_last_error_string())
+    # mftx_ou_heads
+    a712 = ops_mod.split_activations(torch.randn(M, 712, generator=g).to(DEV))
+    w1 = ops_mod.pack_conv_weight((torch.randn(256, 712, 3, 3, generator=g) * 0.02).to(DEV))
+    w2 = ops_mod.pack_conv_weight((torch.randn(3, 256, 3, 3, generator=g) * 0.05).to(DEV))
+    wt, wp = ops_mod.pack_ou_heads_weights(w1, w2)
+    b1, b2 = torch.zeros(256, device=DEV), torch.zeros(3, device=DEV)
+    T_, out = torch.empty(M, 27, device=DEV), torch.zeros(M, 4, device=DEV)
+    ou = [a712.data_ptr(), 712, 1, h, w, wt.data_ptr(), b1.data_ptr(), wp.data_ptr(), b2.data_ptr(), T_.data_ptr(), out.data_ptr(), 4, None]
+    assert lib.mftx_ou_heads(*ou) == 0
+    for i, bad, code in ((0, None, -1), (5, None, -1), (11, 2, -1), (1, 704, -2), (0, a712.data_ptr() + 8, -2), (2, 0, -1)):
+        a = list(ou)
+        a[i] = bad
+        assert lib.mftx_ou_heads(*a) == code, (i, lib.mftx_last_error_string())
+    with pytest.raises(ops_mod.MftxError):
+        ops_mod.pack_ou_heads_weights(w1[:, :, :704].contiguous(), w2)
+    assert lib.mftx_pack_ou_heads_weights(w1.data_ptr(), 700, w2.data_ptr(), wt.data_ptr(), wp.data_ptr(), None) == -1
+    # engine options and setters
+    from mft_amd.weights import make_weights
+    eng = ops_mod.RaftEngine({k: torch.from_numpy(v).to(DEV) for k, v in make_weights(3).items()}, DEV)
+    with pytest.raises(ops_mod.MftxError, match="unknown engine option"):
+        eng.set_option("fuse_everything", 1)
+    assert lib.mftx_raft_set_option(eng._h, 99, 1) == -1
+    assert lib.mftx_raft_set_ou_heads(eng._h, wt.data_ptr(), None) == -1
+    assert lib.mftx_raft_set_nonfinite_counter(eng._h, z.data_ptr() + 2) == -2
+    assert lib.mftx_raft_clear_graphs(None) == -4 and lib.mftx_raft_clear_graphs(eng._h) == 0
+    assert lib.mftx_tile_conv_fills_chip(0, 64, 64) == 0 and lib.mftx_tile_conv_fills_chip(7, 64, 64) == 1
