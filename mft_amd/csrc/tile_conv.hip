@@ -549,26 +549,37 @@ __global__ __launch_bounds__(512, 2) void gru_half_kernel(GruHalfArgs p) {
     // (the candidate's first weight fragments: in flight during the gate algebra)
 #pragma unroll
     for (int s = 0; s < PF; ++s) { bq[s][0] = w2[s * 128]; bq[s][1] = w2[s * 128 + 64]; }
-    tc_barrier();           // every wave is done with the h parts of the tile
-    if (wv < 4) park128(wv);
-    tc_barrier();
-    // z = sigmoid(. + context part): row-wise, 8 consecutive channels of a cell per lane -> global (this workgroup reads it back)
+    // z = sigmoid(. + context part), by the z waves themselves, straight from their accumulators (a lane: 4 x 4 consecutive channels of
+    // one cell per row tile -> 16-byte pieces), -> global (this workgroup reads it back for the blend).  The older wave of every SIMD --
+    // these four -- leaves the gates' K loop ~27 k cycles before its partner (the matrix pipe serves it first; tools/gru_trace.py): the
+    // z pass costs nothing here, and its memory traffic falls into a time when the chip's memory system has nothing else to do.  (As a
+    // row-wise pass behind a barrier -- parked sums, all 512 threads -- it was 9 k of the launch's 148 k cycles, every workgroup's at
+    // the same moment.)  Same arithmetic per value as the row-wise form: the same bits.
+    if (wv < 4) {
 #pragma unroll
-    for (int it = 0; it < RT; ++it) {
-        const int item = tid + 512 * it, m = item >> 4, n0 = (item & 15) * 8;
-        const int yy = y0 + m / TW, xx = x0 + m % TW, along = HORIZ ? xx : yy;
-        const float *src = reinterpret_cast<const float *>(slot(m)) + n0;
-        tc_f32x4 u = *reinterpret_cast<const tc_f32x4 *>(src), v = *reinterpret_cast<const tc_f32x4 *>(src + 4);
-        if (yy < 0 || yy >= p.h || xx < 0 || xx >= p.w || along < olo || along >= ohi) continue;
-        const long long cell = img_base + (long long)yy * p.w + xx;
-        u += *reinterpret_cast<const tc_f32x4 *>(p.pre_zr + cell * 256 + n0);
-        v += *reinterpret_cast<const tc_f32x4 *>(p.pre_zr + cell * 256 + n0 + 4);
+        for (int i = 0; i < RT; ++i) {
+            const int m = 32 * i + (lane & 31);
+            const int yy = y0 + m / TW, xx = x0 + m % TW, along = HORIZ ? xx : yy;
+            const bool own = yy >= 0 && yy < p.h && xx >= 0 && xx < p.w && along >= olo && along < ohi;
+            const int yc = yy < 0 ? 0 : (yy >= p.h ? p.h - 1 : yy), xc = xx < 0 ? 0 : (xx >= p.w ? p.w - 1 : xx);
+            const long long cell = img_base + (long long)yc * p.w + xc;
+            const int n0 = 32 * wv + 4 * (lane >> 5);
+            tc_f32x4 a[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { u[e] = tc_sigmoid(u[e]); v[e] = tc_sigmoid(v[e]); }
-        *reinterpret_cast<tc_f32x4 *>(p.z + cell * 128 + n0) = u;
-        *reinterpret_cast<tc_f32x4 *>(p.z + cell * 128 + n0 + 4) = v;
+            for (int b = 0; b < 4; ++b) a[b] = *reinterpret_cast<const tc_f32x4 *>(p.pre_zr + cell * 256 + n0 + 8 * b);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                tc_f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * b + e] + accx[i][4 * b + e] * inv2048;
+                v += a[b];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = tc_sigmoid(v[e]);
+                if (own) *reinterpret_cast<tc_f32x4 *>(p.z + cell * 128 + n0 + 8 * b) = v;
+            }
+        }
     }
-    tc_barrier();           // the z sums have been read
+    tc_barrier();           // every wave is done with the h parts of the tile
     if (wv >= 4) park128(wv - 4);
     tc_barrier();
     // r * h, in place: the sums of 8 channels become their split form (zero outside the image: the candidate's zero padding)
