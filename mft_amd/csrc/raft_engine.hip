@@ -663,7 +663,7 @@ static int refine_impl(mftx_raft *r, int P, int h, int w, int iters, const float
         // The upsampling mask is consumed only after the last iteration in test
         // mode (core/raft.py:190-196,234-239), so it is computed once.
         // (the hidden 256 channels go to the 1 x 1 layer in split form: a GEMM that splits its A operand in registers runs at half the
-        // matrix utilisation of one that finds it split -- profiles/r4j_pmc_mfma_util.csv: 0.18 against 0.35)
+        // matrix utilisation of one that finds it split -- profiles/r4k_pmc_mfma_util.csv: 0.18 against 0.35)
         if (tile_w(W_MASK0)) {
             TileConvLaunch t = tile_layer(ws.hx, 384, nullptr, 0, tile_w(W_MASK0), W[B_MASK0], 256, 3, 3, 1);
             t.out = ws.fh; t.ldo = 256; t.out_split = SP ? 1 : 0;
