@@ -61,6 +61,9 @@ CATS = ["corr_volume_gemm", "corr_pool", "corr_lookup", "conv_gemm", "convf1", "
         "encoder_conv_gemm", "gru_half_fused"]
 FLOP_CATS = {0, 3, 4, 8, 11, 12, 13}
 GEMM_PARTS = ("conv_gemm", "gru_half_fused", "encoder_conv_gemm")    # every conv GEMM of the step: what `roofline` prices, as in earlier rounds
+# kernel symbols booked under GEMM_PARTS (profile.h: PC_CONV_GEMM / PC_GRU_HALF / PC_ENC_GEMM): the counter file is averaged over the
+# same set that `roofline.achieved` and `flops_per_launch` are
+GEMM_KERNEL_NAMES = ("conv_gemm", "tile_conv_kernel", "gru_half_kernel", "ou_head_kernel")
 VALU_CATS = {4, 8}
 FULL_PAIRS = 7                  # flow pairs per frame once every delta is live
 FIRST_FULL_FRAME = 33           # first frame index with FULL_PAIRS pairs (forward tracking from frame 0)
@@ -196,10 +199,10 @@ def profiled_traffic(profiles_dir=None):
         return None, f"{files[-1].name} refused: measured on build {m.group(1) if m else 'unknown'}, this run loads {mine}"
     tot = n = 0.0
     for line in text.splitlines():
-        if line.startswith("#") or not any(k in line for k in ("conv_gemm", "tile_conv_kernel", "gru_half_kernel")):
+        if line.startswith("#") or not any(k in line for k in GEMM_KERNEL_NAMES):
             continue
         name, launches, _fetch, fetch_x2, write = line.rsplit(",", 4)     # the kernel name contains commas
-        if "volume" in name or re.search(r"<\d+, \d+, \d+, \d+, 4[,>]", name):
+        if "volume" in name or "pack_" in name or re.search(r"<\d+, \d+, \d+, \d+, 4[,>]", name):
             continue                                 # the correlation volume GEMM is its own category
         tot += float(launches) * (float(fetch_x2) + float(write)) * 1e6
         n += float(launches)
@@ -551,7 +554,21 @@ def main():
                                   "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic,
                                   "traffic_source": source,
                                   "avg_launch_us": dom["avg_us"], "flops_per_launch": dom["work_per_launch"]}
+            # the per-category times are bracketed with every kernel ALONE on one stream (profile_pass); the timed region overlaps
+            # the encoders of frame t+1 (side stream) with frame t, so their sum exceeds ms_per_step by the overlap
+            serial = sum(v["total_ms_per_step"] for k, v in kernels.items() if k != "conv_gemm_all")
+            result["kernels_serial_ms_per_step"] = serial
+            result["overlap_ms_per_step"] = serial - result["ms_per_step"]
+            lk = kernels.get("lookup_convc1_fused") or kernels.get("corr_lookup")
+            if lk:
+                result["roofline"]["north_star_lookup"] = {
+                    "target_frac_of_hbm": 0.8, "achieved_frac": lk["frac"], "achieved_GBps": lk["achieved"],
+                    "kernel": "lookup_convc1_fused" if "lookup_convc1_fused" in kernels else "corr_lookup",
+                    "standalone_corr_lookup_frac": kernels.get("corr_lookup", {}).get("frac"),
+                    "note": "algorithmic lookup bytes (SURVEY 8d) / kernel time vs 8 TB/s; at 512x512 the pyramid is "
+                            "Infinity-Cache resident; DESIGN.md section 4 'lookup' has the 1080p (HBM-resident) figure"}
             if split:
+                result["roofline"]["frac_algorithmic"] = dom["algorithmic_tflops"] / F16_MFMA_PEAK_TFLOPS
                 result["roofline"].update(
                     note="achieved = 3 x algorithmic flops (the fp16 MFMA products executed) against the dense fp16 MFMA peak",
                     algorithmic_tflops=dom["algorithmic_tflops"],
@@ -586,7 +603,7 @@ def main():
             enc = getattr(tracker.flower, "_enc_stream", None)
             ring = FrameRing((host_frames[i] for i in range(base, base + n_io_frames)), keep=40,
                              streams=[enc] if enc is not None else None).prepare(host_frames[0].shape)
-            drain = ResultDrain(depth=4).prepare(tracker.memory[tracker.current_frame_i]['result'])
+            drain = ResultDrain(depth=4, nonfinite_from=tracker).prepare(tracker.memory[tracker.current_frame_i]['result'])
             got = 0
             # (the loop issues no CPU tensor math; torch's intra-op pool -- 128 threads on this host -- only adds wake-up and
             # spin noise to the host-side waits: tools/io_paths3.py, 101 vs 124 frames/s)

@@ -180,29 +180,37 @@ class MFT():
             logger.debug("chain + selection (%d candidates, one kernel): %.2fms", len(lefts), t0.elapsed_time(t1))
         # invalid flows are already marked occluded inside the selection kernel
         result = FlowOUTrackingResult(flow, occl, sigma, validate=False)
-        self.current_frame_i = frame_i
-        self.last_pairs = [(left_id, frame_i) for _, left_id, _ in plan]
-        self.last_chosen = chosen
         if self.C.keep_result_on_device:
             meta.result = result.clone()       # a copy: the consumer may move it in place (meta.result.cpu())
         else:
             meta.result = result.clone().cpu()
+        # the guard runs BEFORE any tracker state changes: a FloatingPointError leaves the tracker exactly at frame t-1
+        # (current_frame_i, memory, last_pairs untouched), so the caller may switch raft_params.arith and call track() again
         self._check_nonfinite(synced=not self.C.keep_result_on_device)
+        self.current_frame_i = frame_i
+        self.last_pairs = [(left_id, frame_i) for _, left_id, _ in plan]
+        self.last_chosen = chosen
         self.memory[frame_i] = {'img': input_img, 'result': result}
         self.cleanup_memory()
         return meta
 
     def _check_nonfinite(self, synced):
-        """The flow plugin counts non-finite output pixels on the device (mftx_raft_set_nonfinite_counter).  The count is read --
-        and a FloatingPointError raised -- where the host has synchronised anyway (the result just went to the CPU), otherwise
-        every C.nonfinite_check_every frames (default 32; 0: never -- ResultDrain.collect / check_nonfinite() remain): a NaN
-        must not travel through tracker.memory unnoticed (the reference has no such guard: MFT/MFT.py:96-143)."""
+        """The flow plugin counts, on the device, output pixels the reference could not have produced from finite activations: a
+        NaN in any plane or an infinite flow / occlusion (mftx_raft_set_nonfinite_counter; sigma = +inf, which MFT/raft.py:62
+        produces for log-variances > ~88.7 and the reference tolerates, is NOT counted).  The count is read -- and a
+        FloatingPointError raised, the tracker still at frame t-1 -- where the host has synchronised anyway (the result just went
+        to the CPU), otherwise every C.nonfinite_check_every frames (default 32).  The reference has no such guard
+        (MFT/MFT.py:96-143), so it can be switched off entirely: C.nonfinite_check_every = 0 or C.raise_on_nonfinite = False
+        disable it on BOTH paths (check_nonfinite() / ResultDrain(nonfinite_from=...) remain for explicit use)."""
         if not hasattr(self.flower, "raise_if_nonfinite"):
             return
         every = self.C.nonfinite_check_every
-        every = int(every) if isinstance(every, (int, float)) else 32          # (an unset Config attribute is a falsy Config)
+        every = int(every) if isinstance(every, (int, float)) and not isinstance(every, bool) else 32   # (unset attribute: a falsy Config)
+        off = every <= 0 or (isinstance(self.C.raise_on_nonfinite, bool) and not self.C.raise_on_nonfinite)
+        if off:
+            return
         self._frames_unchecked = getattr(self, "_frames_unchecked", 0) + 1
-        if synced or (every > 0 and self._frames_unchecked >= every):
+        if synced or self._frames_unchecked >= every:
             self._frames_unchecked = 0
             self.flower.raise_if_nonfinite()
 

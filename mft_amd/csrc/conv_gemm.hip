@@ -1489,19 +1489,27 @@ static int launch_cfg(const ConvArgs &a, int batch, hipStream_t s, ProfCat cat, 
 // everything here, for the tuning builds of tools/build_ablations.sh.)
 template <int EPI>
 int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, ProfCat cat) {
+    if constexpr (EPI == EPI_GRU_Q) {
+        // the candidate epilogue keeps z, h and r * h fragments live beside the accumulators: on three shapes that does not fit
+        // 256 VGPRs (17 / 6 / 10 spilled registers).  They are reachable only with the fused GRU pass switched off (or a forced
+        // tile) and every tile shape sums K in the same order (bit-identical results), so they run on their no-spill neighbours.
+        if (a.arith == AR_SPLIT && a.a_pre && tile == 11) tile = 6;
+        if (a.arith != AR_SPLIT && (tile == 1 || tile == 4)) tile = 2;
+    }
     if (a.arith == AR_SPLIT && a.a_pre) {              // A already in split form: the production tiles only
         switch (tile) {
             case 0: return launch_cfg<128, 128, 2, 2, EPI, 32, AR_PRESPLIT, 2>(a, batch, s, cat);
             case 6: return launch_cfg<128, 128, 4, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);       // (ring of three: 125.1 -> 126.2 frames/s against four)
             case 10: return launch_cfg<128, 256, 2, 4, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
             case 14: return launch_cfg<128, 192, 4, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);   // eight waves of 32 x 96: N = 192 without a half-empty column tile
-            case 11: return launch_cfg<128, 128, 2, 2, EPI, 32, AR_PRESPLIT, 4, 1>(a, batch, s, cat);   // warp-specialised: four 64 x 64 consumer waves + four producer waves, ring of four chunks (128 KiB)
+            case 11: if constexpr (EPI != EPI_GRU_Q) return launch_cfg<128, 128, 2, 2, EPI, 32, AR_PRESPLIT, 4, 1>(a, batch, s, cat); else break;   // warp-specialised: four 64 x 64 consumer waves + four producer waves, ring of four chunks (128 KiB)
 #ifdef MFTX_EXPERIMENTAL_TILES       // measurement-only shapes: bit-identical, slower
             case 15: return launch_cfg<224, 128, 2, 4, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);   // four waves of 128 x 32 over four of 96 x 32: 7 x 4096 cells = 128 x 224
             case 13: return launch_cfg<112, 256, 1, 4, EPI, 16, AR_PRESPLIT, 3>(a, batch, s, cat);  // four waves of 112 x 64 on 16-row MFMAs: 7 x 4096 cells = 256 tiles
 #endif
             default: return launch_cfg<64, 64, 2, 2, EPI, 32, AR_PRESPLIT, 3>(a, batch, s, cat);
         }
+        return fail(MFTX_E_STATE, "conv2d: tile %d has no instance for this epilogue", tile);
     }
     if (a.arith == AR_SPLIT) {
         switch (tile) {
@@ -1517,12 +1525,13 @@ int launch_tile(int tile, const ConvArgs &a, int batch, hipStream_t s, ProfCat c
     }
     switch (tile) {
         case 0: return launch_cfg<128, 128, 2, 2, EPI>(a, batch, s, cat);
-        case 1: return launch_cfg<128, 64, 2, 2, EPI>(a, batch, s, cat);
+        case 1: if constexpr (EPI != EPI_GRU_Q) return launch_cfg<128, 64, 2, 2, EPI>(a, batch, s, cat); else break;
         case 2: return launch_cfg<64, 64, 2, 2, EPI>(a, batch, s, cat);
-        case 4: return launch_cfg<64, 128, 2, 2, EPI>(a, batch, s, cat);       // a wave owns 32 x 64: the A tile is gathered once for N = 128
+        case 4: if constexpr (EPI != EPI_GRU_Q) return launch_cfg<64, 128, 2, 2, EPI>(a, batch, s, cat); else break;       // a wave owns 32 x 64: the A tile is gathered once for N = 128
         case 5: return launch_cfg<32, 32, 2, 2, EPI, 16>(a, batch, s, cat);    // 4 waves of 16x16: four times the workgroups of 64x64
         default: return launch_cfg<128, 32, 4, 1, EPI>(a, batch, s, cat);
     }
+    return fail(MFTX_E_STATE, "conv2d: tile %d has no instance for this epilogue", tile);
 }
 
 #if defined(MFTX_CONV_PART)

@@ -598,10 +598,14 @@ static int refine_impl(mftx_raft *r, int P, int h, int w, int iters, const float
         }
         TRY(launch_conv(gemm(conv_desc(ws.corflo, 256, 256, nullptr, 0, 0, G[W_CONV], W[B_CONV], ws.hx + 256, 384, P, h, w, 126, 3, 3, 1), true, true), s));
         // SepConvGRU (core/update.py:108-123): horizontal 1x5 then vertical 5x1
+        // (decided ONCE for both passes: they hand h over through the ping-pong pair hx/hf <-> hb/hfb, so one fused and one
+        // unfused pass would read a buffer the other never wrote -- a partial set of tile weights runs both passes unfused)
+        const bool gru_fused = tile_w(W_ZR1_DYN) && tile_w(W_Q1_DYN) && tile_w(W_ZR2_DYN) && tile_w(W_Q2_DYN) &&
+                               r->opt[MFTX_RAFT_OPT_FUSE_GRU] != 0;
         for (int pass = 0; pass < 2; ++pass) {
             const int kh = pass ? 5 : 1, kw = pass ? 1 : 5;
             const int szr = pass ? W_ZR2_DYN : W_ZR1_DYN, sq = pass ? W_Q2_DYN : W_Q1_DYN;
-            if (tile_w(szr) && tile_w(sq) && r->opt[MFTX_RAFT_OPT_FUSE_GRU] != 0) {
+            if (gru_fused) {
                 // the whole pass as ONE kernel (tile_conv.hip: gru_half_kernel): the tile is loaded once, r * h stays in LDS; h goes
                 // hx -> hb in the horizontal pass and back in the vertical one (a tile's halo cells are its neighbours' outputs)
                 GruHalfLaunch g{};

@@ -98,7 +98,10 @@ __global__ __launch_bounds__(64 * UP_WAVES) void convex_upsample_kernel(UpArgs p
     // must not enter a tracker's memory unnoticed: counted here, where every output of a refinement passes -- one ballot per
     // wave, an atomic only when something IS wrong; the host reads the counter when it synchronises anyway.
     if (p.nonfinite != nullptr) {
-        const bool bad = !(isfinite(fxv) && isfinite(fyv) && isfinite(oc) && isfinite(sg));
+        // (sigma = sqrt(exp(u)) = +inf for u > ~88.7 is a value the reference produces and tolerates -- MFT/raft.py:62 applies no
+        // clamp -- and the selection handles it; what is counted is what the reference could not have produced from finite
+        // activations: a NaN anywhere, or an infinite flow / occlusion)
+        const bool bad = !(isfinite(fxv) && isfinite(fyv) && isfinite(oc)) || sg != sg;
         const unsigned long long b = __ballot(bad);
         if (b != 0ull && bad && (unsigned)lane == (unsigned)__builtin_ctzll(b)) atomicAdd(p.nonfinite, (unsigned)__builtin_popcountll(b));
     }

@@ -764,7 +764,8 @@ class RaftEngine:
             raise MftxError(f"unknown arithmetic {arith!r}")
         # device-side count of non-finite output pixels, incremented by the last kernel of every refinement (no host sync;
         # read by nonfinite_count() when the caller synchronises anyway)
-        self._nonfinite = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # (16 bytes, the counter in word 0: the size mftx_copy_bytes moves, see nonfinite_snapshot)
+        self._nonfinite = torch.zeros(4, dtype=torch.int32, device=self.device)
         check(lib.mftx_raft_set_nonfinite_counter(self._h, self._nonfinite.data_ptr()), "mftx_raft_set_nonfinite_counter")
         options = dict(options or {})
         self._gather = bool(options.pop("gather", 1))     # (Python-side: per-pair map lists instead of stacked batch tensors, A/B)
@@ -818,10 +819,15 @@ class RaftEngine:
 
     def nonfinite_count(self, reset=False):
         """Output pixels with a non-finite flow / occlusion / sigma since the last reset (one 4-byte read: synchronises)."""
-        n = int(self._nonfinite.item())
+        n = int(self._nonfinite[0].item())
         if reset and n:
             self._nonfinite.zero_()
         return n
+
+    def nonfinite_snapshot(self, host_words):
+        """Enqueue, on the current stream, a copy of the counter into ``host_words`` (4 int32 of PINNED host memory, the count in
+        word 0) -- no host wait: whoever later waits for an event recorded behind this call may read the word."""
+        copy_bytes(self._nonfinite, host_words)
 
     def set_option(self, name, value):
         if name not in self.OPTIONS:

@@ -129,13 +129,23 @@ class RAFTWrapper:
         """Non-finite output pixels counted on the device since the last reset, over all engines of this plugin."""
         return sum(e.nonfinite_count(reset=reset) for e in dict.fromkeys([self.engine] + list(self._engines)))
 
+    def nonfinite_snapshot(self, host_words):
+        """Asynchronous read of the counters (no host wait): enqueues, on the current stream, copies of every engine's counter into
+        ``host_words`` -- pinned int32 [n, 4] with n >= the number of engines; the caller sums column 0 after waiting for an
+        event recorded behind this call (mft_amd.video.ResultDrain does)."""
+        for i, e in enumerate(dict.fromkeys([self.engine] + list(self._engines))):
+            e.nonfinite_snapshot(host_words[i])
+
+    def nonfinite_error(self, bad):
+        return FloatingPointError(
+            f"flow network: {bad} output pixels with a non-finite value (a NaN, or an infinite flow / occlusion)" + (
+                " -- an activation left the fp16 range of the split arithmetic (|x| >= 65504); "
+                "set raft_params.arith = 'fp32'" if self._arith == ops.ARITH_SPLIT else ""))
+
     def raise_if_nonfinite(self):
         bad = self.nonfinite_count(reset=True)
         if bad:
-            raise FloatingPointError(
-                f"flow network: {bad} output pixels with a non-finite flow / occlusion / sigma" + (
-                    " -- an activation left the fp16 range of the split arithmetic (|x| >= 65504); "
-                    "set raft_params.arith = 'fp32'" if self._arith == ops.ARITH_SPLIT else ""))
+            raise self.nonfinite_error(bad)
 
     @property
     def arith(self):

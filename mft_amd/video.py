@@ -181,12 +181,19 @@ class ResultDrain:
     once): a collected result stays valid until ``depth`` more results have been submitted (``copy=True`` returns
     private copies instead)."""
 
-    def __init__(self, device="cuda", depth=4, check=None):
-        """check: optional callable run by every ``collect`` after its wait (e.g. ``tracker.check_nonfinite``: the host has
-        synchronised with the GPU there anyway, so reading the device-side non-finite counter costs nothing extra)."""
+    def __init__(self, device="cuda", depth=4, check=None, nonfinite_from=None):
+        """nonfinite_from: a tracker (or flow plugin) whose device-side non-finite counters ride along with every result: ``submit``
+        enqueues a 16-byte copy of each counter into a pinned word behind the result's planes, ``collect`` reads the word after
+        the event it waits for anyway and raises FloatingPointError -- no extra synchronisation, the pipeline stays asynchronous.
+        check: optional callable run by every ``collect`` after its wait.  NOTE: ``tracker.check_nonfinite`` here reads the
+        counter with ``.item()``, which waits for EVERYTHING queued on the stream (frames t+1 .. t+depth included), i.e. it
+        drains the pipeline on every collect; prefer ``nonfinite_from``."""
         self.device = torch.device(device)
         self.depth = depth
         self.check = check
+        src = getattr(nonfinite_from, "flower", nonfinite_from)
+        self._nf_src = src if hasattr(src, "nonfinite_snapshot") else None
+        self._nf_words = []            # per slot: pinned int32 [8, 4]
         self._sets, self._queue, self._n = [], [], 0
 
     def prepare(self, result):
@@ -214,14 +221,24 @@ class ResultDrain:
                 ops.copy_bytes(t, h)
             else:       # pageable host results (keep_result_on_device = False) or a plane view off the 16-byte grid: torch's copy
                 h.copy_(t, non_blocking=True)
+        words = None
+        if self._nf_src is not None:
+            while len(self._nf_words) <= slot:
+                self._nf_words.append(torch.zeros(8, 4, dtype=torch.int32).pin_memory())
+            words = self._nf_words[slot]
+            self._nf_src.nonfinite_snapshot(words)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
-        self._queue.append((ev, host))
+        self._queue.append((ev, host, words))
         self._n += 1
 
     def collect(self, copy=False):
-        ev, host = self._queue.pop(0)
+        ev, host, words = self._queue.pop(0)
         ev.synchronize()
+        if words is not None:
+            bad = int(words[:, 0].sum())
+            if bad:       # (the counters stay set: every later collect raises too, until nonfinite_count(reset=True))
+                raise self._nf_src.nonfinite_error(bad)
         if self.check is not None:
             self.check()
         return tuple(torch.from_numpy(h.numpy().copy()) for h in host) if copy else tuple(host)      # (numpy: a plain memcpy, see FrameRing)

@@ -18,10 +18,11 @@ def test_profiled_traffic_is_tied_to_the_build(tmp_path):
     body = ("# rocprofv3 ...\nkernel,launches,fetch_MB,fetch_x2_MB,write_MB\n"
             '"mftx::conv_gemm_kernel<128, 192, 4, 2, 1, 32, 2, 3, 0>",24,20.0,40.0,22.0\n'
             '"mftx::gru_half_kernel<2, 64, 1, 5>",24,30.0,60.0,18.0\n'
+            '"mftx::ou_head_kernel<128, 5>",24,40.0,80.0,10.0\n'
             '"mftx::volume_tile_kernel",2,200.0,200.0,600.0\n')
     (tmp_path / "r9z_pmc_hbm_traffic.csv").write_text(f"# build: {mine}  (sha256 ...)\n" + body)
     traffic, source = bench.profiled_traffic(tmp_path)
-    assert abs(traffic - 70e6) < 1 and source.startswith("r9z_pmc_hbm_traffic.csv") and mine in source
+    assert abs(traffic - (62e6 + 78e6 + 90e6) / 3) < 1 and source.startswith("r9z_pmc_hbm_traffic.csv") and mine in source
     (tmp_path / "r9z_pmc_hbm_traffic.csv").write_text("# build: 0123456789abcdef\n" + body)
     traffic, source = bench.profiled_traffic(tmp_path)
     assert traffic is None and "refused" in source

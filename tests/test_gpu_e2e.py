@@ -543,9 +543,22 @@ def test_nonfinite_results_are_counted_and_raise(weights_np):
     f = torch.full((N, 256), 7.0e4, device=DEV)                            # (beyond fp16: the high halves are inf)
     z = torch.zeros(N, 128, device=DEV)
     fl._frames[1] = FrameFeatures(f, z, z, 16, 24, (0, 0, 0, 0), (128, 192))
+    keys = sorted(tr.memory.keys())
     with pytest.raises(FloatingPointError, match="non-finite"):
         tr.track(vid[2])
     assert fl.nonfinite_count() == 0                                       # read and reset by the raise
+    # the raise leaves the tracker exactly at frame t-1: no half-advanced state
+    assert tr.current_frame_i == 1 and sorted(tr.memory.keys()) == keys and tr.last_pairs == [(0, 1)]
+    # the reference has no guard: nonfinite_check_every = 0 (or raise_on_nonfinite = False) disables it on the synced path too
+    for knob, val in (("nonfinite_check_every", 0), ("raise_on_nonfinite", False)):
+        tr0 = make_tracker(fl, deltas=(np.inf, 1))
+        setattr(tr0.C, knob, val)
+        tr0.init(vid[0])
+        tr0.track(vid[1])
+        fl._frames[1] = FrameFeatures(f, z, z, 16, 24, (0, 0, 0, 0), (128, 192))
+        out = tr0.track(vid[2]).result                                     # NaN flows through, as in the reference
+        assert not torch.isfinite(out.flow).all() and tr0.current_frame_i == 2
+        assert fl.nonfinite_count(reset=True) > 0
     # results kept on the device: no sync per frame, the check comes every C.nonfinite_check_every frames / on demand
     tr2 = make_tracker(fl, deltas=(np.inf, 1))
     tr2.C.keep_result_on_device = True
@@ -560,6 +573,43 @@ def test_nonfinite_results_are_counted_and_raise(weights_np):
     fl._frames[2] = FrameFeatures(f, z, z, 16, 24, (0, 0, 0, 0), (128, 192))
     with pytest.raises(FloatingPointError):
         tr2.track(vid[3])                                                  # third unchecked frame: the periodic check fires
+
+
+def test_infinite_sigma_is_not_an_error_and_drain_checks_without_sync(weights_np):
+    """sigma = sqrt(exp(u)) = +inf for u > ~88.7 is what the reference computes and tolerates (MFT/raft.py:62, no clamp): the
+    counter ignores it.  A NaN is caught by ResultDrain(nonfinite_from=...) through the pinned snapshot that rides behind the
+    result -- collect() does not touch the device."""
+    from mft_amd.config import Config
+    from mft_amd.raft import FrameFeatures, RAFTWrapper
+    from mft_amd.video import ResultDrain
+    h, w = 16, 24
+    M = h * w
+    c = Config()
+    c.flow_iters = 2
+    vid = SyntheticVideo(128, 192, n_frames=4, seed=1)
+    big = dict(weights_np)
+    big["occlusion_block.uncertainty_head.conv2.bias"] = np.full_like(big["occlusion_block.uncertainty_head.conv2.bias"], 250.0)
+    fl_inf = RAFTWrapper(c, state_dict=big)
+    tri = make_tracker(fl_inf, deltas=(np.inf, 1))
+    tri.init(vid[0])
+    out = tri.track(vid[1]).result                                        # synced path, default guard ON: must not raise
+    assert torch.isinf(out.sigma).all() and torch.isfinite(out.flow).all() and fl_inf.nonfinite_count() == 0
+    del tri, fl_inf
+    fl = RAFTWrapper(c, state_dict=weights_np)
+    tr = make_tracker(fl, deltas=(np.inf, 1))
+    tr.C.keep_result_on_device = True
+    tr.C.nonfinite_check_every = 0
+    tr.init(vid[0])
+    drain = ResultDrain(nonfinite_from=tr)
+    drain.submit(tr.track(vid[1]).result)
+    assert len(drain.collect()) == 3                                      # finite: nothing raised
+    f = torch.full((M, 256), 7.0e4, device=DEV)
+    z = torch.zeros(M, 128, device=DEV)
+    fl._frames[1] = FrameFeatures(f, z, z, h, w, (0, 0, 0, 0), (128, 192))
+    drain.submit(tr.track(vid[2]).result)
+    with pytest.raises(FloatingPointError, match="non-finite"):
+        drain.collect()
+    assert fl.nonfinite_count(reset=True) > 0
 
 
 def test_async_encode_is_bitwise_identical(weights_np):
