@@ -14,11 +14,25 @@ Reference behaviour restated here (nothing is imported from it):
     confusion counts and precision the reference adds.
   * ``MFT/evaluation/tapvid_eval_stuff.py:275-386`` -- 'strided' / 'first' query sampling.
 
-The dataset readers (pickled DAVIS / Kinetics / RGB-stacking shards) are not
-rebuilt: no dataset is reachable from the build environment.  ``synthetic_sequence``
-makes TAP-Vid-shaped ground truth from the seeded synthetic video instead.
+  * ``MFT/evaluation/tapvid_eval_stuff.py:612-672`` -- ``create_tapvid_dataset``: the pickled TAP-Vid
+    shards (a dict of sequences for DAVIS / RGB-stacking, a list of JPEG-encoded sequences for the
+    Kinetics shards, ``:528-549``), the chain of rescalings a ``scaling`` string such as
+    ``'256x256_512x512'`` asks for (``MFT/utils/misc.py:65-92``: resize to 256 x 256, THEN to 512 x 512 --
+    the tracker runs at 512 x 512 on twice-resampled frames, scores are taken on the 256 x 256 raster) and
+    ``resize_video`` (``:61-80``).
+  * ``MFT/runners/run_MFT_tapvid.py:100-237`` / ``eval_MFT_tapvid.py:69-133`` -- the per-dataset runner
+    (``run_dataset``: one flow cache per sequence, ``<seq>-<mode>.pklz`` tracklet pickles, ``cont``
+    skipping, flowou export of the frame-0 template) and its evaluation (``evaluate_dataset``).
+
+No dataset is reachable from the build environment: ``synthetic_sequence`` / ``synthetic_pickle`` make
+TAP-Vid-shaped ground truth (and a TAP-Vid-shaped pickle) from the seeded synthetic video instead.
 """
 from __future__ import annotations
+
+import io as _pyio
+import pickle
+import shutil
+from pathlib import Path
 
 import numpy as np
 import torch
@@ -26,6 +40,116 @@ import torch
 from .point_tracking import convert_to_point_tracking
 
 THRESHOLDS = (1, 2, 4, 8, 16)
+TRAIN_SIZE = (24, 256, 256, 3)          # tapnet's training raster: the default target of create_tapvid_dataset
+
+
+# ---------------------------------------------------------------------------
+# dataset reader
+# ---------------------------------------------------------------------------
+def parse_scale_WH(scale_WH, frames_shape):
+    """'fullres' | 'WxH' | 'Wx' | 'xH', several joined by '_' = a SEQUENCE of rescalings -> list of shape dicts (the keys
+    of ``frames_shape`` with 'W' / 'H' replaced; a missing side keeps the ORIGINAL aspect ratio, rounded).
+    ``MFT/utils/misc.py:65-92``."""
+    if scale_WH == "fullres":
+        return [frames_shape]
+    out = []
+    for part in scale_WH.split("_"):
+        if part == "fullres":
+            out.append(frames_shape)
+            continue
+        W_str, H_str = part.split("x")
+        W = int(W_str) if W_str != "" else None
+        H = int(H_str) if H_str != "" else None
+        assert W is not None or H is not None, "at least one dimmension has to be set"
+        shape = dict(frames_shape.items())
+        shape["W"] = W if W is not None else int(round(frames_shape["W"] * (H / frames_shape["H"])))
+        shape["H"] = H if H is not None else int(round(frames_shape["H"] * (W / frames_shape["W"])))
+        out.append(shape)
+    return out
+
+
+def resize_frame(frame, output_size):
+    """One uint8 frame [H, W, C] -> [output_size[0], output_size[1], C] with PIL's Lanczos filter: what
+    ``mediapy.resize_video`` (the reference's resizer, ``tapvid_eval_stuff.py:80``) does for uint8 RGB frames."""
+    from PIL import Image
+    frame = np.asarray(frame)
+    assert frame.dtype == np.uint8 and frame.ndim == 3
+    H, W = int(output_size[0]), int(output_size[1])
+    return np.asarray(Image.fromarray(frame).resize((W, H), resample=Image.Resampling.LANCZOS), dtype=np.uint8)
+
+
+def resize_video(video, output_size, fake_video=False, lazy_video=False):
+    """(N, H, W, C) uint8 -> (N, output_size[0], output_size[1], C).  ``fake_video``: zeros of the right shape (the evaluation
+    only needs the shape, ``eval_MFT_tapvid.py:82``).  ``lazy_video``: a list of zero-argument callables, one per frame
+    (the reference's version of this branch returns callables that return None, ``tapvid_eval_stuff.py:64-69``)."""
+    video = np.asarray(video)
+    N, _, _, C = video.shape
+    if lazy_video:
+        return [(lambda i=i: resize_frame(video[i], output_size)) for i in range(N)]
+    if fake_video:
+        return np.zeros((N, int(output_size[0]), int(output_size[1]), C), dtype=video.dtype)
+    return np.stack([resize_frame(video[i], output_size) for i in range(N)]) if N else \
+        np.zeros((0, int(output_size[0]), int(output_size[1]), C), dtype=video.dtype)
+
+
+def load_kinetics_video(data):
+    """A Kinetics shard entry: ``data['video']`` is a list of JPEG byte strings -> (N, H, W, 3) uint8 RGB, in place
+    (``tapvid_eval_stuff.py:528-549``)."""
+    from PIL import Image
+    frames = []
+    for byte_string in data["video"]:
+        img = np.asarray(Image.open(_pyio.BytesIO(byte_string)))
+        assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+        frames.append(img)
+    data["video"] = np.array(frames)
+    return data
+
+
+def create_tapvid_dataset(pickle_path, query_modes, train_size=None, fake_video=False, lazy_video=False):
+    """Generator over the sequences of one TAP-Vid pickle (``tapvid_eval_stuff.py:612-672``):
+    ``{'data': {mode: sample_queries_<mode>(...)}, 'video_name': str, 'N_sequences': int}``.
+
+    pickle: ``{name: {'video' (N, H, W, 3) uint8 RGB, 'points' (n, N, 2) xy in [0, 1], 'occluded' (n, N) bool}}`` or a LIST
+    of such dicts with JPEG-encoded frames (a Kinetics shard; sequences are then named ``kin-<shard>-<i:04d>``).
+    train_size: None -> 256 x 256 (tapnet's raster); False -> the video's own size; a ``parse_scale_WH`` string ->
+    the frames go through EVERY rescaling of the string in turn and the points are scaled to the LAST one; a tuple
+    (_, H, W, _) -> that size.  Like the reference a size, once set, is kept for the remaining sequences of the pickle
+    (``train_size`` is rebound inside the loop) and the points of the loaded pickle are scaled in place."""
+    if lazy_video:
+        # the reference's lazy branch yields a list and then trips over `frames.shape` (tapvid_eval_stuff.py:650)
+        raise ValueError("create_tapvid_dataset: lazy_video is not usable (nor is it in the reference)")
+    if train_size is None:
+        train_size = TRAIN_SIZE
+    size_str = train_size if isinstance(train_size, str) else None
+    with open(pickle_path, "rb") as f:
+        dataset = pickle.load(f)
+    if isinstance(dataset, list):
+        shard = Path(pickle_path).stem
+        dataset = {f"kin-{shard}-{i:04d}": load_kinetics_video(d) for i, d in enumerate(dataset)}
+    n_sequences = len(dataset)
+    for name in dataset:
+        frames = np.asarray(dataset[name]["video"])
+        N, H, W, C = frames.shape
+        shape = {"N_frames": N, "H": H, "W": W, "C": C}
+        if size_str is not None:
+            for scaled in parse_scale_WH(size_str, shape):
+                train_size = (1, scaled["H"], scaled["W"], C)
+                frames = resize_video(frames, train_size[1:3], fake_video=fake_video)
+        elif train_size is False:
+            train_size = (1, H, W, C)
+            frames = resize_video(frames, train_size[1:3], fake_video=fake_video)
+        else:
+            frames = resize_video(frames, train_size[1:3], fake_video=fake_video)
+        assert frames.ndim == 4 and frames.shape[0] == N and frames.shape[3] == C
+        points = dataset[name]["points"]
+        occluded = dataset[name]["occluded"]
+        points *= np.array([train_size[2], train_size[1]])
+        converted = {}
+        if "strided" in query_modes:
+            converted["strided"] = sample_queries_strided(occluded, points, frames)
+        if "first" in query_modes:
+            converted["first"] = sample_queries_first(occluded, points, frames)
+        yield {"data": converted, "video_name": name, "N_sequences": n_sequences}
 
 
 # ---------------------------------------------------------------------------
@@ -159,11 +283,12 @@ def track_sequence(tracker, video, start_frame, direction="forward", debug=False
     return metas
 
 
-def run_sequence(tracker, video, query_points, query_mode, flow_cache=None, device=None):
+def run_sequence(tracker, video, query_points, query_mode, flow_cache=None, device=None, on_run=None, debug=False):
     """One sequence, one query mode: ``video`` (n_frames, H, W, 3) uint8 BGR, ``query_points``
     (n_queries, 3) as (t, y, x) in video pixels.  Returns {'tracks': (1, n, T, 2) xy on the
     256 x 256 raster, 'occluded': (1, n, T) occlusion scores} -- the reference's per-sequence
-    tracklet pickle.  Occlusion scores are left soft, as the reference stores them."""
+    tracklet pickle.  Occlusion scores are left soft, as the reference stores them.
+    ``on_run(start_frame, direction, metas)``: called after every tracker run (exports)."""
     if query_mode not in ("first", "strided"):
         raise ValueError("Unknown query mode " + query_mode)
     query_points = np.asarray(query_points).astype(np.int64)
@@ -178,13 +303,139 @@ def run_sequence(tracker, video, query_points, query_mode, flow_cache=None, devi
         if device is not None:
             queries_xy = queries_xy.to(device)
         for direction in directions:
-            metas = track_sequence(tracker, video, int(start_frame), direction=direction, flow_cache=flow_cache)
+            metas = track_sequence(tracker, video, int(start_frame), direction=direction, debug=debug, flow_cache=flow_cache)
             for frame_i, meta in metas.items():
                 coords, occl = convert_to_point_tracking(meta.result, queries_xy)
                 pred_tracks[sel, frame_i] = coords
                 pred_occluded[sel, frame_i] = occl
+            if on_run is not None:
+                on_run(int(start_frame), direction, metas)
     pred_tracks *= np.array([256.0 / W, 256.0 / H])
     return {"tracks": pred_tracks[None], "occluded": pred_occluded[None]}
+
+
+def _query_modes(mode):
+    if mode not in ("first", "strided", "both"):
+        raise ValueError("Unknown query mode " + str(mode))
+    return ["first", "strided"] if mode == "both" else [mode]
+
+
+def validate_configs(configs):
+    """All tracker configs of one run share the tracker class and the flow config: ONE tracker object is built and its ``C`` is
+    swapped between runs (``run_MFT_tapvid.py:89-96, 151, 297-300``)."""
+    assert all(c.tracker_class == configs[0].tracker_class for c in configs)
+    assert all(c.flow_config == configs[0].flow_config for c in configs)
+
+
+def result_path(export, tracker_name, sequence_name, query_mode):
+    return Path(export) / tracker_name / "results" / f"{sequence_name}-{query_mode}.pklz"
+
+
+def run_dataset(dataset_conf, configs, export, cache_root, mode="both", cont=False, seqs=None, write_flow=False,
+                ram_cache_limit=30, gpu_cache_limit=5, tracker=None, device="cuda", debug=False, cache_factory=None):
+    """The TAP-Vid run of ``MFT/runners/run_MFT_tapvid.py:85-247``: every sequence of every pickle of ``dataset_conf``
+    (``.pickles``, ``.scaling``, ``.name``) is tracked for every query mode and tracker config, all runs of a sequence
+    sharing one flow cache (``cache_root/<dataset>/<flow name>/<sequence>``, emptied before and removed after), and the
+    tracklets are pickled to ``export/<tracker name>/results/<sequence>-<mode>.pklz`` as {'tracks' (1, n, T, 2) on the
+    256 x 256 raster, 'occluded' (1, n, T) scores}.  ``cont``: existing result files are skipped.  ``write_flow``: the
+    frame-0 template's results of the 'first' run are written as ``flowous/<sequence>/0--<i>.flowouX16.pkl``.
+    ``cache_factory(dir, max_RAM_MB, max_GPU_RAM_MB)`` defaults to ``mft_amd.io.FlowCache`` (HBM tier first: on an MI355X
+    ``gpu_cache_limit`` can be raised to hundreds of GB).  -> list of {'sequence', 'mode', 'tracker', 'path', 'skipped'}."""
+    from .io import FlowCache
+    configs = list(configs)
+    validate_configs(configs)
+    if tracker is None:
+        tracker = configs[0].tracker_class(configs[0])
+    export, cache_root = Path(export), Path(cache_root)
+    for c in configs:
+        (export / c.name / "results").mkdir(parents=True, exist_ok=True)
+    modes = _query_modes(mode)
+    make_cache = cache_factory or (lambda d, ram, gpu: FlowCache(d, max_RAM_MB=ram, max_GPU_RAM_MB=gpu, device=device))
+    done = []
+    for pickle_path in dataset_conf.pickles:
+        for seq in create_tapvid_dataset(pickle_path, modes, dataset_conf.scaling):
+            name = seq["video_name"]
+            if seqs is not None and name not in seqs:
+                continue
+            video = seq["data"][modes[0]]["video"][0]                   # every mode carries the same video
+            video = np.ascontiguousarray(video[:, :, :, ::-1])           # RGB -> BGR, what the tracker takes
+            assert video.dtype == np.uint8 and video.shape[3] == 3
+            flow_name = configs[0].flow_config.name
+            assert flow_name
+            cache_dir = cache_root / str(dataset_conf.name) / str(flow_name) / name
+            shutil.rmtree(cache_dir, ignore_errors=True)
+            cache_dir.mkdir(parents=True, exist_ok=True)
+            cache = make_cache(cache_dir, ram_cache_limit * 1e3, gpu_cache_limit * 1e3)
+            for query_mode in modes:
+                query_points = np.asarray(seq["data"][query_mode]["query_points"])[0].astype(np.int64)
+                if query_mode == "first" and write_flow and 0 not in np.unique(query_points[:, 0]):
+                    raise Exception("Trying to export flowous from first frame, but 0 is not in 'start_frames'" +
+                                    f"in {name} in {Path(pickle_path).stem}")
+                for cfg in configs:
+                    tracker.C = cfg
+                    path = result_path(export, cfg.name, name, query_mode)
+                    if cont and path.exists():
+                        done.append(dict(sequence=name, mode=query_mode, tracker=cfg.name, path=path, skipped=True))
+                        continue
+
+                    def on_run(start_frame, direction, metas, _cfg=cfg, _mode=query_mode):
+                        if start_frame == 0 and _mode == "first" and write_flow and direction == "forward":
+                            flowou_dir = export / _cfg.name / "flowous" / name
+                            flowou_dir.mkdir(parents=True, exist_ok=True)
+                            for frame_i, meta in metas.items():
+                                meta.result.write(flowou_dir / f"0--{frame_i}.flowouX16.pkl")
+                    out = run_sequence(tracker, video, query_points, query_mode, flow_cache=cache, device=device, on_run=on_run,
+                                       debug=debug)
+                    assert out["tracks"].shape[0] == 1 and out["tracks"].shape[3] == 2 and out["tracks"].ndim == 4
+                    with open(path, "wb") as f:
+                        pickle.dump(out, f)
+                    done.append(dict(sequence=name, mode=query_mode, tracker=cfg.name, path=path, skipped=False))
+            shutil.rmtree(cache_dir, ignore_errors=True)
+            cache.clear()
+    return done
+
+
+def evaluate_dataset(dataset_conf, configs, export, mode="both", write=True):
+    """``MFT/runners/eval_MFT_tapvid.py:69-133``: the tracklet pickles of ``run_dataset`` against the ground truth of the same
+    pickles (frames are not needed: ``fake_video``), both on the 256 x 256 raster, occlusion scores thresholded at 0.5.
+    -> {mode: {tracker name: [metrics dict per sequence, + 'seq']}}; with ``write`` each list also goes to
+    ``export/<tracker>/eval/tapvid-eval[-strided].pklz`` as a pandas DataFrame, like the reference."""
+    modes = _query_modes(mode)
+    export = Path(export)
+    all_metrics = {m: {c.name: [] for c in configs} for m in modes}
+    for pickle_path in dataset_conf.pickles:
+        for seq in create_tapvid_dataset(pickle_path, modes, dataset_conf.scaling, fake_video=True):
+            name = seq["video_name"]
+            H, W = seq["data"][modes[0]]["video"].shape[2:4]
+            scale = np.array([256.0 / W, 256.0 / H])
+            for query_mode in modes:
+                gt = seq["data"][query_mode]
+                query_points = np.asarray(gt["query_points"])[0].astype(np.int64)[None]
+                gt_tracks = gt["target_points"] * scale
+                gt_occluded = gt["occluded"]
+                for cfg in configs:
+                    path = result_path(export, cfg.name, name, query_mode)
+                    if not path.exists():
+                        continue                               # (a subset run: --seq)
+                    with open(path, "rb") as f:
+                        out = pickle.load(f)
+                    pred_occluded = np.float32(out["occluded"] > 0.5)
+                    assert out["tracks"].shape == gt_tracks.shape and pred_occluded.shape == gt_occluded.shape
+                    m = compute_tapvid_metrics(query_points, gt_occluded, gt_tracks, pred_occluded, out["tracks"], query_mode)
+                    assert all(v.shape == (1,) for v in m.values())
+                    m = {k: v[0] for k, v in m.items()}
+                    m["seq"] = name
+                    all_metrics[query_mode][cfg.name].append(m)
+    if write:
+        import pandas as pd
+        for cfg in configs:
+            eval_dir = export / cfg.name / "eval"
+            eval_dir.mkdir(parents=True, exist_ok=True)
+            for query_mode in modes:
+                rows = dict(enumerate(all_metrics[query_mode][cfg.name]))
+                pd.DataFrame.from_dict(rows, orient="index").to_pickle(
+                    eval_dir / ("tapvid-eval-strided.pklz" if query_mode == "strided" else "tapvid-eval.pklz"))
+    return all_metrics
 
 
 def evaluate(outputs, gt, query_mode, occlusion_threshold=0.5):
@@ -198,6 +449,20 @@ def evaluate(outputs, gt, query_mode, occlusion_threshold=0.5):
     q[..., 2] *= scale[0]
     return compute_tapvid_metrics(q, gt["occluded"].astype(bool), gt["target_points"] * scale,
                                   outputs["occluded"] > occlusion_threshold, outputs["tracks"], query_mode)
+
+
+def synthetic_pickle(path, videos, n_tracks=24, seed=0):
+    """Write a TAP-Vid-shaped pickle (dict form: RGB frames, points normalised to [0, 1], occlusion flags) for
+    ``{name: SyntheticVideo}`` -- what ``create_tapvid_dataset`` reads; the analytic ground truth of ``synthetic_sequence``."""
+    data = {}
+    for i, (name, video) in enumerate(videos.items()):
+        occ, pts, frames = synthetic_sequence(video, n_tracks=n_tracks, seed=seed + i)
+        data[name] = {"video": np.ascontiguousarray(frames[..., ::-1]),          # BGR -> RGB
+                      "points": pts / np.array([float(video.W), float(video.H)]),
+                      "occluded": occ}
+    with open(path, "wb") as f:
+        pickle.dump(data, f, protocol=4)
+    return data
 
 
 def synthetic_sequence(video, n_tracks=32, seed=0):

@@ -115,6 +115,27 @@ def tapvid_inputs():
                 pred_occluded=pred_occluded, frames=frames)
 
 
+def tapvid_pickle_sequences():
+    """TAP-Vid-shaped sequences for the dataset-reader pin: {name: {'video' (N, H, W, 3) uint8 RGB smooth texture,
+    'points' (n, N, 2) xy in [0, 1], 'occluded' (n, N) bool}} -- two sequences of different size / aspect ratio (the real
+    pickles hold 256-frame DAVIS clips; these are 8 frames of 40 x 56 and 36 x 36)."""
+    r = _rng(53)
+    out = {}
+    for name, (N, H, W, n) in (("seq-wide", (8, 40, 56, 7)), ("seq-square", (8, 36, 36, 5))):
+        base = smooth_field(r, 3, H + 16, W + 16, cells=4, amp=110.0) + 128.0
+        video = np.stack([np.clip(base[:, i: i + H, i // 2: i // 2 + W], 0, 255).transpose(1, 2, 0) for i in range(N)]).astype(np.uint8)
+        pts = np.clip(r.uniform(0.05, 0.95, size=(n, 1, 2)) + np.cumsum(r.normal(0, 0.01, size=(n, N, 2)), axis=1), 0.0, 0.999)
+        occ = r.random((n, N)) < 0.25
+        occ[0] = True                               # a never-visible track
+        occ[1, :3] = True                           # first visible late
+        occ[2, 0] = False
+        out[name] = {"video": np.ascontiguousarray(video), "points": pts.astype(np.float64), "occluded": occ}
+    return out
+
+
+TAPVID_SCALINGS = ("default", "false", "fullres", "32x24_64x48", "x30", "48x", "fullres_40x40", "256x256_512x512")
+
+
 def results_api_inputs():
     """A FlowOU result on a 40 x 56 frame (smooth flow that leaves the frame on two sides), an image to warp,
     a mask, and query points incl. out-of-frame and integral ones."""

@@ -593,7 +593,8 @@ def test_infinite_sigma_is_not_an_error_and_drain_checks_without_sync(weights_np
     tri = make_tracker(fl_inf, deltas=(np.inf, 1))
     tri.init(vid[0])
     out = tri.track(vid[1]).result                                        # synced path, default guard ON: must not raise
-    assert torch.isinf(out.sigma).all() and torch.isfinite(out.flow).all() and fl_inf.nonfinite_count() == 0
+    # (inf, or NaN where the chain's bilinear sampling multiplies an inf by a zero weight -- grid_sample does the same)
+    assert not torch.isfinite(out.sigma).any() and torch.isfinite(out.flow).all() and fl_inf.nonfinite_count() == 0
     del tri, fl_inf
     fl = RAFTWrapper(c, state_dict=weights_np)
     tr = make_tracker(fl, deltas=(np.inf, 1))

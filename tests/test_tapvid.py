@@ -127,3 +127,189 @@ def test_synthetic_ground_truth_is_consistent():
     m = tapvid.evaluate({"tracks": s["target_points"] * np.array([256 / 128, 256 / 96]),
                          "occluded": s["occluded"].astype(np.float64)}, s, "first")
     assert m["average_jaccard"][0] == 1.0
+
+
+# ---------------------------------------------------------------------------
+# dataset reader (create_tapvid_dataset / parse_scale_WH / Kinetics shards) vs the reference's own reader run on the
+# fixture pickles (tests/golden/tapvid_dataset.npz, tools/make_goldens.py tapvid_dataset)
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def gd(golden_dir):
+    return np.load(golden_dir / "tapvid_dataset.npz")
+
+
+def test_parse_scale_WH_matches_reference(gd):
+    shapes = [{"N_frames": 8, "H": 40, "W": 56, "C": 3}, {"N_frames": 3, "H": 480, "W": 854, "C": 3}]
+    n = 0
+    for j, fs in enumerate(shapes):
+        for sc in ("fullres", "256x256", "x1080", "512x", "256x256_x480", "fullres_300x", "x7_9x_fullres"):
+            got = tapvid.parse_scale_WH(sc, fs)
+            want = gd[f"parse|{j}|{sc}"]
+            assert [[d["N_frames"], d["H"], d["W"], d["C"]] for d in got] == want.tolist(), sc
+            n += 1
+    assert n == 14
+    assert tapvid.parse_scale_WH("256x256_512x512", shapes[1])[-1]["W"] == 512      # the BASELINE config 3 string
+    with pytest.raises(AssertionError):
+        tapvid.parse_scale_WH("x", shapes[0])
+
+
+@pytest.mark.parametrize("form,fname", [("dict", "tapvid_davis_like.pkl"), ("kin", "tapvid_kinetics_like_0007.pkl")])
+def test_create_tapvid_dataset_matches_reference(gd, golden_dir, form, fname):
+    """Every scaling kind x both pickle forms: names, N_sequences, the resized video (bitwise; by checksum for the big ones), and
+    the sampled query / target / occlusion tables of both query modes -- all equal to what the reference's reader returned."""
+    import zlib
+    seen = 0
+    for sc in gi.TAPVID_SCALINGS:
+        arg = {"default": None, "false": False}.get(sc, sc)
+        for fake in (False, True):
+            if fake and sc not in ("256x256_512x512", "x30"):
+                continue
+            els = list(tapvid.create_tapvid_dataset(golden_dir / fname, ["first", "strided"], arg, fake_video=fake))
+            assert len(els) == 2
+            for i, el in enumerate(els):
+                key = f"{form}|{sc}|{'fake' if fake else 'real'}|{i}"
+                assert el["video_name"] == str(gd[key + "|name"]) and el["N_sequences"] == int(gd[key + "|N"])
+                assert sorted(el["data"]) == ["first", "strided"]
+                for mode in ("first", "strided"):
+                    g = el["data"][mode]
+                    assert list(g["video"].shape) == gd[f"{key}|{mode}|video_shape"].tolist(), key
+                    assert zlib.crc32(np.ascontiguousarray(g["video"]).tobytes()) == int(gd[f"{key}|{mode}|video_crc"]), key
+                    for k in ("query_points", "target_points", "occluded", "trackgroup"):
+                        want = gd[f"{key}|{mode}|{k}"]
+                        assert g[k].shape == want.shape and np.array_equal(np.asarray(g[k], want.dtype), want), (key, mode, k)
+                if key + "|video" in gd.files:
+                    assert np.array_equal(el["data"]["first"]["video"], gd[key + "|video"])
+                seen += 1
+    assert seen == 2 * (len(gi.TAPVID_SCALINGS) + 2)
+    # the BASELINE config-3 string: tracked at 512 x 512 on frames resampled 40x56 -> 256x256 -> 512x512, points at 512 scale
+    el = next(iter(tapvid.create_tapvid_dataset(golden_dir / fname, ["first"], "256x256_512x512")))
+    assert el["data"]["first"]["video"].shape[2:4] == (512, 512) and el["data"]["first"]["target_points"].max() > 256
+
+
+def test_create_tapvid_dataset_rejects_lazy(golden_dir):
+    with pytest.raises(ValueError):
+        next(tapvid.create_tapvid_dataset(golden_dir / "tapvid_davis_like.pkl", ["first"], lazy_video=True))
+    frames = tapvid.resize_video(np.zeros((3, 8, 8, 3), np.uint8), (4, 6), lazy_video=True)
+    assert len(frames) == 3 and frames[1]().shape == (4, 6, 3)
+    assert tapvid.resize_video(np.zeros((3, 8, 8, 3), np.uint8), (4, 6), fake_video=True).shape == (3, 4, 6, 3)
+
+
+# ---------------------------------------------------------------------------
+# dataset runner + evaluation (run_MFT_tapvid.py:100-237, eval_MFT_tapvid.py:69-133) on the fixture pickle, stub flows
+# ---------------------------------------------------------------------------
+class HashFlower:
+    """Stub flow plugin for arbitrary frames: recognises a frame by its bytes (the frames of the sequences it was given)."""
+
+    def __init__(self):
+        self.ids, self.calls = {}, []
+
+    def learn(self, video, tag):
+        import zlib
+        for i, f in enumerate(video):
+            self.ids[zlib.crc32(np.ascontiguousarray(f).tobytes())] = (tag, i)
+
+    def compute_flow(self, src_img, dst_img, mode="flow", init_flow=None, **kw):
+        import zlib
+        (ta, l), (tb, r) = (self.ids[zlib.crc32(np.ascontiguousarray(np.asarray(x)).tobytes())] for x in (src_img, dst_img))
+        assert ta == tb
+        self.calls.append((ta, l, r))
+        H, W = np.asarray(src_img).shape[:2]
+        flow, occl, sigma = gi.stub_flowou(l, r, H, W)
+        return torch.from_numpy(flow * 0.25), {"occlusion": torch.from_numpy(occl), "sigma": torch.from_numpy(sigma), "debug": None}
+
+
+def _dataset_conf(golden_dir, scaling):
+    from mft_amd.config import Config
+    c = Config()
+    c.pickles = [golden_dir / "tapvid_davis_like.pkl"]
+    c.scaling = scaling
+    c.name = "fixture-" + scaling
+    return c
+
+
+def test_run_dataset_and_evaluate(golden_dir, tmp_path):
+    import pickle
+    from mft_amd.io import FlowCache
+    scaling = "32x24_64x48"                       # track at 64 x 48 on twice-resampled frames, score at 256 x 256
+    dconf = _dataset_conf(golden_dir, scaling)
+    fl = HashFlower()
+    for el in tapvid.create_tapvid_dataset(dconf.pickles[0], ["first"], scaling):
+        fl.learn(el["data"]["first"]["video"][0][..., ::-1], el["video_name"])
+    tr = make_tracker(fl, deltas=(np.inf, 1, 2, 4))
+    tr.C.name = "stubtracker"
+    tr.C.flow_config.name = "stubflow"
+    tr.C.tracker_class = None
+    caches = []
+
+    def factory(d, ram, gpu):
+        caches.append(FlowCache(d, max_RAM_MB=ram, max_GPU_RAM_MB=gpu, device="cpu"))
+        return caches[-1]
+    export, cache_root = tmp_path / "export", tmp_path / "cache"
+    done = tapvid.run_dataset(dconf, [tr.C], export, cache_root, mode="both", tracker=tr, device=None, cache_factory=factory,
+                              write_flow=False)
+    assert [(d["sequence"], d["mode"], d["skipped"]) for d in done] == [
+        ("seq-wide", "first", False), ("seq-wide", "strided", False), ("seq-square", "first", False), ("seq-square", "strided", False)]
+    assert len(caches) == 2 and not any((cache_root / dconf.name / "stubflow").glob("*"))      # one cache per sequence, removed after
+    # the files hold what run_sequence returns for the same queries (a fresh tracker, a fresh cache)
+    els = {el["video_name"]: el for el in tapvid.create_tapvid_dataset(dconf.pickles[0], ["first", "strided"], scaling)}
+    for d in done:
+        with open(d["path"], "rb") as f:
+            out = pickle.load(f)
+        assert d["path"] == export / "stubtracker" / "results" / f"{d['sequence']}-{d['mode']}.pklz"
+        el = els[d["sequence"]]["data"][d["mode"]]
+        video = np.ascontiguousarray(el["video"][0][..., ::-1])
+        assert video.shape[1:3] == (48, 64)
+        want = tapvid.run_sequence(make_tracker(fl, deltas=(np.inf, 1, 2, 4)), video, el["query_points"][0], d["mode"],
+                                   flow_cache=FlowCache(None, device="cpu"))
+        assert np.array_equal(out["tracks"], want["tracks"]) and np.array_equal(out["occluded"], want["occluded"])
+        assert out["tracks"].shape == el["target_points"].shape
+        assert out["tracks"][..., 0].max() <= 256 * 1.5           # on the 256 raster, whatever the tracking size
+    # cont: nothing is recomputed; without it everything is
+    n_calls = len(fl.calls)
+    again = tapvid.run_dataset(dconf, [tr.C], export, cache_root, mode="both", cont=True, tracker=tr, device=None, cache_factory=factory)
+    assert all(d["skipped"] for d in again) and len(fl.calls) == n_calls
+    sub = tapvid.run_dataset(dconf, [tr.C], export, cache_root, mode="first", seqs=["seq-square"], tracker=tr, device=None,
+                             cache_factory=factory)
+    assert [(d["sequence"], d["mode"]) for d in sub] == [("seq-square", "first")] and len(fl.calls) > n_calls
+    # evaluation: one row per sequence, the reference's keys, written as DataFrames
+    m = tapvid.evaluate_dataset(dconf, [tr.C], export, mode="both")
+    assert sorted(m) == ["first", "strided"]
+    rows = m["strided"]["stubtracker"]
+    assert [r["seq"] for r in rows] == ["seq-wide", "seq-square"] and 0.0 <= rows[0]["average_jaccard"] <= 1.0
+    import pandas as pd
+    df = pd.read_pickle(export / "stubtracker" / "eval" / "tapvid-eval-strided.pklz")
+    assert list(df["seq"]) == ["seq-wide", "seq-square"] and "average_pts_within_thresh" in df.columns
+    assert (export / "stubtracker" / "eval" / "tapvid-eval.pklz").exists()
+    # ground truth as the prediction scores 1: the scale chain of the evaluation is consistent with the runner's
+    for d in done:
+        el = els[d["sequence"]]["data"][d["mode"]]
+        H, W = el["video"].shape[2:4]
+        with open(d["path"], "wb") as f:
+            pickle.dump({"tracks": el["target_points"] * np.array([256.0 / W, 256.0 / H]), "occluded": el["occluded"].astype(np.float64)}, f)
+    m = tapvid.evaluate_dataset(dconf, [tr.C], export, mode="both", write=False)
+    assert all(r["average_jaccard"] == 1.0 and r["occlusion_accuracy"] == 1.0 for mode in m for r in m[mode]["stubtracker"])
+
+
+@pytest.mark.gpu
+def test_run_dataset_write_flow_exports_template_results(golden_dir, tmp_path):
+    """(gpu: the X16 writer quantises on the device)"""
+    from mft_amd.io import FlowCache
+    from mft_amd.results import FlowOUTrackingResult
+    dconf = _dataset_conf(golden_dir, "fullres")
+    fl = HashFlower()
+    for el in tapvid.create_tapvid_dataset(dconf.pickles[0], ["first"], "fullres"):
+        # (not `False`: like the reference, a non-string size is rebound by the first sequence and kept for the rest)
+        fl.learn(el["data"]["first"]["video"][0][..., ::-1], el["video_name"])
+    tr = make_tracker(fl, deltas=(np.inf, 1, 2))
+    tr.C.name, tr.C.flow_config.name, tr.C.tracker_class = "t", "f", None
+    factory = lambda d, ram, gpu: FlowCache(d, max_RAM_MB=ram, max_GPU_RAM_MB=gpu, device="cpu")    # noqa: E731
+    try:
+        tapvid.run_dataset(dconf, [tr.C], tmp_path / "e", tmp_path / "c", mode="first", tracker=tr, device=None,
+                           cache_factory=factory, write_flow=True, seqs=["seq-square"])
+    except Exception as e:                      # (only if no track of the fixture is visible in frame 0)
+        assert "0 is not in 'start_frames'" in str(e)
+        return
+    files = sorted((tmp_path / "e" / "t" / "flowous" / "seq-square").glob("0--*.flowouX16.pkl"))
+    assert len(files) == 8
+    r = FlowOUTrackingResult.read(files[3])
+    assert r.flow.shape == (2, 36, 36)

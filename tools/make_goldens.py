@@ -427,8 +427,77 @@ def gen_tapvid():
     print("tapvid.npz", sum(v.nbytes for v in out.values()) / 1e3, "kB,", len(out), "arrays")
 
 
+def gen_tapvid_dataset():
+    """The reference's dataset reader (create_tapvid_dataset: tapvid_eval_stuff.py:612-672, parse_scale_WH: MFT/utils/misc.py:65-92,
+    load_kinetics_video: :528-549) on two small TAP-Vid-shaped pickles written here as FIXTURES (tests/golden/tapvid_*.pkl:
+    data -- a dict-form pickle and a Kinetics-style list of JPEG-encoded sequences) under every kind of scaling string.
+    ``mediapy`` is absent: its ``resize_video`` is stubbed with what mediapy does for uint8 RGB frames -- PIL's Lanczos filter,
+    frame by frame -- so the resampler itself is pinned only as far as that stub is faithful; everything around it (the chain of
+    rescalings, which size the points are scaled to, the train_size carry-over between sequences, the shard naming, the in-place
+    point scaling, the samplers' inputs) is the reference's own code running."""
+    import io as pyio
+    import pickle
+    import zlib
+    from PIL import Image
+    mediapy = types.ModuleType("mediapy")
+
+    def resize_video(video, shape):
+        return np.stack([np.asarray(Image.fromarray(f).resize((shape[1], shape[0]), resample=Image.Resampling.LANCZOS))
+                         for f in video])
+    mediapy.resize_video = resize_video
+    sys.modules["mediapy"] = mediapy
+    from MFT.evaluation import tapvid_eval_stuff as tves
+    from MFT.utils.misc import parse_scale_WH
+    seqs = gi.tapvid_pickle_sequences()
+    dict_path = OUT / "tapvid_davis_like.pkl"
+    with open(dict_path, "wb") as f:
+        pickle.dump(seqs, f, protocol=4)
+    kin = []
+    for name, d in seqs.items():
+        jpegs = []
+        for frame in d["video"]:
+            buf = pyio.BytesIO()
+            Image.fromarray(frame).save(buf, format="JPEG", quality=92)
+            jpegs.append(buf.getvalue())
+        kin.append({"video": jpegs, "points": d["points"].copy(), "occluded": d["occluded"].copy()})
+    kin_path = OUT / "tapvid_kinetics_like_0007.pkl"
+    with open(kin_path, "wb") as f:
+        pickle.dump(kin, f, protocol=4)
+    out = {}
+    for form, path in (("dict", dict_path), ("kin", kin_path)):
+        for sc in gi.TAPVID_SCALINGS:
+            arg = {"default": None, "false": False}.get(sc, sc)
+            for fake in (False, True):
+                if fake and sc not in ("256x256_512x512", "x30"):
+                    continue
+                for i, el in enumerate(tves.create_tapvid_dataset(path, ["first", "strided"], arg, fake_video=fake)):
+                    key = f"{form}|{sc}|{'fake' if fake else 'real'}|{i}"
+                    out[key + "|name"] = np.array(el["video_name"])
+                    out[key + "|N"] = np.array(el["N_sequences"])
+                    for mode in ("first", "strided"):
+                        g = el["data"][mode]
+                        video = np.asarray(g["video"])
+                        out[f"{key}|{mode}|video_shape"] = np.array(video.shape)
+                        out[f"{key}|{mode}|video_crc"] = np.array(zlib.crc32(np.ascontiguousarray(video).tobytes()))
+                        if mode == "first" and video.size <= 60000:
+                            out[f"{key}|video"] = video
+                        for k in ("query_points", "target_points", "occluded", "trackgroup"):
+                            out[f"{key}|{mode}|{k}"] = np.asarray(g[k])
+    shapes = [{"N_frames": 8, "H": 40, "W": 56, "C": 3}, {"N_frames": 3, "H": 480, "W": 854, "C": 3}]
+    for j, fs in enumerate(shapes):
+        for sc in ("fullres", "256x256", "x1080", "512x", "256x256_x480", "fullres_300x", "x7_9x_fullres"):
+            res = parse_scale_WH(sc, fs)
+            out[f"parse|{j}|{sc}"] = np.array([[d["N_frames"], d["H"], d["W"], d["C"]] for d in res])
+    np.savez_compressed(OUT / "tapvid_dataset.npz", **out)
+    print("tapvid_dataset.npz", sum(v.nbytes for v in out.values()) / 1e3, "kB,", len(out), "arrays;",
+          dict_path.stat().st_size / 1e3, "+", kin_path.stat().st_size / 1e3, "kB of fixture pickles")
+
+
 if __name__ == "__main__":
     assert REF.exists(), "the reference is only mounted in the build container"
+    if sys.argv[1:] == ["tapvid_dataset"]:
+        gen_tapvid_dataset()
+        sys.exit(0)
     which = sys.argv[1:] or ["ops", "flow", "seq", "e2e", "tapvid", "results", "codec"]
     if set(which) <= {"tapvid", "results", "codec"}:
         if "codec" in which:
