@@ -226,7 +226,11 @@ __device__ __forceinline__ void buf_load_lds(__amdgpu_buffer_rsrc_t r, float *ds
 
 // s_barrier with compiler fences on both sides (the intrinsic alone does not order LDS accesses)
 __device__ __forceinline__ void block_barrier() {
-    asm volatile("" ::: "memory");
+    // s_waitcnt lgkmcnt(0): gfx950 has back-off barriers, so the compiler inserts NO wait in front of s_barrier and the builtin is no
+    // fence -- without this a wave's last ds_write may still sit in the LDS queue when another wave reads the slot behind the
+    // barrier (found in round 5 with tools/race_kernels.py: harmless with the GPU to itself, wrong values under contention).
+    // LDS only: global prefetches and LDS-DMA loads (vmcnt) stay in flight, their consumers count them themselves.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }

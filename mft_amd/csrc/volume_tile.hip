@@ -114,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void volume_tile_kernel(VolTileArgs p) {
             *reinterpret_cast<uint4 *>(lds + m * VT_ROW + pc * 16) = v;
         }
     }
-    asm volatile("" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (no implicit wait in front of s_barrier on gfx950: tile_conv.hip, tc_barrier)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 

@@ -8,7 +8,9 @@ never depend on tracker state -- RAFT sees only the two images, ``flow_init`` is
 
   1. window frames are encoded once, by their owner rank (frame j -> rank j mod G), and the
      features (fmap | net | inp, 8.4 MB per 512x512 frame) are all-gathered: no rank re-encodes
-     a frame another rank already encoded;
+     a frame another rank already encoded; a window with fewer frames than half the ranks (the
+     per-frame mode, L = 1) is encoded by NETWORK instead: fnet of frame j on rank 2 j, cnet on
+     rank 2 j + 1, the two halves meet in the same all-gather;
   2. the units, in (frame, selection-order) order, are cut into G contiguous, equally sized
      shares (sizes differ by at most one); every rank runs its share through the native RAFT
      engine in equal batches of up to 16 pairs -- at or above the single-GPU tracker's 7, where the
@@ -99,14 +101,31 @@ class WindowSharder:
         for ``_finish_feature_exchange`` (None: nothing to exchange)."""
         flower = tracker.flower
         G, L = self.world_size, len(frame_ids)
-        if not hasattr(flower, "encode_packed") or 2 * L < G:
-            return None              # a reference-style plugin, or far fewer frames than ranks (the online mode, L = 1): everyone encodes what it needs
+        if not hasattr(flower, "encode_packed"):
+            return None              # a reference-style plugin: everyone encodes what it needs
+        halves = 2 * L <= G          # fewer frames than half the ranks (the online mode, L = 1): one NETWORK per rank, see below
+        if halves and not hasattr(flower, "encode_half"):
+            return None
         stream = None
         if side and hasattr(flower, "ensure_encode_stream"):
             stream = flower.ensure_encode_stream()   # all encoder work of the plugin is serialised on this stream
+        ctx = torch.cuda.stream(stream) if stream is not None else _NullCtx()
+        if halves:
+            # unit u = 2 j + part (part 0: fnet, part 1: cnet) is encoded by rank u: the frame's serial head is ONE encoder,
+            # its two halves (N * 256 floats each) meet in the all-gather; ranks >= 2 L send a slot nobody reads
+            with ctx:
+                numel = flower.packed_numel(imgs[0]) // 2
+                if self.rank < 2 * L:
+                    send, _ = flower.encode_half(imgs[self.rank // 2], self.rank % 2)
+                    send = send.view(1, numel)
+                    self.stats["encoded"] += 0.5
+                else:
+                    send = torch.empty((1, numel), dtype=torch.float32, device=tracker.device)
+                recv = torch.empty((G, 1, numel), dtype=send.dtype, device=send.device)
+                work = dist.all_gather_into_tensor(recv.view(G, numel), send, group=self.group, async_op=side)
+            return dict(ids=list(frame_ids), imgs=list(imgs), recv=recv, send=send, work=work, stream=stream, halves=True)
         slots = -(-L // G)
         mine = [j for j in range(L) if frame_owner(j, G) == self.rank]
-        ctx = torch.cuda.stream(stream) if stream is not None else _NullCtx()
         with ctx:
             send = None
             for s_, j in enumerate(mine):
@@ -121,7 +140,7 @@ class WindowSharder:
             # (NCCL orders the collective behind the work already on the CURRENT stream -- the side stream here)
             work = dist.all_gather_into_tensor(recv.view(G * send.shape[0], *send.shape[1:]), send, group=self.group,
                                                async_op=side)
-        return dict(ids=list(frame_ids), imgs=list(imgs), recv=recv, send=send, work=work, stream=stream)
+        return dict(ids=list(frame_ids), imgs=list(imgs), recv=recv, send=send, work=work, stream=stream, halves=False)
 
     def _finish_feature_exchange(self, tracker, h):
         """Wait for the exchange and install the features in the flow plugin's per-frame cache (all ranks)."""
@@ -135,7 +154,10 @@ class WindowSharder:
             h["recv"].record_stream(cur)
         G = self.world_size
         for j, fid in enumerate(h["ids"]):
-            tracker.flower.adopt_packed(fid, h["recv"][frame_owner(j, G), j // G], h["imgs"][j])
+            if h["halves"]:
+                tracker.flower.adopt_halves(fid, h["recv"][2 * j, 0], h["recv"][2 * j + 1, 0], h["imgs"][j])
+            else:
+                tracker.flower.adopt_packed(fid, h["recv"][frame_owner(j, G), j // G], h["imgs"][j])
 
     # ------------------------------------------------------------------ the window
     def track_window(self, tracker, imgs, next_imgs=None, defer=False):

@@ -235,6 +235,45 @@ class RAFTWrapper:
             buf.record_stream(main)
         return buf, (h, w)
 
+    @torch.no_grad()
+    def encode_half(self, img_bgr, part, wait=True):
+        """One of the two encoders of a frame: part 0 = fnet -> fmap [N, 256], part 1 = cnet -> net [N, 128] | inp [N, 128]; both
+        are N * 256 floats -- the two halves of an ``encode_packed`` buffer.  The multi-GPU path hands the two networks of a frame
+        to two ranks when a window has fewer frames than half the ranks (the per-frame mode): the serial head of the frame is one
+        encoder instead of two.  Stream handling as in ``encode_packed``."""
+        H0, W0 = img_bgr.shape[:2]
+        h, w, _ = self._geometry(H0, W0)
+        N = h * w
+
+        def run():
+            img = self._device_image(img_bgr)
+            buf = torch.empty(N * 256, dtype=torch.float32, device=self.device)
+            if part == 0:
+                self.fnet_engine.forward(img, out=(buf.view(N, 256), None))
+            else:
+                self.cnet_engine.forward(img, out=(buf[: N * 128].view(N, 128), buf[N * 128:].view(N, 128)))
+            return buf
+
+        if self._enc_stream is None or torch.cuda.current_stream(self.device) == self._enc_stream:
+            return run(), (h, w)
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self._enc_stream):
+            buf = run()
+        if wait:
+            main.wait_stream(self._enc_stream)
+            buf.record_stream(main)
+        return buf, (h, w)
+
+    def adopt_halves(self, frame_id, fbuf, cbuf, img_bgr):
+        """Install a frame's features from the two ``encode_half`` buffers (produced here or on other ranks)."""
+        H0, W0 = img_bgr.shape[:2]
+        h, w, pads = self._geometry(H0, W0)
+        N = h * w
+        assert fbuf.numel() == N * 256 and cbuf.numel() == N * 256
+        fbuf, cbuf = fbuf.reshape(-1), cbuf.reshape(-1)
+        self._frames[frame_id] = FrameFeatures(fbuf.view(N, 256), cbuf[: N * 128].view(N, 128), cbuf[N * 128:].view(N, 128),
+                                               h, w, pads, (H0, W0))
+
     def packed_numel(self, img_bgr):
         """Floats in the buffer ``encode_packed`` produces for a frame of this size."""
         h, w, _ = self._geometry(*img_bgr.shape[:2])

@@ -18,7 +18,8 @@ N_FRAMES = 20
 
 class ExchangingFlower:
     """Test double with the feature-exchange interface of RAFTWrapper: a frame's "features" are its id;
-    a pair may only be computed from features this rank encoded itself or adopted from a peer."""
+    a pair may only be computed from features this rank encoded itself or adopted from a peer.  A window with fewer frames
+    than half the ranks is encoded by network: one half (fnet | cnet) per rank."""
 
     def __init__(self):
         self.features, self.encoded, self.local = {}, 0, 0
@@ -26,6 +27,14 @@ class ExchangingFlower:
     def encode_packed(self, img):
         self.encoded += 1
         return torch.full((6,), float(gi.decode_id(img))), (1, 1)
+
+    def encode_half(self, img, part):
+        self.encoded += 0.5
+        return torch.full((3,), float(gi.decode_id(img)) if part == 0 else -float(gi.decode_id(img))), (1, 1)
+
+    def adopt_halves(self, frame_id, fbuf, cbuf, img):
+        assert int(fbuf[0]) == gi.decode_id(img) == frame_id == -int(cbuf[0])      # the fnet half and the cnet half, in that order
+        self.features[frame_id] = torch.cat([fbuf, -cbuf])
 
     def packed_numel(self, img):
         return 6
@@ -110,12 +119,12 @@ if __name__ == "__main__":
     dist.init_process_group("gloo")
     rank = dist.get_rank()
     wx = max(5, dist.get_world_size())       # the feature exchange needs at least one frame per rank in a window
-    for mode, window, mk in (("L1", 1, StubFlower), ("L8", 8, StubFlower), ("L5x", wx, ExchangingFlower),
+    for mode, window, mk in (("L1", 1, StubFlower), ("L8", 8, StubFlower), ("L1x", 1, ExchangingFlower), ("L5x", wx, ExchangingFlower),
                              ("L5p", wx, ExchangingFlower), ("L5d", wx, ExchangingFlower)):
         fl = mk()
         # L5p: next window's features exchanged early; L5d: that, and every window's results one call late (pipelined)
         res, tr = run(True, window, fl, prefetch=(mode in ("L5p", "L5d")), defer=(mode == "L5d"))
-        if mode in ("L5x", "L5p", "L5d"):
+        if mode in ("L1x", "L5x", "L5p", "L5d"):
             st = tr.sharder.stats
             res.update(_encoded=np.array(fl.encoded), _local=np.array(fl.local), _frames=np.array(N_FRAMES - 1), _my_units=np.array(st["my_units"]),
                        _windows=np.array(st["windows"]))

@@ -26,16 +26,54 @@ def test_window_sharding_rccl_bitwise(tmp_path):
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     single = np.load(tmp_path / "single.npz")
     for mode in ("L1", "L6", "L6p", "L6d"):
-        enc = 0
+        enc = 0.0
         for r in range(n):
             got = np.load(tmp_path / f"rank{r}_{mode}.npz")
-            enc += int(got["_encoded"])
+            enc += float(got["_encoded"])
             for k in single.files:
                 assert np.array_equal(got[k], single[k]), (mode, r, k)
         if mode in ("L6", "L6p", "L6d") and n <= 6:
             # every exchanged frame is encoded exactly once across the ranks (the ragged last window of one
             # frame is shorter than the world size when n > 1: every rank encodes it itself)
-            assert enc == (13 if n == 1 else 12), enc
+            assert enc == 13, enc
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 4])
+def test_real_plugin_multirank_on_one_gpu(tmp_path, world):
+    """The REAL plugin with world_size > 1 ("weak" 5a): `world` processes share cuda:0, the collectives run
+    on device tensors through gloo (RCCL refuses two ranks on one device; the code path of mft_amd/dist.py is the same:
+    encode_packed / encode_half / adopt_*, the side-stream exchange, record_stream, asynchronous all_gather_into_tensor +
+    wait, engine-written send buffers).  Every rank, in the per-frame mode (L = 1: the frame's two encoders on two ranks),
+    with one frame per rank (L = G), with look-ahead windows of 6 frames plain / prefetched / pipelined, with a warm flow
+    cache, and on a 512 x 512 window at production settings, is BITWISE equal to the single-process tracker."""
+    port = str(29630 + world)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MFT_DIST_BACKEND="gloo", MFT_DIST_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", port, str(REPO / "tests" / "gpu_dist_worker.py"), str(tmp_path)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=850)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    single = np.load(tmp_path / "single.npz")
+    for mode in ("L1", "LG", "L6", "L6p", "L6d", "cachecold", "cachewarm"):
+        enc = 0.0
+        for r in range(world):
+            got = np.load(tmp_path / f"rank{r}_{mode}.npz")
+            enc += float(got["_encoded"]) if "_encoded" in got.files else 0.0
+            for k in single.files:
+                assert np.array_equal(got[k], single[k]), (mode, r, k)
+        if not mode.startswith("cache"):
+            assert enc == 13.0, (mode, enc)            # every frame encoded exactly once across the ranks, whatever the window
+    warm = [np.load(tmp_path / f"rank{r}_cachewarm.npz") for r in range(world)]
+    # warm run: every finite-delta unit comes from its owner's cache, nothing is written again
+    assert sum(int(w["_hits"]) for w in warm) == sum(int(w["_cold_writes"]) for w in warm) > 0
+    assert all(int(w["_warm_writes"]) == 0 for w in warm)
+    for name in ("big", "big1"):
+        ref = np.load(tmp_path / f"single_{name}.npz")
+        for r in range(world):
+            got = np.load(tmp_path / f"rank{r}_{name}.npz")
+            for k in ref.files:
+                assert np.array_equal(got[k], ref[k]), (name, r, k)
 
 
 def test_bench_sharded_line_carries_roofline_and_ranks_seen():
