@@ -20,7 +20,7 @@ REPO = Path(__file__).resolve().parents[1]
 @pytest.mark.timeout(600)
 def test_kernels_and_refinement_are_deterministic_under_contention():
     py = sys.executable
-    loads = [subprocess.Popen([py, str(REPO / "tools" / "race_kernels.py"), "--load-seconds", "40", "--tag", f"load{i}"],
+    loads = [subprocess.Popen([py, str(REPO / "tools" / "race_kernels.py"), "--load-seconds", "55", "--tag", f"load{i}"],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for i in range(2)]
     try:
         time.sleep(8)                                           # (imports + engine set-up of the load generators)
@@ -30,6 +30,10 @@ def test_kernels_and_refinement_are_deterministic_under_contention():
         e = subprocess.run([py, str(REPO / "tools" / "race_probe.py"), "--reps", "60", "--sets", "default", "tile_cells=32",
                             "tile_cells=64", "--tag", "e"], capture_output=True, text=True, timeout=300)
         assert e.returncode == 0, e.stdout[-2000:] + e.stderr[-2000:]
+        # ... and the full batch (7 pairs: 128-cell tiles, the 128 x 192 / warp-specialised ring tiles)
+        e7 = subprocess.run([py, str(REPO / "tools" / "race_probe.py"), "--reps", "25", "--pairs", "7", "--sets", "default", "--tag", "e"],
+                            capture_output=True, text=True, timeout=300)
+        assert e7.returncode == 0, e7.stdout[-2000:] + e7.stderr[-2000:]
     finally:
         outs = []
         for p in loads:
@@ -47,3 +51,5 @@ def test_kernels_and_refinement_are_deterministic_under_contention():
     runs = re.findall(r"^e (\S+)\s+pairs=1 distinct results (\d+) .* distinct encodings (\d+)", e.stdout, re.M)
     assert len(runs) == 3, e.stdout
     assert all(int(a) == 1 and int(b) == 1 for _, a, b in runs), runs
+    runs7 = re.findall(r"^e (\S+)\s+pairs=7 distinct results (\d+) .* distinct encodings (\d+)", e7.stdout, re.M)
+    assert len(runs7) == 1 and all(int(a) == 1 and int(b) == 1 for _, a, b in runs7), e7.stdout

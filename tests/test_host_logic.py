@@ -389,3 +389,19 @@ def test_point_tracking_adapter():
     q = np.array([[3.0, 4.0], [10.0, 12.0]], np.float32)
     coords, o = convert_to_point_tracking(r, q)
     assert np.allclose(coords, q + [2.0, -1.0]) and np.allclose(o, [0.0, 1.0])
+
+
+def test_every_raw_s_barrier_is_preceded_by_an_lds_wait():
+    """gfx950 has back-off barriers: the compiler inserts no s_waitcnt in front of s_barrier and __builtin_amdgcn_s_barrier() is no
+    fence, so a hand-written barrier must wait for its wave's LDS operations itself (round 5: the race behind
+    tests/test_gpu_contention.py).  Source-level guard: every raw s_barrier in csrc/ has `s_waitcnt lgkmcnt(0)` just in front."""
+    import re
+    bad = []
+    for path in sorted((REPO / "mft_amd" / "csrc").glob("*.h*")):
+        lines = path.read_text().splitlines()
+        for i, line in enumerate(lines):
+            if "__builtin_amdgcn_s_barrier()" in line and not line.lstrip().startswith("//"):
+                before = "\n".join(lines[max(0, i - 3): i])
+                if not re.search(r's_waitcnt lgkmcnt\(0\)', before):
+                    bad.append(f"{path.name}:{i + 1}")
+    assert not bad, bad
