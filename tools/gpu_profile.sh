@@ -73,5 +73,16 @@ for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_E
   timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/prof/lf_$n -o lf -- python tools/bench_lookup_fused.py > /dev/null 2>&1
 done
 python tools/pmc_kernel_table.py $OUT/prof lookup_convc1 > $OUT/pmc_lookup_fused_raw.txt 2>&1
+# ... and where the pyramid is HBM-resident: 7 pairs of 1080p (136 x 240 cells)
+mkdir -p $OUT/prof1080
+for set in "FETCH_SIZE" "WRITE_SIZE" "TA_BUSY_avr TA_TA_BUSY_sum TA_BUFFER_LOAD_WAVEFRONTS_sum TA_BUFFER_WAVEFRONTS_sum" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_VALU_MFMA_BUSY_CYCLES"; do
+  n=$(echo $set | md5sum | cut -c1-6)
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/prof1080/lf_$n -o lf -- python tools/bench_lookup_fused.py 7 136 240 > /dev/null 2>&1
+done
+python tools/pmc_kernel_table.py $OUT/prof1080 lookup_convc1 > $OUT/pmc_lookup_fused_1080p_raw.txt 2>&1
+rm -rf $OUT/prof1080/*/*/
+# determinism under contention (round 5): three concurrent processes, every engine option set; kernels under two load generators
+(for i in 0 1 2; do python tools/race_probe.py --reps 100 --tag p$i > $OUT/race_probe_$i.txt 2>&1 & done; wait; cat $OUT/race_probe_?.txt | grep distinct; rm -f $OUT/race_probe_?.txt
+ for i in 1 2; do python tools/race_kernels.py --load-seconds 35 --tag load$i > $OUT/race_load_$i.txt 2>&1 & done; sleep 8; python tools/race_kernels.py --reps 2000 --tag under-load 2>&1 | grep distinct; wait; cat $OUT/race_load_?.txt | grep "load:"; rm -f $OUT/race_load_?.txt) > $OUT/race_contention.txt 2>&1
 rm -rf $OUT/prof/*/*/   # the per-host raw directories (large)
 du -sh $OUT
