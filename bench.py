@@ -417,12 +417,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # (tests only: MFT_DIST_ONE_GPU=1 puts every rank on cuda:0 and MFT_DIST_BACKEND=gloo carries the collectives on device tensors --
+    # RCCL refuses two ranks on one device -- so that the N > 1 code path of this file runs as real processes on a one-GPU box;
+    # the rates of such a run mean nothing)
+    one_gpu = os.environ.get("MFT_DIST_ONE_GPU") == "1"
+    backend = os.environ.get("MFT_DIST_BACKEND", "nccl")
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.force_sharded
     if sharded:
         if "MASTER_ADDR" not in os.environ:          # --force-sharded started without a launcher
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     # default window = one frame per rank: 7 units per rank and window (one full batch), one frame to encode per rank
     # and window, and short windows pipeline well inside a 20-step timed region (emulated 8 ranks, --steps 20
     # --warmup 5: 671 frames/s with windows of 8 frames, 630 with 16, 610 with 24)
@@ -532,7 +542,8 @@ def main():
                        f"(frame, delta) units of a {window}-frame look-ahead window sharded x{world}, "
                        f"feature + FlowOU all-gather over RCCL, replicated chain/select",
                        "frames_resident_in_hbm": True, "preroll_frames": preroll,
-                       "first_timed_frame": first},
+                       "first_timed_frame": first,
+                       **({"test_only": f"{world} ranks share ONE GPU over {backend}: code-path test, the rate means nothing"} if one_gpu and world > 1 else {})},
             "emulated_world": (args.emulate_world or None),
             **({"invalid_ab": "encoders skipped (--ab-skip-encoders): an upper bound, not a measurement"} if args.ab_skip_encoders else {}),
             "ranks_seen": ranks_seen,          # sum over ranks of 1, by all-reduce (1 without a process group)

@@ -199,3 +199,22 @@ def test_c3_runner_cont_and_flow_export(tmp_path):
     n = len(tracker.flower._frames)
     again = tapvid.run_dataset(dconf, [conf], tmp_path / "e", tmp_path / "c", mode="first", cont=True, tracker=tracker)
     assert again[0]["skipped"] and len(tracker.flower._frames) == n
+
+
+def test_run_MFT_tapvid_command_line(tmp_path):
+    """tools/run_MFT_tapvid.py with the reference's arguments on a synthetic TAP-Vid-shaped pickle: dataset config with the
+    '256x256_512x512' scaling -> tracklet pickles -> evaluation, one JSON summary."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, str(REPO / "tools" / "run_MFT_tapvid.py"), str(REPO / "dataset_configs" / "pkl-tapvid-davis-256x256_512x512.py"),
+                          str(REPO / "configs" / "MFT_cfg.py"), "--synthetic", "1", "--synthetic-frames", "8", "--export", str(tmp_path / "e"),
+                          "--cache", str(tmp_path / "c"), "--mode", "both"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["scaling"] == "256x256_512x512" and d["results"] == 2 and d["skipped"] == 0
+    assert sorted(d["metrics"]) == ["first", "strided"]
+    m = d["metrics"]["strided"]["MFT_cfg"]
+    assert 0.0 <= m["average_jaccard"] <= 1.0 and 0.0 <= m["occlusion_accuracy"] <= 1.0
+    assert (tmp_path / "e" / "MFT_cfg" / "results" / "synth-00-first.pklz").exists()
+    assert (tmp_path / "e" / "MFT_cfg" / "eval" / "tapvid-eval.pklz").exists()

@@ -97,3 +97,25 @@ def test_bench_sharded_line_carries_roofline_and_ranks_seen():
     assert r["bound"] == "mfma" and 0.05 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert "lookup_convc1_fused" in d["kernels"] and "conv_gemm" in d["kernels"]
     assert d["pairs_per_frame"]["timed_min"] == 7
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_real_ranks_on_one_gpu():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), both ranks on the one GPU of the
+    test box over gloo: the N > 1 path of the bench -- barrier + synchronize fences, MAX over ranks of the timed region, window
+    sharding with prefetch and deferred windows, the rank-0 profile pass beside waiting peers, ONE JSON line from rank 0 -- runs with
+    two real processes.  The rate of two ranks time-slicing one GPU means nothing and the line says so."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(MFT_DIST_BACKEND="gloo", MFT_DIST_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29655", str(REPO / "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=850)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                    # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 6 and d["warmup"] == 2
+    assert d["scaling"] == "strong" and d["pairs_per_frame"]["timed_min"] == 7 and d["value"] > 0
+    assert "x2" in d["config"]["parallelism"] and "test_only" in d["config"]
+    assert d["roofline"]["bound"] == "mfma" and "conv_gemm" in d["kernels"]
