@@ -108,6 +108,25 @@ __device__ __forceinline__ void tc_split8(const tc_f32x4 &u, const tc_f32x4 &v, 
     lo = tc_u32x4{l0, l1, l2, l3};
 }
 
+// ... and of 4 consecutive values (the same operations per value: the same bits)
+__device__ __forceinline__ void tc_split4(const tc_f32x4 &u, float k2048, unsigned (&hi)[2], unsigned (&lo)[2]) {
+    unsigned h0, h1, l0, l1;
+    float r0, r1, r2, r3;
+    asm("v_cvt_pk_f16_f32 %0, %8, %9\n\t"
+        "v_cvt_pk_f16_f32 %1, %10, %11\n\t"
+        "v_fma_mix_f32 %4, %0, -1.0, %8 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %5, %0, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %6, %1, -1.0, %10 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %7, %1, -1.0, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %2, %4, %12, 0\n\t"
+        "v_fma_mixlo_f16 %3, %6, %12, 0\n\t"
+        "v_fma_mixhi_f16 %2, %5, %12, 0\n\t"
+        "v_fma_mixhi_f16 %3, %7, %12, 0"
+        : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "s"(k2048));
+    hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
+}
+
 // the gate algebra, as conv_gemm.hip spells it (same functions: the two kernels agree to fp32 rounding of the K sum)
 __device__ __forceinline__ float tc_sigmoid(float s) { return __frcp_rn(1.f + __expf(-s)); }
 __device__ __forceinline__ float tc_tanh(float s) {
@@ -464,7 +483,7 @@ __global__ __launch_bounds__(512, 2) void gru_half_kernel(GruHalfArgs p) {
     const int olo = n_along > 1 ? t_along * p.step : 0, ohi = n_along > 1 ? min(len_along, olo + p.step) : len_along;
     const int x0 = HORIZ ? r0 : tx_ * TW, y0 = HORIZ ? ty_ * TH : r0;
     const long long img_base = (long long)img * p.h * p.w;
-    const uint4 *__restrict__ w1 = reinterpret_cast<const uint4 *>(p.wzr) + (long long)(wv * G1::STEPS) * 128 + lane;
+    const uint4 *__restrict__ w1 = reinterpret_cast<const uint4 *>(p.wzr) + (long long)((wv ^ 4) * G1::STEPS) * 128 + lane;   // (r for waves 0-3: see below)
     const int nt2 = wv % G2::NT, ks2 = wv / G2::NT;
     const uint4 *__restrict__ w2 = reinterpret_cast<const uint4 *>(p.wq) + (long long)((nt2 * G2::KS + ks2) * G2::STEPS) * 128 + lane;
 
@@ -532,20 +551,11 @@ __global__ __launch_bounds__(512, 2) void gru_half_kernel(GruHalfArgs p) {
     auto slot = [&](int m) { return lds + ((m / TW + KH / 2) * HWD + (m % TW + KW / 2)) * CELLB; };
     const float inv2048 = 1.f / 2048.f;
     const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));
-    // four waves' sums (channels 32 c .. 32 c + 31 of 128, all R cells) -> the R cells' h slots, fp32 [cell][128]
-    auto park128 = [&](int c) {
-#pragma unroll
-        for (int i = 0; i < RT; ++i)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                tc_f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * b + e] + accx[i][4 * b + e] * inv2048;
-                *reinterpret_cast<tc_f32x4 *>(slot(32 * i + (lane & 31)) + (32 * c + 8 * b + 4 * (lane >> 5)) * 4) = v;
-            }
-    };
 
-    // ---- z | r gates
+    // ---- z | r gates.  The r waves are the OLDER wave of every SIMD (column tile wv ^ 4: waves 0-3 take r, waves 4-7 take z): the
+    // matrix pipe serves the older wave first, so it leaves this K loop ~27 k cycles before its partner (tools/gru_trace.py) -- and r is
+    // the gate with work on the critical path behind it.
+    const int nt1 = wv ^ 4;
     zero_acc();
     set_abase(0);
     tc_kloop<G1, KW>(abase, w1, bq, acc, accx);
@@ -553,24 +563,26 @@ __global__ __launch_bounds__(512, 2) void gru_half_kernel(GruHalfArgs p) {
     // (the candidate's first weight fragments: in flight during the gate algebra)
 #pragma unroll
     for (int s = 0; s < PF; ++s) { bq[s][0] = w2[s * 128]; bq[s][1] = w2[s * 128 + 64]; }
-    // z = sigmoid(. + context part), by the z waves themselves, straight from their accumulators (a lane: 4 x 4 consecutive channels of
-    // one cell per row tile -> 16-byte pieces), -> global (this workgroup reads it back for the blend).  The older wave of every SIMD --
-    // these four -- leaves the gates' K loop ~27 k cycles before its partner (the matrix pipe serves it first; tools/gru_trace.py): the
-    // z pass costs nothing here, and its memory traffic falls into a time when the chip's memory system has nothing else to do.  (As a
-    // row-wise pass behind a barrier -- parked sums, all 512 threads -- it was 9 k of the launch's 148 k cycles, every workgroup's at
-    // the same moment.)  Same arithmetic per value as the row-wise form: the same bits.
+    // r * h by the r waves themselves, straight from their accumulators (a lane: 4 x 4 consecutive channels of one cell per row tile),
+    // in the shadow of their SIMD partners' K loop: sigmoid(. + context part) * h, split, KEPT IN REGISTERS (the accumulators are dead) --
+    // the h parts of the tile are still being read.  Same arithmetic per value as the row-wise pass over parked sums this replaces
+    // (8.5 k exposed cycles of the launch's 144 k between two barriers): the same bits.
+    unsigned rh_hi[RT][4][2], rh_lo[RT][4][2];
     if (wv < 4) {
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             const int m = 32 * i + (lane & 31);
-            const int yy = y0 + m / TW, xx = x0 + m % TW, along = HORIZ ? xx : yy;
-            const bool own = yy >= 0 && yy < p.h && xx >= 0 && xx < p.w && along >= olo && along < ohi;
+            const int yy = y0 + m / TW, xx = x0 + m % TW;
+            const bool inside = yy >= 0 && yy < p.h && xx >= 0 && xx < p.w;
             const int yc = yy < 0 ? 0 : (yy >= p.h ? p.h - 1 : yy), xc = xx < 0 ? 0 : (xx >= p.w ? p.w - 1 : xx);
             const long long cell = img_base + (long long)yc * p.w + xc;
             const int n0 = 32 * wv + 4 * (lane >> 5);
-            tc_f32x4 a[4];
+            tc_f32x4 a[4], hh[4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) a[b] = *reinterpret_cast<const tc_f32x4 *>(p.pre_zr + cell * 256 + n0 + 8 * b);
+            for (int b = 0; b < 4; ++b) {
+                a[b] = *reinterpret_cast<const tc_f32x4 *>(p.pre_zr + cell * 256 + 128 + n0 + 8 * b);
+                hh[b] = *reinterpret_cast<const tc_f32x4 *>(p.hf_in + cell * 128 + n0 + 8 * b);
+            }
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 tc_f32x4 v;
@@ -579,44 +591,55 @@ __global__ __launch_bounds__(512, 2) void gru_half_kernel(GruHalfArgs p) {
                 v += a[b];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = tc_sigmoid(v[e]);
+                v *= hh[b];
+                tc_split4(v, k2048, rh_hi[i][b], rh_lo[i][b]);
+                if (!inside) { rh_hi[i][b][0] = rh_hi[i][b][1] = rh_lo[i][b][0] = rh_lo[i][b][1] = 0u; }     // (the candidate's zero padding)
+            }
+        }
+    }
+    TC_T(5);
+    tc_barrier();           // every wave is done with the h parts of the tile
+    // r * h, in place: a cell's 8-channel group is [hi x 8 | lo x 8]; this lane holds channels 4 (lane >> 5) .. + 3 of group 4 wv + b
+    if (wv < 4) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            unsigned char *dst = slot(32 * i + (lane & 31)) + (4 * wv) * 32 + (lane >> 5) * 8;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                *reinterpret_cast<uint2 *>(dst + 32 * b) = make_uint2(rh_hi[i][b][0], rh_hi[i][b][1]);
+                *reinterpret_cast<uint2 *>(dst + 32 * b + 16) = make_uint2(rh_lo[i][b][0], rh_lo[i][b][1]);
+            }
+        }
+    }
+    tc_barrier();
+    TC_T(6);
+    // The z waves' sums (acc + accx / 2048, before the context part and the sigmoid) -> global, straight from the accumulators, while
+    // their SIMD partners -- older, served first anyway -- are already in the candidate's K loop; stores only: the context part and the
+    // sigmoid wait for the blend, whose row-wise pass reads z back anyway (same arithmetic per value: the same bits).
+    if (wv >= 4) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int m = 32 * i + (lane & 31);
+            const int yy = y0 + m / TW, xx = x0 + m % TW, along = HORIZ ? xx : yy;
+            const bool own = yy >= 0 && yy < p.h && xx >= 0 && xx < p.w && along >= olo && along < ohi;
+            const long long cell = img_base + (long long)yy * p.w + xx;
+            const int n0 = 32 * nt1 + 4 * (lane >> 5);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                tc_f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * b + e] + accx[i][4 * b + e] * inv2048;
                 if (own) *reinterpret_cast<tc_f32x4 *>(p.z + cell * 128 + n0 + 8 * b) = v;
             }
         }
     }
-    tc_barrier();           // every wave is done with the h parts of the tile
-    if (wv >= 4) park128(wv - 4);
-    tc_barrier();
-    // r * h, in place: the sums of 8 channels become their split form (zero outside the image: the candidate's zero padding)
-#pragma unroll
-    for (int it = 0; it < RT; ++it) {
-        const int item = tid + 512 * it, m = item >> 4, n0 = (item & 15) * 8;
-        const int yy = y0 + m / TW, xx = x0 + m % TW;
-        float *src = reinterpret_cast<float *>(slot(m)) + n0;
-        tc_f32x4 u = *reinterpret_cast<const tc_f32x4 *>(src), v = *reinterpret_cast<const tc_f32x4 *>(src + 4);
-        tc_u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
-        if (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w) {
-            const long long cell = img_base + (long long)yy * p.w + xx;
-            u += *reinterpret_cast<const tc_f32x4 *>(p.pre_zr + cell * 256 + 128 + n0);
-            v += *reinterpret_cast<const tc_f32x4 *>(p.pre_zr + cell * 256 + 128 + n0 + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { u[e] = tc_sigmoid(u[e]); v[e] = tc_sigmoid(v[e]); }
-            u *= *reinterpret_cast<const tc_f32x4 *>(p.hf_in + cell * 128 + n0);
-            v *= *reinterpret_cast<const tc_f32x4 *>(p.hf_in + cell * 128 + n0 + 4);
-            tc_split8(u, v, k2048, hi, lo);
-        }
-        *reinterpret_cast<tc_u32x4 *>(src) = hi;
-        *reinterpret_cast<tc_u32x4 *>(src + 4) = lo;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (this wave's z stores have reached L2 before anyone reads z back)
-    TC_T(5);
-    tc_barrier();
-    TC_T(6);
 
     // ---- the candidate over [r * h | motion]
     zero_acc();
     set_abase(ks2);
     tc_kloop<G2, KW>(abase, w2, bq, acc, accx);
     TC_T(7);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (this wave's z stores have reached L2 before anyone reads z back)
     tc_barrier();           // every wave is done with the tile: its space takes the sums
     float *red = reinterpret_cast<float *>(lds);
 #pragma unroll
@@ -642,7 +665,11 @@ __global__ __launch_bounds__(512, 2) void gru_half_kernel(GruHalfArgs p) {
         const long long cell = img_base + (long long)yy * p.w + xx;
         u += *reinterpret_cast<const tc_f32x4 *>(p.pre_q + cell * 128 + n0);
         v += *reinterpret_cast<const tc_f32x4 *>(p.pre_q + cell * 128 + n0 + 4);
-        const tc_f32x4 z0 = *reinterpret_cast<const tc_f32x4 *>(p.z + cell * 128 + n0), z1 = *reinterpret_cast<const tc_f32x4 *>(p.z + cell * 128 + n0 + 4);
+        tc_f32x4 z0 = *reinterpret_cast<const tc_f32x4 *>(p.z + cell * 128 + n0), z1 = *reinterpret_cast<const tc_f32x4 *>(p.z + cell * 128 + n0 + 4);
+        z0 += *reinterpret_cast<const tc_f32x4 *>(p.pre_zr + cell * 256 + n0);
+        z1 += *reinterpret_cast<const tc_f32x4 *>(p.pre_zr + cell * 256 + n0 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { z0[e] = tc_sigmoid(z0[e]); z1[e] = tc_sigmoid(z1[e]); }
         const float *hrow = p.hf_in + cell * 128 + n0;
         const tc_f32x4 h0 = *reinterpret_cast<const tc_f32x4 *>(hrow), h1 = *reinterpret_cast<const tc_f32x4 *>(hrow + 4);
 #pragma unroll

@@ -402,7 +402,8 @@ def tile_conv2d(x: torch.Tensor, wtile: torch.Tensor, bias, P, h, w, N, kh, kw, 
 def gru_half(h_split, motion_split, wzr_tile, wq_tile, pre_zr, pre_q, hf, P, h, w, vertical=False):
     """One SepConvGRU pass as one kernel (``mftx_gru_half``): h_split / motion_split [M, 128] in split form, the gates' weights
     as ``pack_tile_conv_weights`` streams (cin = 256), pre_zr [M, 256] / pre_q [M, 128] the pre-activation addends, hf [M, 128]
-    the fp32 h -> (new h in fp32 [M, 128], new h in split form [M, 128], z [M, 128])."""
+    the fp32 h -> (new h in fp32 [M, 128], new h in split form [M, 128], the kernel's scratch [M, 128]: the z gate's
+    sums before the context part and the sigmoid)."""
     M = P * h * w
     z = torch.empty(M, 128, dtype=torch.float32, device=hf.device)
     h_out = torch.empty(M, 128, dtype=torch.float32, device=hf.device)

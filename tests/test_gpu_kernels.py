@@ -1155,7 +1155,7 @@ def test_engine_tile_cells_bitwise(P, h, w):
 
 @pytest.mark.parametrize("P,h,w,vertical", [(1, 16, 24, False), (1, 16, 24, True), (2, 9, 150, False), (1, 150, 7, True), (1, 64, 64, False)])
 def test_gru_half_vs_fp64(ops_mod, P, h, w, vertical):
-    """mftx_gru_half against the gate algebra of core/update.py:108-123 in fp64: z, the new h (fp32 copy and split form)."""
+    """mftx_gru_half against the gate algebra of core/update.py:108-123 in fp64: the z gate (from the scratch buffer), the new h (fp32 copy and split form)."""
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(5 + h + w)
     M = P * h * w
@@ -1178,7 +1178,8 @@ def test_gru_half_vs_fp64(ops_mod, P, h, w, vertical):
     zz, rr = zr[:, :128], zr[:, 128:]
     q = torch.tanh(F.conv2d(torch.cat([rr * hd, md], 1), wq.double(), padding=pad) + to_map(pre_q))
     want = (1 - zz) * hd + zz * q
-    assert (z.cpu().double() - to_rows(zz)).abs().max() < 2e-6
+    # (z is the kernel's scratch: the z gate's sums BEFORE the context part and the sigmoid -- the blend applies both)
+    assert (torch.sigmoid(z.cpu().double() + pre_zr[:, :128].double()) - to_rows(zz)).abs().max() < 2e-6
     assert (hf_new.cpu().double() - to_rows(want)).abs().max() < 5e-6
     assert torch.equal(hf_dev.cpu(), hf)                                        # the input state is left alone
     assert torch.equal(ops_mod.unsplit_activations(h_out), ops_mod.unsplit_activations(ops_mod.split_activations(hf_new)))
