@@ -98,6 +98,8 @@ def build_tracker(args, sharded):
     conf.flow_config.synthetic_weights_seed = 0     # seeded synthetic weights
     conf.flow_config.flow_iters = args.iters
     conf.flow_config.async_encode = not args.sync_encode
+    if getattr(args, "frames_in_flight", None):
+        conf.flow_config.frames_in_flight = int(args.frames_in_flight)   # A/B: overrides the plugin's default (mft_amd/raft.py)
     if getattr(args, "alternate_corr", False):
         conf.flow_config.raft_params.alternate_corr = True
     conf.flow_config.raft_params.arith = getattr(args, "arith", "split")
@@ -128,8 +130,10 @@ def profile_pass(tracker, frames, first, steps, arith="split"):
     lib = _lib.load()
     enc_stream = getattr(tracker.flower, "_enc_stream", None)
     split = getattr(tracker.flower, "_split_streams", 1)
+    fif = getattr(tracker.flower, "_fif", 1)
     tracker.flower._enc_stream = None
     tracker.flower._split_streams = 1          # (and the batch as one part on one stream, for the same reason)
+    tracker.flower._fif = 1                    # (and one frame in flight: the timed region overlaps two frames' kernel chains on two streams)
     torch.cuda.synchronize()
     lib.mftx_profile_begin()
     pairs = []
@@ -138,6 +142,7 @@ def profile_pass(tracker, frames, first, steps, arith="split"):
         pairs.append(len(tracker.last_pairs))
     tracker.flower._enc_stream = enc_stream
     tracker.flower._split_streams = split
+    tracker.flower._fif = fif
     n = len(CATS)
     ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
     _lib.check(lib.mftx_profile_end(ms, work, cnt, n), "mftx_profile_end")
@@ -389,6 +394,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size EPE check against the CPU oracle")
     ap.add_argument("--no-host-io", action="store_true")
     ap.add_argument("--sync-encode", action="store_true", help="encode frames on the main stream")
+    ap.add_argument("--frames-in-flight", type=int, default=None,
+                    help="A/B: flow_config.frames_in_flight (consecutive frames' flow batches on that many engines / HIP streams)")
     ap.add_argument("--alternate-corr", action="store_true",
                     help="on-demand correlation (raft_params.alternate_corr): no stored volume, for memory-bound sizes")
     ap.add_argument("--arith", choices=("split", "fp32"), default="split",
@@ -570,6 +577,16 @@ def main():
             serial = sum(v["total_ms_per_step"] for k, v in kernels.items() if k != "conv_gemm_all")
             result["kernels_serial_ms_per_step"] = serial
             result["overlap_ms_per_step"] = serial - result["ms_per_step"]
+            fif = int(getattr(tracker.flower, "_fif", 1))
+            result["frames_in_flight"] = fif
+            result["overlap_note"] = ("timed region: the flow batches of consecutive frames alternate between %d engines on %d HIP streams "
+                                      "(flow_config.frames_in_flight: frame t + 1 needs frame t's features only, chaining / selection "
+                                      "wait on an event) and the encoders run on a side stream; the per-kernel times above are "
+                                      "bracketed with every kernel ALONE on the chip" % (fif, fif))
+            # the step's executed matrix work over the WHOLE step time (non-GEMM kernels included): what the overlap buys shows here,
+            # not in `frac` (a kernel timed alone)
+            result["roofline"]["step_frac"] = dom["achieved"] * dom["total_ms_per_step"] / result["ms_per_step"] / dom["peak"]
+            result["roofline"]["step_frac_note"] = "executed conv-GEMM flops of a step / ms_per_step / peak: the family's share of the peak over the whole frame time"
             lk = kernels.get("lookup_convc1_fused") or kernels.get("corr_lookup")
             if lk:
                 result["roofline"]["north_star_lookup"] = {

@@ -37,10 +37,11 @@ def pad_amounts(H0, W0):
 
 
 class FrameFeatures:
-    __slots__ = ("fmap", "net", "inp", "h", "w", "pads", "shape")
+    __slots__ = ("fmap", "net", "inp", "h", "w", "pads", "shape", "ready")
 
-    def __init__(self, fmap, net, inp, h, w, pads, shape):
+    def __init__(self, fmap, net, inp, h, w, pads, shape, ready=None):
         self.fmap, self.net, self.inp, self.h, self.w, self.pads, self.shape = fmap, net, inp, h, w, pads, shape
+        self.ready = ready          # event behind the kernels that wrote the maps (None: ordered by the caller's stream)
 
 
 class RAFTWrapper:
@@ -87,6 +88,19 @@ class RAFTWrapper:
         self._split_streams = int(os.environ.get("MFTX_SPLIT_STREAMS", "") or getattr(config, "split_streams", 0) or
                                   (1 if self._arith == ops.ARITH_SPLIT else 2))
         self._engines, self._side = [], []            # part k: engine (own workspace) and stream (None = caller's)
+        # C.frames_in_flight (env MFTX_FRAMES_IN_FLIGHT overrides; default 1): consecutive compute_pairs calls -- the tracker's
+        # frames -- alternate between that many LANES, each an engine with its own workspace on its own HIP stream.  The flow
+        # batch of frame t + 1 depends on frame t's FEATURES only (chaining and selection, which need frame t's result, stay on
+        # the caller's stream behind an event), so with the host ahead of the GPU two frames' kernel chains are in flight at
+        # once and the hardware interleaves their workgroups: a 224-workgroup GEMM kernel of one frame leaves 32 CUs and its
+        # load / epilogue phases to the other frame's kernels, and a frame's store-bound volume kernel, OU heads and upsampling
+        # run beside the other frame's matrix work instead of alone.  Same kernels, same batches: the same bits.
+        # Measured (512 x 512, 7 pairs, one MI355X, same box): 1 / 2 / 3 lanes = 162.4 / 178.0 / 165.2 frames/s.  Default: 2 with the
+        # split arithmetic (the fp32 path batches through _refine_split instead), 1 otherwise.
+        self._fif = max(1, int(os.environ.get("MFTX_FRAMES_IN_FLIGHT", "") or getattr(config, "frames_in_flight", 0) or
+                               (2 if self._arith == ops.ARITH_SPLIT else 1)))
+        self._lanes, self._lane_next = [], 0          # [(engine, stream)]
+        self._lanes_stale = False
         # Which GEMM kernels a refinement runs on (tile-resident or ring-buffered: they differ by fp32 rounding of the K sums) must
         # not depend on the batch a pair happens to ride in -- a tracker's ramp-up frames, a remainder window or one rank's share
         # of a sharded job would then give other bits than the full batch.  The choice is made ONCE per image size, for the
@@ -121,19 +135,33 @@ class RAFTWrapper:
         v = self._tile_choice.get((h, w))
         if v is None:
             v = self._tile_choice[(h, w)] = 2 if ops._lib.load().mftx_tile_conv_fills_chip(self.nominal_pairs, h, w) else 0
-        for e in dict.fromkeys([self.engine] + list(self._engines)):
+        for e in self._all_engines():
             if getattr(e, "_tile_conv", None) != v:
                 e.set_option("tile_conv", v)
 
+    def _all_engines(self):
+        return list(dict.fromkeys([self.engine] + list(self._engines) + [e for e, _ in self._lanes]))
+
+    def _lane(self):
+        """The next lane (engine, stream) of C.frames_in_flight; lane 0 is the plugin's first engine."""
+        while len(self._lanes) < self._fif:
+            eng = self.engine if not self._lanes else ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand,
+                                                                      arith=self._arith, options=self._engine_options)
+            self._lanes.append((eng, torch.cuda.Stream(device=self.device)))
+            self._lanes_stale = True              # (a new engine packs its weights on the caller's stream: the lanes wait for that)
+        lane = self._lanes[self._lane_next % self._fif]
+        self._lane_next += 1
+        return lane
+
     def nonfinite_count(self, reset=False):
         """Non-finite output pixels counted on the device since the last reset, over all engines of this plugin."""
-        return sum(e.nonfinite_count(reset=reset) for e in dict.fromkeys([self.engine] + list(self._engines)))
+        return sum(e.nonfinite_count(reset=reset) for e in self._all_engines())
 
     def nonfinite_snapshot(self, host_words):
         """Asynchronous read of the counters (no host wait): enqueues, on the current stream, copies of every engine's counter into
         ``host_words`` -- pinned int32 [n, 4] with n >= the number of engines; the caller sums column 0 after waiting for an
         event recorded behind this call (mft_amd.video.ResultDrain does)."""
-        for i, e in enumerate(dict.fromkeys([self.engine] + list(self._engines))):
+        for i, e in enumerate(self._all_engines()):
             e.nonfinite_snapshot(host_words[i])
 
     def nonfinite_error(self, bad):
@@ -299,10 +327,14 @@ class RAFTWrapper:
 
     def _encode(self, img):
         if self._enc_stream is None:
-            return self.encode(img)
+            f = self.encode(img)
+            if self._fif > 1:
+                f.ready = torch.cuda.current_stream().record_event()
+            return f
         main = torch.cuda.current_stream()
         with torch.cuda.stream(self._enc_stream):
             f = self.encode(img)
+            f.ready = self._enc_stream.record_event()
         main.wait_stream(self._enc_stream)
         for t in (f.fmap, f.net, f.inp):          # allocated on the side stream, consumed on `main`
             if t is not None:
@@ -349,11 +381,18 @@ class RAFTWrapper:
             flow_init = self._init_flow_lr(init_flow, ref)
         packed = None
         H0, W0 = ref.shape
+        want_planar = planar or packed_out is None or packed_out is False
+        if (self._fif > 1 and gather and flow_init is None and not self._check_finite
+                and (packed_out is None or isinstance(packed_out, bool))):
+            return self._refine_on_lane(fls, frs, fmap1, fmap2, net, inp, ref, iters, bool(packed_out), want_planar)
         if packed_out is not None and packed_out is not False:
             packed = packed_out if isinstance(packed_out, torch.Tensor) else \
                 torch.empty(P, H0, W0, 4, dtype=torch.float32, device=self.device)
-        want_planar = planar or packed is None
         self._pin_kernels(ref.h, ref.w)
+        if self._lanes:                               # (lane 0 shares this engine's workspace: in-flight lane work finishes first)
+            for _, s_ in self._lanes:
+                torch.cuda.current_stream(self.device).wait_stream(s_)
+            self._lanes_stale = True
         if self._split_streams > 1 and P >= 6 and flow_init is None:
             flow, occl, sigma = self._refine_split(fmap1, fmap2, net, inp, ref, iters, packed, want_planar)
         else:
@@ -366,6 +405,43 @@ class RAFTWrapper:
                     f"compute_flow: {bad} non-finite output values" + (
                         " -- an activation left the fp16 range of the split arithmetic (|x| >= 65504); "
                         "set raft_params.arith = 'fp32'" if self._arith == ops.ARITH_SPLIT else ""))
+        if packed is not None and flow is None:
+            return [(None, None, None, packed[i]) for i in range(P)]
+        if packed is not None:
+            return [(flow[i], occl[i], sigma[i], packed[i]) for i in range(P)]
+        return [(flow[i], occl[i], sigma[i]) for i in range(P)]
+
+    def _refine_on_lane(self, fls, frs, fmap1, fmap2, net, inp, geom, iters, want_packed, planar):
+        """One batch on the next lane of C.frames_in_flight (see __init__): the lane's stream waits for the frames' features
+        only, the caller's stream for the lane -- whatever else is queued on the caller's stream (the previous frame's chaining
+        and selection, result copies) does not hold the batch back."""
+        eng, st = self._lane()
+        main = torch.cuda.current_stream(self.device)
+        P = len(fls)
+        H0, W0 = geom.shape
+        self._pin_kernels(geom.h, geom.w)
+        if self._lanes_stale:                         # an engine ran on the caller's stream since the lanes last did: order them behind it
+            for _, s_ in self._lanes:
+                s_.wait_stream(main)
+            self._lanes_stale = False
+        for f in dict.fromkeys(fls + frs):
+            if f.ready is not None:
+                st.wait_event(f.ready)
+            else:
+                st.wait_stream(main)                  # features without an event: ordered by the caller's stream
+            for t in (f.fmap, f.net, f.inp):
+                if t is not None:
+                    t.record_stream(st)
+        with torch.cuda.stream(st):
+            # (outputs come from the LANE's pool: a block the caller's stream freed a moment ago may still be read there)
+            packed = torch.empty(P, H0, W0, 4, dtype=torch.float32, device=self.device) if want_packed else None
+            flow, occl, sigma = eng.refine(fmap1, fmap2, net, inp, geom.h, geom.w, iters, pads=geom.pads,
+                                           flow_init=None, packed=packed, planar=planar)
+            done = st.record_event()
+        main.wait_event(done)
+        for t in (packed, flow, occl, sigma):
+            if t is not None:
+                t.record_stream(main)
         if packed is not None and flow is None:
             return [(None, None, None, packed[i]) for i in range(P)]
         if packed is not None:
@@ -443,6 +519,10 @@ class RAFTWrapper:
             fl, fr = self._features(None, src_img), self._features(None, dst_img)
             flow_init = self._init_flow_lr(init_flow, fl) if init_flow is not None else None
             self._pin_kernels(fl.h, fl.w)
+            if self._lanes:
+                for _, s_ in self._lanes:
+                    torch.cuda.current_stream(self.device).wait_stream(s_)
+                self._lanes_stale = True
             (flow, occl, sigma), debug = self.engine.debug_refine(fl.fmap[None], fr.fmap[None], fl.net[None], fl.inp[None],
                                                                    fl.h, fl.w, int(self.C.flow_iters), pads=fl.pads,
                                                                    flow_init=flow_init)

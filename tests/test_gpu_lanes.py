@@ -1,0 +1,112 @@
+"""flow_config.frames_in_flight (mft_amd/raft.py: consecutive frames' flow batches alternate between engines on their own HIP
+streams): scheduling only -- every frame's result must equal the one-lane tracker's bit for bit.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from mft_amd.synth import SyntheticVideo
+
+pytestmark = pytest.mark.gpu
+
+
+def _tracker(weights_np, lanes, iters, deltas, async_encode=True):
+    from mft_amd.config import Config
+    from mft_amd.MFT import MFT
+    from mft_amd.raft import RAFTWrapper
+    c = Config()
+    c.flow_iters = iters
+    c.async_encode = async_encode
+    c.frames_in_flight = lanes
+    fl = RAFTWrapper(c, state_dict=weights_np)
+    t = Config()
+    t.deltas = list(deltas)
+    t.occlusion_threshold = 0.02
+    t.keep_result_on_device = True
+    t.flow_config = Config()
+    t.flow_config.of_class = lambda cfg: fl
+    return MFT(t), fl
+
+
+def _run(tr, vid, n, cache=None, on_device=True):
+    first = torch.from_numpy(vid[0]).cuda() if on_device else vid[0]
+    tr.init(first, flow_cache=cache)
+    res = []
+    for i in range(1, n):
+        res.append(tr.track(torch.from_numpy(vid[i]).cuda() if on_device else vid[i]).result)   # no host sync in between: the host runs ahead
+    torch.cuda.synchronize()
+    return res
+
+
+def _same(a, b):
+    return torch.equal(a.flow, b.flow) and torch.equal(a.occlusion, b.occlusion) and torch.equal(a.sigma, b.sigma)
+
+
+@pytest.mark.parametrize("async_encode", [True, False])
+def test_lanes_bitwise_small(weights_np, async_encode):
+    """128 x 160, every batch size of the ramp (1 .. 5 pairs), 2 and 3 lanes against 1."""
+    vid = SyntheticVideo(128, 160, n_frames=14, seed=33)
+    deltas = (np.inf, 1, 2, 4, 8)
+    base = _run(_tracker(weights_np, 1, 4, deltas, async_encode)[0], vid, 14)
+    for lanes in (2, 3):
+        tr, fl = _tracker(weights_np, lanes, 4, deltas, async_encode)
+        got = _run(tr, vid, 14)
+        assert len(fl._lanes) == lanes and len({id(e) for e, _ in fl._lanes}) == lanes
+        for i, (a, b) in enumerate(zip(base, got)):
+            assert _same(a, b), (lanes, i)
+        assert fl.nonfinite_count() == 0
+
+
+@pytest.mark.timeout(600)
+def test_lanes_bitwise_512_full_batch(weights_np):
+    """512 x 512, 12 iterations, all seven deltas (the benchmark's configuration: 224-workgroup kernels of two frames interleaved on
+    the chip), host-resident frames through the upload path; and a second sequence on the same plugin (lane order continues)."""
+    vid = SyntheticVideo(512, 512, n_frames=40, seed=3)
+    deltas = (np.inf, 1, 2, 4, 8, 16, 32)
+    base = _run(_tracker(weights_np, 1, 12, deltas)[0], vid, 40)
+    tr, fl = _tracker(weights_np, 2, 12, deltas)
+    got = _run(tr, vid, 40)
+    for i, (a, b) in enumerate(zip(base, got)):
+        assert _same(a, b), i
+    again = _run(tr, vid, 9, on_device=False)
+    for i, (a, b) in enumerate(zip(base, again)):
+        assert _same(a, b), ("second sequence", i)
+
+
+def test_lanes_mixed_with_single_stream_calls(weights_np):
+    """Calls that do not ride a lane (compute_flow with an initial flow, check_finite-style synchronous use) between tracked frames
+    share lane 0's engine: they wait for the lanes and the lanes for them."""
+    vid = SyntheticVideo(128, 160, n_frames=10, seed=8)
+    deltas = (np.inf, 1, 2)
+    tr1, fl1 = _tracker(weights_np, 1, 3, deltas)
+    tr2, fl2 = _tracker(weights_np, 2, 3, deltas)
+    outs = []
+    for tr, fl in ((tr1, fl1), (tr2, fl2)):
+        tr.init(torch.from_numpy(vid[0]).cuda())
+        res = []
+        for i in range(1, 10):
+            res.append(tr.track(torch.from_numpy(vid[i]).cuda()).result)
+            if i % 3 == 0:
+                init = torch.full((2, 128, 160), 0.5, device="cuda")
+                f, extra = fl.compute_flow(vid[0], vid[i], mode="flow", init_flow=init)
+                res.append(f.clone())
+        torch.cuda.synchronize()
+        outs.append(res)
+    for a, b in zip(*outs):
+        if isinstance(a, torch.Tensor):
+            assert torch.equal(a, b)
+        else:
+            assert _same(a, b)
+
+
+def test_lanes_with_flow_cache(weights_np, tmp_path):
+    """A flow cache asks for planar outputs next to the packed ones (written on the lane, read on the caller's stream)."""
+    from mft_amd.io import FlowCache
+    vid = SyntheticVideo(128, 160, n_frames=8, seed=5)
+    deltas = (np.inf, 1, 2, 4)
+    outs = []
+    for lanes in (1, 2):
+        cache = FlowCache(tmp_path / f"c{lanes}", max_RAM_MB=64)
+        tr, _ = _tracker(weights_np, lanes, 3, deltas)
+        outs.append(_run(tr, vid, 8, cache=cache))
+    for a, b in zip(*outs):
+        assert _same(a, b)
