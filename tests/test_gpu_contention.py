@@ -53,3 +53,37 @@ def test_kernels_and_refinement_are_deterministic_under_contention():
     assert all(int(a) == 1 and int(b) == 1 for _, a, b in runs), runs
     runs7 = re.findall(r"^e (\S+)\s+pairs=7 distinct results (\d+) .* distinct encodings (\d+)", e7.stdout, re.M)
     assert len(runs7) == 1 and all(int(a) == 1 and int(b) == 1 for _, a, b in runs7), e7.stdout
+
+
+@pytest.mark.timeout(600)
+def test_chain_select_and_tracker_are_deterministic_under_contention():
+    """Round 5, second find: the chain + selection kernels gave 16 wrong pixels (lanes 48..63 of one wave, one output plane) in a
+    third of their launches whenever another PROCESS used the GPU -- with the flow batches, the encodings and every other kernel
+    deterministic; the packed-fp32 code of the SLP vectoriser (csrc/Makefile: chain.o is built without it now).  Under two load
+    generators: the four chain / select entry points on fixed inputs, and whole tracker sequences (512 x 512, seven deltas, 12
+    iterations) with one and with two frames in flight, asynchronous and host-synchronised -- one distinct result each."""
+    py = sys.executable
+    loads = [subprocess.Popen([py, str(REPO / "tools" / "race_kernels.py"), "--load-seconds", "75", "--tag", f"load{i}"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for i in range(2)]
+    try:
+        time.sleep(8)
+        c = subprocess.run([py, str(REPO / "tools" / "race_chain2.py"), "120"], capture_output=True, text=True, timeout=300)
+        assert c.returncode == 0, c.stdout[-2000:] + c.stderr[-2000:]
+        a = subprocess.run([py, str(REPO / "tools" / "race_lanes.py"), "--reps", "8", "--tag", "A"], capture_output=True, text=True, timeout=300)
+        b = subprocess.run([py, str(REPO / "tools" / "race_lanes.py"), "--reps", "6", "--sync", "--numpy", "--tag", "B"], capture_output=True,
+                           text=True, timeout=300)
+    finally:
+        outs = []
+        for p in loads:
+            try:
+                outs.append(p.communicate(timeout=120)[0])
+            except subprocess.TimeoutExpired:
+                p.kill()
+                outs.append("")
+    done = [int(m.group(1)) for o in outs for m in re.finditer(r"load: (\d+) refinements", o)]
+    assert len(done) == 2 and min(done) > 100, outs
+    kinds = re.findall(r"^(\S.*?)\s+distinct\s+(\d+) \[", c.stdout, re.M)
+    assert len(kinds) == 7 and all(int(n) == 1 for _, n in kinds), c.stdout
+    for run in (a, b):
+        assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-2000:]        # (non-zero: more than one distinct result overall)
+        assert re.search(r"overall distinct 1$", run.stdout, re.M), run.stdout[-2000:]
