@@ -146,18 +146,29 @@ class WindowSharder:
         """Wait for the exchange and install the features in the flow plugin's per-frame cache (all ranks)."""
         if h is None:
             return
-        if h["work"] is not None:
-            h["work"].wait()                          # the caller's stream now waits for the collective
+        on_gpu = h["recv"].is_cuda
+        cur = torch.cuda.current_stream(h["recv"].device) if on_gpu else None
         if h["stream"] is not None:
-            cur = torch.cuda.current_stream(h["recv"].device)
-            cur.wait_stream(h["stream"])
+            # the SIDE stream waits for the collective and marks the moment the features are complete with an event of its own:
+            # the caller's stream waits for that event -- and so can any other stream that consumes the features (the plugin's
+            # lanes, flow_config.frames_in_flight) without waiting for whatever else is queued on the caller's stream
+            with torch.cuda.stream(h["stream"]):
+                if h["work"] is not None:
+                    h["work"].wait()
+                ready = h["stream"].record_event()
+            cur.wait_event(ready)
             h["recv"].record_stream(cur)
+        else:
+            if h["work"] is not None:
+                h["work"].wait()                      # the caller's stream now waits for the collective
+            ready = cur.record_event() if on_gpu else None
         G = self.world_size
+        kw = {"ready": ready} if ready is not None else {}       # (plugins without streams: the plain interface)
         for j, fid in enumerate(h["ids"]):
             if h["halves"]:
-                tracker.flower.adopt_halves(fid, h["recv"][2 * j, 0], h["recv"][2 * j + 1, 0], h["imgs"][j])
+                tracker.flower.adopt_halves(fid, h["recv"][2 * j, 0], h["recv"][2 * j + 1, 0], h["imgs"][j], **kw)
             else:
-                tracker.flower.adopt_packed(fid, h["recv"][frame_owner(j, G), j // G], h["imgs"][j])
+                tracker.flower.adopt_packed(fid, h["recv"][frame_owner(j, G), j // G], h["imgs"][j], **kw)
 
     # ------------------------------------------------------------------ the window
     def track_window(self, tracker, imgs, next_imgs=None, defer=False):
@@ -251,7 +262,11 @@ class WindowSharder:
         n_todo = len(todo)
         n_batches = -(-n_todo // max_batch) if n_todo else 0
         bounds = [(n_todo * i) // n_batches for i in range(n_batches + 1)] if n_todo else [0]
-        contiguous = todo == list(range(cnt))       # (no cache, or nothing found: the engine writes into the send buffer itself)
+        # (no cache, or nothing found: the engine writes into the send buffer itself -- unless the plugin keeps several frames in
+        # flight (flow_config.frames_in_flight): then the batch rides a lane, on that lane's stream into that lane's memory, so that
+        # consecutive windows' batches overlap like consecutive frames of the single-GPU tracker, and its results are copied into
+        # the send buffer behind the lane's event: 4 MB per unit, microseconds against the batch's milliseconds)
+        contiguous = todo == list(range(cnt)) and int(getattr(tracker.flower, "_fif", 1)) <= 1
         for b0, b1 in zip(bounds[:-1], bounds[1:]):
             batch = [mine[i] for i in todo[b0: b1]]
             pairs = []

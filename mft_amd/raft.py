@@ -292,7 +292,7 @@ class RAFTWrapper:
             buf.record_stream(main)
         return buf, (h, w)
 
-    def adopt_halves(self, frame_id, fbuf, cbuf, img_bgr):
+    def adopt_halves(self, frame_id, fbuf, cbuf, img_bgr, ready=None):
         """Install a frame's features from the two ``encode_half`` buffers (produced here or on other ranks)."""
         H0, W0 = img_bgr.shape[:2]
         h, w, pads = self._geometry(H0, W0)
@@ -300,22 +300,23 @@ class RAFTWrapper:
         assert fbuf.numel() == N * 256 and cbuf.numel() == N * 256
         fbuf, cbuf = fbuf.reshape(-1), cbuf.reshape(-1)
         self._frames[frame_id] = FrameFeatures(fbuf.view(N, 256), cbuf[: N * 128].view(N, 128), cbuf[N * 128:].view(N, 128),
-                                               h, w, pads, (H0, W0))
+                                               h, w, pads, (H0, W0), ready=ready)
 
     def packed_numel(self, img_bgr):
         """Floats in the buffer ``encode_packed`` produces for a frame of this size."""
         h, w, _ = self._geometry(*img_bgr.shape[:2])
         return h * w * 512
 
-    def adopt_packed(self, frame_id, buf, img_bgr):
-        """Install features produced by ``encode_packed`` (here or on another rank) for ``frame_id``."""
+    def adopt_packed(self, frame_id, buf, img_bgr, ready=None):
+        """Install features produced by ``encode_packed`` (here or on another rank) for ``frame_id``.  ``ready``: an event behind
+        whatever wrote ``buf`` (None: ordered by the stream that is current when the features are used)."""
         H0, W0 = img_bgr.shape[:2]
         h, w, pads = self._geometry(H0, W0)
         N = h * w
         assert buf.numel() == N * 512
         buf = buf.reshape(-1)
         self._frames[frame_id] = FrameFeatures(buf[: N * 256].view(N, 256), buf[N * 256: N * 384].view(N, 128),
-                                               buf[N * 384:].view(N, 128), h, w, pads, (H0, W0))
+                                               buf[N * 384:].view(N, 128), h, w, pads, (H0, W0), ready=ready)
 
     def reset_cache(self):
         self._frames = {}
