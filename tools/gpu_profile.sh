@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 BENCH="python bench.py --steps 20 --warmup 5"
 # per-kernel passes: one batch, one stream, encoders on the main stream -> every kernel runs alone, like bench.py's own
 # HIP-event pass (the timed region of the default run overlaps two half-batches and the next frame's encoders)
-QUIET="--no-cpu-baseline --no-profile --no-parity --no-host-io --sync-encode --no-alt-arith --no-graphs"
+QUIET="--no-cpu-baseline --no-profile --no-parity --no-host-io --sync-encode --no-alt-arith --no-graphs --frames-in-flight 1"
 
 $BENCH > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 # A/B of the round's structural changes, same box, same run (results do not depend on any of them beyond fp32 rounding)
@@ -20,6 +20,10 @@ $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-fused-lookup > $OUT/ben
    args=""; for kv in $o; do args="$args --engine-opt $kv"; done
    for rep in 1 2; do $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-host-io $args 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('engine options [$o]:', round(d['value'],1), 'frames/s, host', round(d['host_enqueue_ms_per_step'],2), 'ms per frame, conv GEMM', round(d['roofline']['frac'],3), 'of the fp16 MFMA peak')"; done
  done) > $OUT/engine_options_ab.txt
+# frames in flight (flow_config.frames_in_flight): 1 / 2 / 3 lanes, same box, twice
+(for rep in 1 2; do for f in 1 2 3; do $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-profile --frames-in-flight $f 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('frames in flight $f:', round(d['value'],1), 'frames/s,', round(d['ms_per_step'],3), 'ms per frame, with PCIe', round(d['host_io_fps'],1))"; done; done
+ for f in 1 2; do python bench.py --steps 20 --warmup 5 --height 256 --width 256 --no-cpu-baseline --no-parity --no-alt-arith --no-profile --no-host-io --frames-in-flight $f 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('256 x 256, frames in flight $f:', round(d['value'],1), 'frames/s')"; done
+ for f in 1 2; do python bench.py --steps 6 --warmup 2 --height 1080 --width 1920 --no-cpu-baseline --no-parity --no-alt-arith --no-profile --no-host-io --frames-in-flight $f 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('1080p, frames in flight $f:', round(d['value'],2), 'frames/s')"; done) > $OUT/frames_in_flight_ab.txt
 python bench.py --steps 20 --warmup 5 --height 256 --width 256 --no-cpu-baseline --no-parity --no-alt-arith > $OUT/bench_256.json 2>/dev/null
 python bench.py --steps 5 --warmup 2 --height 1080 --width 1920 --no-cpu-baseline --no-parity --no-alt-arith --no-host-io > $OUT/bench_1080p.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --force-sharded --no-cpu-baseline --no-parity --no-alt-arith > $OUT/bench_forced_sharded_x1.json 2>/dev/null
@@ -84,5 +88,7 @@ rm -rf $OUT/prof1080/*/*/
 # determinism under contention (round 5): three concurrent processes, every engine option set; kernels under two load generators
 (for i in 0 1 2; do python tools/race_probe.py --reps 100 --tag p$i > $OUT/race_probe_$i.txt 2>&1 & done; wait; cat $OUT/race_probe_?.txt | grep distinct; rm -f $OUT/race_probe_?.txt
  for i in 1 2; do python tools/race_kernels.py --load-seconds 35 --tag load$i > $OUT/race_load_$i.txt 2>&1 & done; sleep 8; python tools/race_kernels.py --reps 2000 --tag under-load 2>&1 | grep distinct; wait; cat $OUT/race_load_?.txt | grep "load:"; rm -f $OUT/race_load_?.txt) > $OUT/race_contention.txt 2>&1
+# ... and the tracker level (chain + selection, one and two frames in flight) beside two load generators
+LOAD_S=130 bash tools/lane_stress.sh > $OUT/race_tracker_contention.txt 2>&1
 rm -rf $OUT/prof/*/*/   # the per-host raw directories (large)
 du -sh $OUT
