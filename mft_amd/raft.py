@@ -113,8 +113,7 @@ class RAFTWrapper:
         # only need the image, so with results kept on the device (no per-frame host sync) their
         # kernels overlap the tail of frame t-1's GEMM-bound refinement instead of sitting on the
         # critical path.  Device-tensor frames must be complete when passed in.
-        self._enc_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("MFTX_ENC_PRIORITY", "0") or 0)) \
-            if getattr(config, "async_encode", False) else None
+        self._enc_stream = torch.cuda.Stream(device=self.device) if getattr(config, "async_encode", False) else None
 
     def _build_engines(self):
         graph = bool(self._engine_options.get("graph", 1))
@@ -148,7 +147,7 @@ class RAFTWrapper:
         while len(self._lanes) < self._fif:
             eng = self.engine if not self._lanes else ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand,
                                                                       arith=self._arith, options=self._engine_options)
-            self._lanes.append((eng, torch.cuda.Stream(device=self.device, priority=int(os.environ.get("MFTX_LANE_PRIORITY", "0") or 0))))
+            self._lanes.append((eng, torch.cuda.Stream(device=self.device)))      # (stream priorities: measured, no effect)
             self._lanes_stale = True              # (a new engine packs its weights on the caller's stream: the lanes wait for that)
         lane = self._lanes[self._lane_next % self._fif]
         self._lane_next += 1
