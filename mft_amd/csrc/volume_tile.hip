@@ -37,7 +37,7 @@ struct VolTileArgs {
     int P, N, h, w, sbw, n_sb, wb0;
     float scale;
     int qchunks, blocks_per_chunk;      // query blocks (of 32) per workgroup
-    int ablate;                         // tuning builds only (MFTX_VT_ABLATE): 1 no level-0 stores, 2 no pooled stores, 4 no MFMAs
+    int ablate;                         // tuning builds only (MFTX_VT_ABLATE): 1 no level-0 stores, 2 no pooled stores, 8 no level-2 / 3 stores
     int gathered;                       // pair bz's queries at f1p.p[bz] (mftx_raft_refine_gather)
     long long f2_bstride;               // floats between the pairs' target maps in f2s (0: shared)
     PairPtrs f1p;
@@ -200,23 +200,44 @@ __global__ __launch_bounds__(512, 2) void volume_tile_kernel(VolTileArgs p) {
         // first query row, records = its valid rows, so rows past the last query fall out of range by themselves --, the lane's offset
         // inside a row in ONE 32-bit register for all 80 stores, the row in a scalar offset.  Half the address traffic of a
         // global store (64-bit address per lane) on the CU's store path, which is what this epilogue is bound by.  Levels 2 and 3
-        // (a few lanes each) stay global stores under EXEC: an out-of-range lane of a buffer store still takes its turn in the
-        // address unit (round 3's all-buffer variant: 430 instead of 360 us).
+        // are global stores under EXEC (an out-of-range lane of a buffer store still takes its turn in the address unit: round 3's
+        // all-buffer variant, 430 instead of 360 us) -- merged over the rows of a block since round 5, see below.
         const int rows_ok = p.N - q0 < 32 ? p.N - q0 : 32;
         const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(p.lvl0 + (qbase + q0) * p.s0, 0, (unsigned)((long long)rows_ok * p.s0 * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(p.lvl1 + (qbase + q0) * p.s1, 0, (unsigned)((long long)rows_ok * p.s1 * 4), 0x00020000);
         const unsigned v0off = (unsigned)((4 * hf * p.s0 + blk0) * 4), v1off = (unsigned)((4 * hf * p.s1 + ((long long)sby * p.sbw + sbx) * 32 + m) * 4);
         const unsigned s0b = (unsigned)(p.s0 * 4), s1b = (unsigned)(p.s1 * 4), jrow = (unsigned)(p.wb0 * 128);
+        // Levels 2 and 3 leave MERGED: a row of the accumulators gives 8 level-2 values and 2 level-3 values per half-wave -- as one masked
+        // store each they were 32 of a query block's 112 store instructions, for 6 % of its bytes, and 11-12 % of the kernel's time
+        // (MFTX_VT_ABLATE = 8: 4912 -> 4387 us at 2 x 1080p, 345 -> 303 us at 7 x 512 x 512).  Instead every row's values are pulled
+        // (ds_bpermute: the lane crossbar, no LDS memory) into their place in a register that collects FOUR rows of level 2 (lane d:
+        // row d >> 4 of the group, half-wave (d >> 3) & 1, cell d & 7 = 4 y + x of the super-block's 2 x 4 level-2 cells) or all SIXTEEN
+        // rows of level 3 (lane d: row d >> 2, half-wave (d >> 1) & 1, cell d & 1), and a query block's levels 2 and 3 are 4 + 1 stores
+        // with every lane active.  The same values: the same bits.
+        int le = lane;
+        asm volatile("" : "+v"(le));                // (worked out per query block, behind the K loop: nothing of it lives across the MFMAs)
+        const int d2c = le & 7, d2hf = (le >> 3) & 1, d2i = le >> 4;
+        const int l2_pull = 4 * (32 * d2hf + 16 * (d2c >> 2) + 2 * (d2c & 3));
+        const int l2_y = 2 * sby + (d2c >> 2), l2_x = 4 * sbx + (d2c & 3);
+        const bool l2_ok = l2_y < h2 && l2_x < w2;
+        const int l2_off = l2_y * w2 + l2_x, l2_row = 4 * d2hf + d2i;               // + 8 (r >> 2): the query row inside the block
+        const int d3c = le & 1, d3hf = (le >> 1) & 1, d3r = le >> 2;
+        const int l3_pull = 4 * (32 * d3hf + 4 * d3c);
+        const int l3_x = 2 * sbx + d3c;
+        const bool l3_ok = sby < h3 && l3_x < w3;
+        const int l3_off = sby * w3 + l3_x, l3_row = 8 * (d3r >> 2) + 4 * d3hf + (d3r & 3);
+        float acc2 = 0.f, acc3 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qrow = q0 + 8 * (r >> 2) + 4 * hf + (r & 3);
             const bool row_ok = qrow < p.N;
 #ifdef MFTX_TUNING
             const bool st0 = row_ok && !(p.ablate & 1), st1 = row_ok && !(p.ablate & 2);
+#define MFTX_VT_ST23 (!(p.ablate & 10))
 #else
             const bool st0 = row_ok, st1 = row_ok;
+#define MFTX_VT_ST23 true
 #endif
-            const long long qr = qbase + qrow;
             float merged = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -247,16 +268,28 @@ __global__ __launch_bounds__(512, 2) void volume_tile_kernel(VolTileArgs p) {
             t2 = t2 + vt_shl<8>(l1);
             t2 = (t2 + vt_shl<9>(l1)) * 0.25f;
             asm volatile("" : "+v"(t2));
-            const int y2 = 2 * sby + (m >> 4), x2 = 4 * sbx + ((m >> 1) & 3);
-            if (st1 && !(m & 1) && !((m >> 3) & 1) && y2 < h2 && x2 < w2) p.lvl2[qr * p.s2 + (long long)y2 * w2 + x2] = t2;
+            {
+                const float pulled = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(l2_pull, __builtin_bit_cast(int, t2)));
+                acc2 = d2i == (r & 3) ? pulled : acc2;
+                if ((r & 3) == 3) {
+                    const int row2 = q0 + 8 * (r >> 2) + l2_row;
+                    if (MFTX_VT_ST23 && l2_ok && row2 < p.N) p.lvl2[(qbase + row2) * p.s2 + l2_off] = acc2;
+                }
+            }
             // level 3: cells x3l = 0, 1 = level-2 cells at lanes (4 x3l, 4 x3l + 2 | 16 + 4 x3l, 16 + 4 x3l + 2)
             const float bq = vt_shl<2>(t2);
             const float cq = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(l3_src, __builtin_bit_cast(int, t2)));
             const float dq = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(l3_src + 8, __builtin_bit_cast(int, t2)));
             float v3 = (((t2 + bq) + cq) + dq) * 0.25f;
             asm volatile("" : "+v"(v3));
-            const int x3 = 2 * sbx + (m >> 2);
-            if (st1 && (m == 0 || m == 4) && sby < h3 && x3 < w3) p.lvl3[qr * p.s3 + (long long)sby * w3 + x3] = v3;
+            {
+                const float pulled = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(l3_pull, __builtin_bit_cast(int, v3)));
+                acc3 = d3r == r ? pulled : acc3;
+                if (r == 15) {
+                    const int row3 = q0 + l3_row;
+                    if (MFTX_VT_ST23 && l3_ok && row3 < p.N) p.lvl3[(qbase + row3) * p.s3 + l3_off] = acc3;
+                }
+            }
         }
     }
 }
