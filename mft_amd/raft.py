@@ -101,6 +101,12 @@ class RAFTWrapper:
                                (2 if self._arith == ops.ARITH_SPLIT else 1)))
         self._lanes, self._lane_next = [], 0          # [(engine, stream)]
         self._lanes_stale = False
+        # ... and the host may not run ahead of the GPU without bound (every queued batch holds its outputs, allocated when it is
+        # enqueued: 29 MB per 512 x 512 frame of 7 pairs): at most C.max_batches_ahead (default 16) lane batches are pending, the
+        # call that would queue one more first waits for the oldest.  Far above what keeps two lanes busy, never reached by a caller
+        # that consumes results as they complete.
+        self._ahead_max = max(2, int(getattr(config, "max_batches_ahead", 0) or 16))
+        self._ahead = []                              # done events of the queued lane batches, oldest first
         # Which GEMM kernels a refinement runs on (tile-resident or ring-buffered: they differ by fp32 rounding of the K sums) must
         # not depend on the batch a pair happens to ride in -- a tracker's ramp-up frames, a remainder window or one rank's share
         # of a sharded job would then give other bits than the full batch.  The choice is made ONCE per image size, for the
@@ -440,6 +446,9 @@ class RAFTWrapper:
                                            flow_init=None, packed=packed, planar=planar)
             done = st.record_event()
         main.wait_event(done)
+        self._ahead.append(done)
+        while len(self._ahead) > self._ahead_max:
+            self._ahead.pop(0).synchronize()
         for t in (packed, flow, occl, sigma):
             if t is not None:
                 t.record_stream(main)

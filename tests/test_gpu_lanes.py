@@ -110,3 +110,35 @@ def test_lanes_with_flow_cache(weights_np, tmp_path):
         outs.append(_run(tr, vid, 8, cache=cache))
     for a, b in zip(*outs):
         assert _same(a, b)
+
+
+def test_lanes_host_lookahead_is_bounded(weights_np):
+    """C.max_batches_ahead: the host queues at most that many lane batches before it waits for the oldest; results unchanged."""
+    from mft_amd.config import Config
+    from mft_amd.MFT import MFT
+    from mft_amd.raft import RAFTWrapper
+    vid = SyntheticVideo(128, 160, n_frames=12, seed=33)
+    deltas = (np.inf, 1, 2, 4)
+    base = _run(_tracker(weights_np, 1, 3, deltas)[0], vid, 12)
+    c = Config()
+    c.flow_iters = 3
+    c.async_encode = True
+    c.frames_in_flight = 2
+    c.max_batches_ahead = 2
+    fl = RAFTWrapper(c, state_dict=weights_np)
+    t = Config()
+    t.deltas = list(deltas)
+    t.occlusion_threshold = 0.02
+    t.keep_result_on_device = True
+    t.flow_config = Config()
+    t.flow_config.of_class = lambda cfg: fl
+    tr = MFT(t)
+    tr.init(torch.from_numpy(vid[0]).cuda())
+    got = []
+    for i in range(1, 12):
+        got.append(tr.track(torch.from_numpy(vid[i]).cuda()).result)
+        assert len(fl._ahead) <= 2
+        assert all(e.query() for e in fl._ahead[:-2]) or len(fl._ahead) <= 2
+    torch.cuda.synchronize()
+    for a, b in zip(base, got):
+        assert _same(a, b)
