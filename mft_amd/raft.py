@@ -97,8 +97,7 @@ class RAFTWrapper:
         # run beside the other frame's matrix work instead of alone.  Same kernels, same batches: the same bits.
         # Measured (512 x 512, 7 pairs, one MI355X, same box): 1 / 2 / 3 lanes = 162.4 / 178.0 / 165.2 frames/s.  Default: 2 with the
         # split arithmetic (the fp32 path batches through _refine_split instead), 1 otherwise.
-        self._fif = max(1, int(os.environ.get("MFTX_FRAMES_IN_FLIGHT", "") or getattr(config, "frames_in_flight", 0) or
-                               (2 if self._arith == ops.ARITH_SPLIT else 1)))
+        self._fif = self._frames_in_flight_setting(config)
         self._lanes, self._lane_next = [], 0          # [(engine, stream)]
         self._lanes_stale = False
         # ... and the host may not run ahead of the GPU without bound (every queued batch holds its outputs, allocated when it is
@@ -119,7 +118,21 @@ class RAFTWrapper:
         # only need the image, so with results kept on the device (no per-frame host sync) their
         # kernels overlap the tail of frame t-1's GEMM-bound refinement instead of sitting on the
         # critical path.  Device-tensor frames must be complete when passed in.
-        self._enc_stream = torch.cuda.Stream(device=self.device) if getattr(config, "async_encode", False) else None
+        # Default (the key absent from the config): ON when several frames are in flight (C.frames_in_flight below) -- a lane waits
+        # for the encoders' event only, and encoders queued on the caller's stream would sit behind the previous frame's selection,
+        # i.e. behind the previous frame's whole batch; `async_encode = False` said explicitly still wins.
+        ae = getattr(config, "__dict__", {}).get("async_encode", None)
+        # (on by DEFAULT it is also safe for frames that are device tensors still being produced on the caller's stream: the encode
+        # stream then waits for that stream first.  `async_encode = True` said explicitly keeps the contract above -- device frames
+        # complete when passed in -- and the overlap that goes with it.  Host frames are uploaded on the encode stream either way.)
+        self._enc_waits_for_device_frames = ae is None
+        if ae is None:
+            ae = self._frames_in_flight_setting(config) > 1
+        self._enc_stream = torch.cuda.Stream(device=self.device) if ae else None
+
+    def _frames_in_flight_setting(self, config):
+        return max(1, int(os.environ.get("MFTX_FRAMES_IN_FLIGHT", "") or getattr(config, "frames_in_flight", 0) or
+                          (2 if self._arith == ops.ARITH_SPLIT else 1)))
 
     def _build_engines(self):
         graph = bool(self._engine_options.get("graph", 1))
@@ -339,6 +352,8 @@ class RAFTWrapper:
                 f.ready = torch.cuda.current_stream().record_event()
             return f
         main = torch.cuda.current_stream()
+        if self._enc_waits_for_device_frames and isinstance(img, torch.Tensor) and img.is_cuda:
+            self._enc_stream.wait_stream(main)
         with torch.cuda.stream(self._enc_stream):
             f = self.encode(img)
             f.ready = self._enc_stream.record_event()
