@@ -27,7 +27,8 @@ typedef _Float16 vt_f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int VT_C = 256;                       // feature channels
 constexpr int VT_ROW = VT_C * 4 + 16;           // bytes per resident target row (consecutive targets 65 sixteen-byte slots apart)
-constexpr int VT_LDS = 128 * VT_ROW;            // 133 120
+constexpr int VT_TARGETS = 128 * VT_ROW;        // 133 120
+constexpr int VT_LDS = VT_TARGETS + 8 * 1024;   // + a 1 KB transpose slab per wave (level-0 lines, see the epilogue)
 
 struct VolTileArgs {
     const float *f1;            // [P][N][256] fp32
@@ -198,18 +199,19 @@ __global__ __launch_bounds__(512, 2) void volume_tile_kernel(VolTileArgs p) {
         const long long blk0 = ((long long)(2 * sby) * p.wb0 + 2 * sbx) * 32 + m;          // + (j >> 1) wb0 * 32 + (j & 1) * 32
         // Levels 0 and 1 (every lane stores) leave as raw BUFFER stores: one descriptor per query block and level -- base = the block's
         // first query row, records = its valid rows, so rows past the last query fall out of range by themselves --, the lane's offset
-        // inside a row in ONE 32-bit register for all 80 stores, the row in a scalar offset.  Half the address traffic of a
+        // inside a row in ONE 32-bit register for all stores of a level, the row in a scalar offset.  Half the address traffic of a
         // global store (64-bit address per lane) on the CU's store path, which is what this epilogue is bound by.  Levels 2 and 3
         // are global stores under EXEC (an out-of-range lane of a buffer store still takes its turn in the address unit: round 3's
         // all-buffer variant, 430 instead of 360 us) -- merged over the rows of a block since round 5, see below.
         const int rows_ok = p.N - q0 < 32 ? p.N - q0 : 32;
         const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(p.lvl0 + (qbase + q0) * p.s0, 0, (unsigned)((long long)rows_ok * p.s0 * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(p.lvl1 + (qbase + q0) * p.s1, 0, (unsigned)((long long)rows_ok * p.s1 * 4), 0x00020000);
-        const unsigned v0off = (unsigned)((4 * hf * p.s0 + blk0) * 4), v1off = (unsigned)((4 * hf * p.s1 + ((long long)sby * p.sbw + sbx) * 32 + m) * 4);
+        const unsigned v1off = (unsigned)((4 * hf * p.s1 + ((long long)sby * p.sbw + sbx) * 32 + m) * 4);
         const unsigned s0b = (unsigned)(p.s0 * 4), s1b = (unsigned)(p.s1 * 4), jrow = (unsigned)(p.wb0 * 128);
         // Levels 2 and 3 leave MERGED: a row of the accumulators gives 8 level-2 values and 2 level-3 values per half-wave -- as one masked
         // store each they were 32 of a query block's 112 store instructions, for 6 % of its bytes, and 11-12 % of the kernel's time
-        // (MFTX_VT_ABLATE = 8: 4912 -> 4387 us at 2 x 1080p, 345 -> 303 us at 7 x 512 x 512).  Instead every row's values are pulled
+        // (MFTX_VT_ABLATE = 8: 4912 -> 4387 us at 2 x 1080p, 345 -> 303 us at 7 x 512 x 512, of which the merge recovers a quarter:
+        // same box, 4921 -> 4785 / 334 -> 326 us).  Instead every row's values are pulled
         // (ds_bpermute: the lane crossbar, no LDS memory) into their place in a register that collects FOUR rows of level 2 (lane d:
         // row d >> 4 of the group, half-wave (d >> 3) & 1, cell d & 7 = 4 y + x of the super-block's 2 x 4 level-2 cells) or all SIXTEEN
         // rows of level 3 (lane d: row d >> 2, half-wave (d >> 1) & 1, cell d & 1), and a query block's levels 2 and 3 are 4 + 1 stores
@@ -226,23 +228,55 @@ __global__ __launch_bounds__(512, 2) void volume_tile_kernel(VolTileArgs p) {
         const int l3_x = 2 * sbx + d3c;
         const bool l3_ok = sby < h3 && l3_x < w3;
         const int l3_off = sby * w3 + l3_x, l3_row = 8 * (d3r >> 2) + 4 * d3hf + (d3r & 3);
+        // Level 0 leaves TRANSPOSED (round 5): per row group g (8 query rows) and block j a lane holds 4 values of ONE target column --
+        // 64 dword stores per query block, two 128-byte lines each.  They go through the wave's own 1 KB of LDS instead ([8 rows][32
+        // targets]: four ds_write_b32, one ds_read_b128 -- LDS serves a wave's operations in order, no barrier, no second buffer), after
+        // which lane l holds targets 4 (l & 7) .. + 3 of row l >> 3: ONE dwordx4 store per (g, j) writes the eight rows' lines whole.
+        // 16 stores instead of 64; the same values in the same places.  Same box, on top of the merged levels 2 / 3: 4785 -> 4722 us at
+        // 2 x 1080p, 326 -> 310 us at 7 x 512 x 512.
+        float *slab = reinterpret_cast<float *>(lds + VT_TARGETS + wv * 1024);
+        const unsigned v0off4 = (unsigned)((le >> 3) * s0b) + (unsigned)((blk0 - m) * 4) + (unsigned)(le & 7) * 16u;
         float acc2 = 0.f, acc3 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int g = 0; g < 4; ++g) {
+#ifdef MFTX_TUNING
+            const bool st0g = !(p.ablate & 1);
+#else
+            const bool st0g = true;
+#endif
+            float vv[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vv[i][j] = (acc[j][4 * g + i] + accx[j][4 * g + i] * inv2048) * p.scale;
+            vt_f32x4 line[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) slab[(4 * hf + i) * 32 + m] = vv[i][j];
+                line[j] = *reinterpret_cast<const vt_f32x4 *>(slab + (le >> 3) * 32 + (le & 7) * 4);
+            }
+            if (st0g) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vt_u32x4, line[j]), r0, v0off4 + (j >> 1) * jrow + (j & 1) * 128u, (unsigned)(8 * g) * s0b, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * g + i;
             const int qrow = q0 + 8 * (r >> 2) + 4 * hf + (r & 3);
             const bool row_ok = qrow < p.N;
 #ifdef MFTX_TUNING
-            const bool st0 = row_ok && !(p.ablate & 1), st1 = row_ok && !(p.ablate & 2);
+            const bool st1 = row_ok && !(p.ablate & 2);
 #define MFTX_VT_ST23 (!(p.ablate & 10))
 #else
-            const bool st0 = row_ok, st1 = row_ok;
+            const bool st1 = row_ok;
 #define MFTX_VT_ST23 true
 #endif
             float merged = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float v = (acc[j][r] + accx[j][r] * inv2048) * p.scale;
-                if (st0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r0, v0off + (j >> 1) * jrow + (j & 1) * 128u, (unsigned)(8 * (r >> 2) + (r & 3)) * s0b, 0);
+                const float v = vv[i][j];
                 // level 1: the 2 x 2 cells (y, x), (y, x + 1), (y + 1, x), (y + 1, x + 1) are lanes m, m + 1, m + 8, m + 9 of one 16-lane row
                 // (valid where x and y are even), summed in ATen's order
                 float t = v + vt_shl<1>(v);
@@ -290,6 +324,7 @@ __global__ __launch_bounds__(512, 2) void volume_tile_kernel(VolTileArgs p) {
                     if (MFTX_VT_ST23 && l3_ok && row3 < p.N) p.lvl3[(qbase + row3) * p.s3 + l3_off] = acc3;
                 }
             }
+        }
         }
     }
 }
