@@ -109,6 +109,8 @@ class WindowSharder:
         stream = None
         if side and hasattr(flower, "ensure_encode_stream"):
             stream = flower.ensure_encode_stream()   # all encoder work of the plugin is serialised on this stream
+            if getattr(flower, "_enc_waits_for_device_frames", False) and any(isinstance(im, torch.Tensor) and im.is_cuda for im in imgs):
+                stream.wait_stream(torch.cuda.current_stream(tracker.device))   # (device frames may still be being written there)
         ctx = torch.cuda.stream(stream) if stream is not None else _NullCtx()
         if halves:
             # unit u = 2 j + part (part 0: fnet, part 1: cnet) is encoded by rank u: the frame's serial head is ONE encoder,
@@ -222,7 +224,11 @@ class WindowSharder:
         if pre is not None and pre["ids"] == frame_ids:
             self._finish_feature_exchange(tracker, pre)                      # started during the previous window
         else:
-            self._finish_feature_exchange(tracker, self._start_feature_exchange(tracker, frame_ids, imgs))
+            # (with several frames in flight the exchange of THIS window, too, runs on the plugin's encode stream: on the caller's
+            # stream its encoders would queue behind the previous window's selection, i.e. behind the previous window's whole batch --
+            # the per-frame mode, which has nothing to prefetch, then never has two frames in flight)
+            lanes = int(getattr(tracker.flower, "_fif", 1)) > 1 and hasattr(tracker.flower, "ensure_encode_stream")
+            self._finish_feature_exchange(tracker, self._start_feature_exchange(tracker, frame_ids, imgs, side=lanes))
         if next_imgs:
             nxt_ids = [frame_ids[-1] + d * (j + 1) for j in range(len(next_imgs))]
             tracker._window_ids |= set(nxt_ids)
