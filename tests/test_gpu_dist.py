@@ -39,7 +39,7 @@ def test_window_sharding_rccl_bitwise(tmp_path):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_real_plugin_multirank_on_one_gpu(tmp_path, world):
     """The REAL plugin with world_size > 1 ("weak" 5a): `world` processes share cuda:0, the collectives run
     on device tensors through gloo (RCCL refuses two ranks on one device; the code path of mft_amd/dist.py is the same:
