@@ -103,5 +103,15 @@ if __name__ == "__main__":
         if rank == 0:
             np.savez(outdir / "single_big.npz", **run(big, False, 1, size=(512, 512), n_frames=world + 2, seed=9)[0])
             np.savez(outdir / "single_big1.npz", **run(big, False, 1, size=(512, 512), n_frames=4, seed=9)[0])
+    if world > 1 and os.environ.get("MFT_DIST_1080P") == "1":
+        # BASELINE config 5's multi-GPU half on the one GPU of a test box: 1080 x 1920 windows (136 x 240 cells: the HBM-resident
+        # pyramid, 272 workgroups and more per kernel) sharded over the ranks, pipelined, against the single-process tracker
+        fc3 = Config()
+        fc3.flow_iters = 12
+        hd = RAFTWrapper(fc3, state_dict=make_weights(7))
+        res, _ = run(hd, sharding, world, prefetch=True, defer=True, size=(1080, 1920), n_frames=2 * world + 1, seed=11)
+        np.savez(outdir / f"rank{rank}_hd.npz", **res)
+        if rank == 0:
+            np.savez(outdir / "single_hd.npz", **run(hd, False, 1, size=(1080, 1920), n_frames=2 * world + 1, seed=11)[0])
     dist.barrier()
     dist.destroy_process_group()

@@ -76,6 +76,26 @@ def test_real_plugin_multirank_on_one_gpu(tmp_path, world):
                 assert np.array_equal(got[k], ref[k]), (name, r, k)
 
 
+@pytest.mark.timeout(900)
+def test_c5_1080p_windows_sharded_over_two_ranks_on_one_gpu(tmp_path):
+    """BASELINE config 5 (1080p, the pyramid resident in HBM, multi-GPU): two real ranks on the one GPU of the test box (gloo on
+    device tensors), look-ahead windows of two 1080 x 1920 frames, prefetched and pipelined, 12 iterations, deltas inf / 1 / 2 / 4 / 8:
+    every rank bitwise equal to the single-process tracker (whose 1080p pairs are held against the oracle in test_gpu_e2e.py)."""
+    port = "29655"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MFT_DIST_BACKEND="gloo", MFT_DIST_ONE_GPU="1", MFT_DIST_1080P="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", port, str(REPO / "tests" / "gpu_dist_worker.py"), str(tmp_path)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=850)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    ref = np.load(tmp_path / "single_hd.npz")
+    assert ref["flow1"].shape == (2, 1080, 1920) and len([k for k in ref.files if k.startswith("flow")]) == 4
+    for r in range(2):
+        got = np.load(tmp_path / f"rank{r}_hd.npz")
+        for k in ref.files:
+            assert np.array_equal(got[k], ref[k]), (r, k)
+
+
 def test_bench_sharded_line_carries_roofline_and_ranks_seen():
     """The N > 1 form of bench.py (forced here with the one visible GPU: RCCL process group of one rank, window-sharded
     tracker, pipelined windows): its JSON line must carry what the N = 1 line carries -- `roofline`, `kernels` -- plus
