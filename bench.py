@@ -35,6 +35,11 @@ import time
 from pathlib import Path
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and a stream that waits for an event blocks the
+# queue it shares: with the tracker's streams (caller, encoders / exchange, two lanes, the graph proxies) four are too few for the
+# sharded path -- emulated rank 0 of 8: window mode 1081 -> 1173 frames/s, per-frame mode 325 -> 559 -- while one GPU alone does not
+# care (178.5 / 179.4).  Read by the HIP runtime when it initialises: set before torch is imported (mft_amd/__init__.py does the same).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 # stdout must carry ONE JSON line and nothing else.  Native libraries print to fd 1 from C (the RCCL version banner, some
 # of it only when the process exits, through descriptors they set up when they are loaded), so fd 1 is pointed at stderr

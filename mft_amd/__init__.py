@@ -5,8 +5,17 @@ Drop-in names: ``MFT`` (tracker), ``FlowOUTrackingResult`` / ``FlowOUResult``,
 Compute runs in ``libmftx.so`` (hand-written gfx950 HIP kernels, C ABI in
 ``include/mftx.h``); there is no CPU fallback.
 """
-from .config import Config, load_config  # noqa: F401
-from .results import FlowOUTrackingResult, FlowOUResult  # noqa: F401
+import os as _os
+
+# The tracker runs on five or more HIP streams (the caller's, the encoders' / feature exchange's, one per frame in flight, the graph
+# proxies); HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and a stream waiting for an event blocks the
+# queue it shares.  Eight queues cost nothing on one GPU and are worth + 9 % (windows) / + 70 % (per-frame mode) on the sharded path
+# (DESIGN.md section 5).  The HIP runtime reads the variable when it initialises, i.e. at the process's first GPU call: importing this
+# package before that is enough; an explicit setting in the environment wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from .config import Config, load_config  # noqa: F401,E402
+from .results import FlowOUTrackingResult, FlowOUResult  # noqa: F401,E402
 
 
 def __getattr__(name):  # lazy: these import torch-heavy modules
