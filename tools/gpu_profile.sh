@@ -27,7 +27,8 @@ $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-fused-lookup > $OUT/ben
 python bench.py --steps 20 --warmup 5 --height 256 --width 256 --no-cpu-baseline --no-parity --no-alt-arith > $OUT/bench_256.json 2>/dev/null
 python bench.py --steps 5 --warmup 2 --height 1080 --width 1920 --no-cpu-baseline --no-parity --no-alt-arith --no-host-io > $OUT/bench_1080p.json 2>/dev/null
 python bench.py --steps 20 --warmup 5 --force-sharded --no-cpu-baseline --no-parity --no-alt-arith > $OUT/bench_forced_sharded_x1.json 2>/dev/null
-(for g in 2 4 8; do python bench.py --steps 20 --warmup 5 --force-sharded --emulate-world $g --no-cpu-baseline --no-parity --no-alt-arith --no-profile 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('emulated world $g (driver flags):', round(d['value'],1), 'frames/s')"; done; python bench.py --steps 80 --warmup 5 --force-sharded --emulate-world 8 --no-cpu-baseline --no-parity --no-alt-arith --no-profile 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('emulated world 8 (80 steps):', round(d['value'],1), 'frames/s')") > $OUT/emulated_world.txt
+(for g in 2 4 8; do python bench.py --steps 20 --warmup 5 --force-sharded --emulate-world $g --no-cpu-baseline --no-parity --no-alt-arith --no-profile 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('emulated world $g (driver flags):', round(d['value'],1), 'frames/s')"; done; python bench.py --steps 80 --warmup 5 --force-sharded --emulate-world 8 --no-cpu-baseline --no-parity --no-alt-arith --no-profile 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('emulated world 8 (80 steps):', round(d['value'],1), 'frames/s')"
+ for g in 2 4 8; do python bench.py --steps 40 --warmup 8 --force-sharded --emulate-world $g --window 1 --no-cpu-baseline --no-parity --no-alt-arith --no-profile 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('per-frame mode (--window 1), emulated world $g:', round(d['value'],1), 'frames/s')"; done) > $OUT/emulated_world.txt
 IO_ALL=1 timeout 300 python tools/io_paths3.py 2>&1 | grep -v amdgpu.ids > $OUT/io_paths.txt; IO_ALL=1 IO_THREADS=1 timeout 300 python tools/io_paths3.py 2>&1 | grep -v amdgpu.ids >> $OUT/io_paths.txt
 timeout 100 python tools/io_kernel_copy.py 2>&1 | grep -v amdgpu.ids >> $OUT/io_paths.txt
 timeout 300 python tools/lf_stress.py 2>&1 | grep -v amdgpu.ids > $OUT/lf_stress.txt
