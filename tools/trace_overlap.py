@@ -1,3 +1,10 @@
+#!/usr/bin/env python3
+"""Do kernels of different streams ever run at the same time?  From a rocprofv3 --kernel-trace CSV (second half = steady state): wall
+time, the sum of the kernel durations, the time covered by at least one kernel, kernels per hardware queue, idle gaps > 50 us.
+Sum = covered means NO two kernels overlapped -- how HIP's default of four hardware queues was found to serialise the sharded
+per-frame mode (profiles/r5s_hw_queues.txt).
+
+    rocprofv3 --kernel-trace --output-format csv -d out -o t -- python bench.py ...;  python tools/trace_overlap.py out/.../t_kernel_trace.csv"""
 import csv, sys, re, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
