@@ -405,3 +405,27 @@ def test_every_raw_s_barrier_is_preceded_by_an_lds_wait():
                 if not re.search(r's_waitcnt lgkmcnt\(0\)', before):
                     bad.append(f"{path.name}:{i + 1}")
     assert not bad, bad
+
+
+def test_chain_kernels_are_built_without_packed_fp32_code():
+    """Round 5, the chain race: the SLP vectoriser's packed-fp32 code in the chain + selection kernels lost lanes 48..63 of one result
+    register whenever another process shared the GPU (profiles/r5q_chain_race.txt).  Build-level guard: with the flags of the
+    Makefile's chain.o rule -- and of tools/build_tuning.sh -- the device code of chain.hip contains no v_pk_* instruction."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("no hipcc")
+    mk = (REPO / "mft_amd" / "csrc" / "Makefile").read_text()
+    m = re.search(r"^chain\.o:.*\n\t\$\(HIPCC\) \$\(CXXFLAGS\) (.*?) -c \$< -o \$@", mk, re.M)
+    assert m, "chain.o rule not found"
+    extra = m.group(1).split()
+    assert "-fno-slp-vectorize" in extra and "-ffp-contract=off" in extra, extra
+    assert '"chain.hip|chain.o|-ffp-contract=off -fno-slp-vectorize"' in (REPO / "tools" / "build_tuning.sh").read_text()
+    cxx = re.search(r"^CXXFLAGS := (.*)$", mk, re.M).group(1).replace("$(ARCH)", "gfx950").split()
+    out = subprocess.run([hipcc, *cxx, *extra, "-I", str(REPO / "include"), "-S", "--cuda-device-only", "-o", "-",
+                          str(REPO / "mft_amd" / "csrc" / "chain.hip")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "chain_select_packed_kernel" in out.stdout
+    assert not re.search(r"\bv_pk_\w+", out.stdout), re.findall(r"\bv_pk_\w+", out.stdout)[:5]
