@@ -429,10 +429,3 @@ def test_chain_kernels_are_built_without_packed_fp32_code():
     assert out.returncode == 0, out.stderr[-2000:]
     assert "chain_select_packed_kernel" in out.stdout
     assert not re.search(r"\bv_pk_\w+", out.stdout), re.findall(r"\bv_pk_\w+", out.stdout)[:5]
-    # the same recipe (SLP-made packed code next to bounds-masked loads) in the other small kernels: built without SLP as well
-    rule = re.search(r"^corr\.o upsample\.o encoder\.o corr_ondemand\.o:.*\n\t\$\(HIPCC\) \$\(CXXFLAGS\) (.*?) -c \$< -o \$@", mk, re.M)
-    assert rule and "-fno-slp-vectorize" in rule.group(1).split()
-    for name in ("corr", "upsample"):
-        o = subprocess.run([hipcc, *cxx, "-fno-slp-vectorize", "-I", str(REPO / "include"), "-S", "--cuda-device-only", "-o", "-",
-                            str(REPO / "mft_amd" / "csrc" / f"{name}.hip")], capture_output=True, text=True, timeout=300)
-        assert o.returncode == 0 and not re.search(r"\bv_pk_\w+", o.stdout), name

@@ -7,8 +7,7 @@ cd "$(dirname "$0")/.."
 SRC=mft_amd/csrc; OBJ=build_tune/obj; mkdir -p $OBJ
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DMFTX_TUNING -DMFTX_EXPERIMENTAL_TILES $1"
 jobs=()
-for f in conv_small lookup_convc1 flow_branch tile_conv volume_tile raft_engine conv_gemm; do jobs+=("$f.hip|$f.o|"); done
-for f in corr corr_ondemand upsample encoder; do jobs+=("$f.hip|$f.o|-fno-slp-vectorize"); done      # (as in csrc/Makefile)
+for f in conv_small corr corr_ondemand lookup_convc1 flow_branch tile_conv volume_tile upsample raft_engine encoder conv_gemm; do jobs+=("$f.hip|$f.o|"); done
 for k in 0 1 2 3; do jobs+=("conv_gemm.hip|conv_gemm_p$k.o|-DMFTX_CONV_PART=$k"); done
 jobs+=("chain.hip|chain.o|-ffp-contract=off -fno-slp-vectorize" "codec.hip|codec.o|-ffp-contract=off -fno-slp-vectorize" "api.cpp|api.o|-x hip")
 printf '%s\n' "${jobs[@]}" | xargs -P 8 -I{} bash -c 'IFS="|" read s o x <<< "{}"; /opt/rocm/bin/hipcc '"$FLAGS"' $x -c '"$SRC"'/$s -o '"$OBJ"'/$o'
