@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -DMFTX_TU
 jobs=()
 for f in conv_small corr corr_ondemand lookup_convc1 flow_branch tile_conv volume_tile upsample raft_engine encoder conv_gemm; do jobs+=("$f.hip|$f.o|"); done
 for k in 0 1 2 3; do jobs+=("conv_gemm.hip|conv_gemm_p$k.o|-DMFTX_CONV_PART=$k"); done
-jobs+=("chain.hip|chain.o|-ffp-contract=off -fno-slp-vectorize" "codec.hip|codec.o|-ffp-contract=off -fno-slp-vectorize" "api.cpp|api.o|-x hip")
+jobs+=("chain.hip|chain.o|-ffp-contract=off -fno-slp-vectorize" "codec.hip|codec.o|-ffp-contract=off" "api.cpp|api.o|-x hip")
 printf '%s\n' "${jobs[@]}" | xargs -P 8 -I{} bash -c 'IFS="|" read s o x <<< "{}"; /opt/rocm/bin/hipcc '"$FLAGS"' $x -c '"$SRC"'/$s -o '"$OBJ"'/$o'
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build_tune/libmftx_tune.so $OBJ/*.o
 ls -la build_tune/libmftx_tune.so
