@@ -36,6 +36,23 @@ def pad_amounts(H0, W0):
     return pw // 2, pw - pw // 2, ph // 2, ph - ph // 2
 
 
+# The plugin's own HIP streams (encoders / feature exchange, one per frame in flight) are created ONCE per process and device and
+# shared by every plugin instance.  HIP hands its hardware queues to streams round robin as they are created: the first set of a
+# process ends up on queues of its own (GPU_MAX_HW_QUEUES = 8, mft_amd/__init__.py), but the streams of a second, third, ... plugin
+# instance may land on the queue of the caller's stream or of each other -- and a stream that waits for an event blocks the queue it
+# shares: measured, trackers 2-4 of one process ran 153-160 frames/s where the first and a fresh process's run 174.  Instances that
+# share a stream merely take turns on it.
+_STREAMS = {}
+
+
+def _shared_stream(device, kind, index=0):
+    key = (torch.device(device).index or 0, kind, index)
+    st = _STREAMS.get(key)
+    if st is None:
+        st = _STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class FrameFeatures:
     __slots__ = ("fmap", "net", "inp", "h", "w", "pads", "shape", "ready")
 
@@ -122,13 +139,13 @@ class RAFTWrapper:
         # for the encoders' event only, and encoders queued on the caller's stream would sit behind the previous frame's selection,
         # i.e. behind the previous frame's whole batch; `async_encode = False` said explicitly still wins.
         ae = getattr(config, "__dict__", {}).get("async_encode", None)
-        # (on by DEFAULT it is also safe for frames that are device tensors still being produced on the caller's stream: the encode
-        # stream then waits for that stream first.  `async_encode = True` said explicitly keeps the contract above -- device frames
+        # (on by DEFAULT it is also safe for frames that are device tensors still being produced on the caller's stream: such a frame
+        # is encoded on the caller's stream, in order.  `async_encode = True` said explicitly keeps the contract above -- device frames
         # complete when passed in -- and the overlap that goes with it.  Host frames are uploaded on the encode stream either way.)
         self._enc_waits_for_device_frames = ae is None
         if ae is None:
             ae = self._frames_in_flight_setting(config) > 1
-        self._enc_stream = torch.cuda.Stream(device=self.device) if ae else None
+        self._enc_stream = _shared_stream(self.device, "enc") if ae else None
 
     def _frames_in_flight_setting(self, config):
         return max(1, int(os.environ.get("MFTX_FRAMES_IN_FLIGHT", "") or getattr(config, "frames_in_flight", 0) or
@@ -166,7 +183,7 @@ class RAFTWrapper:
         while len(self._lanes) < self._fif:
             eng = self.engine if not self._lanes else ops.RaftEngine(self.sd, self.device, ondemand_corr=self._ondemand,
                                                                       arith=self._arith, options=self._engine_options)
-            self._lanes.append((eng, torch.cuda.Stream(device=self.device)))      # (stream priorities: measured, no effect)
+            self._lanes.append((eng, _shared_stream(self.device, "lane", len(self._lanes))))      # (stream priorities: measured, no effect)
             self._lanes_stale = True              # (a new engine packs its weights on the caller's stream: the lanes wait for that)
         lane = self._lanes[self._lane_next % self._fif]
         self._lane_next += 1
@@ -251,7 +268,7 @@ class RAFTWrapper:
         """The stream every encoder launch of this plugin runs on from now on (the encoder engines own ONE workspace
         each: encodes issued from different streams would race on it)."""
         if self._enc_stream is None:
-            self._enc_stream = torch.cuda.Stream(device=self.device)
+            self._enc_stream = _shared_stream(self.device, "enc")
             self._enc_stream.wait_stream(torch.cuda.current_stream(self.device))   # encodes already queued elsewhere finish first
         return self._enc_stream
 
@@ -353,7 +370,12 @@ class RAFTWrapper:
             return f
         main = torch.cuda.current_stream()
         if self._enc_waits_for_device_frames and isinstance(img, torch.Tensor) and img.is_cuda:
-            self._enc_stream.wait_stream(main)
+            # async_encode by DEFAULT and a frame that is a device tensor: it may still be being written on the caller's stream, so it
+            # is encoded there, in order (as before round 5; the encode stream waiting for the caller's stream would cost more: 142
+            # against 160 frames/s).  Frames known to be complete: say async_encode = True.
+            f = self.encode(img)
+            f.ready = main.record_event()
+            return f
         with torch.cuda.stream(self._enc_stream):
             f = self.encode(img)
             f.ready = self._enc_stream.record_event()
