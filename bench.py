@@ -186,6 +186,49 @@ def profile_pass(tracker, frames, first, steps, arith="split"):
     return out, pairs
 
 
+def api_default_pass(args, host_frames, n):
+    """The reference's literal loop on the SHIPPED configuration (configs/MFT_cfg.py untouched but for the stand-in weights --
+    there is no checkpoint here -- and the iteration count of the command line): numpy frames in, `tracker.track(frame)` returning
+    `meta.result` as a CPU FlowOUTrackingResult (MFT/MFT.py:145-148, demo.py:59-65), default torch threads, no helper classes.
+    Two loops over steady-state frames (7 pairs each):
+      kept:     results are collected and read after the loop (a runner that writes its outputs at the end; demo.py keeps them in
+                a list) -- `meta.result` is a PendingHostResult, so the tracker runs ahead of the copies;
+      consumed: every result's planes are read before the next track() call (demo.py's convert_to_point_tracking does): one
+                host synchronisation per frame, as with the reference -- the frame's latency, nothing overlaps."""
+    from mft_amd.config import load_config
+    conf = load_config(REPO / "configs" / "MFT_cfg.py")
+    conf.flow_config.model = None
+    conf.flow_config.synthetic_weights_seed = 0
+    conf.flow_config.flow_iters = args.iters
+    tr = conf.tracker_class(conf)
+    warm = FIRST_FULL_FRAME + 7
+    assert len(host_frames) >= warm + 2 * n, (len(host_frames), warm, n)
+    tr.init(host_frames[0])
+    for i in range(1, warm):
+        tr.track(host_frames[i]).result.flow
+    out = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kept = [tr.track(host_frames[i]).result for i in range(warm, warm + n)]
+    checksum = sum(float(r.flow[0, 0, 0]) for r in kept)          # every result read on the host (waits for the last copies)
+    torch.cuda.synchronize()
+    out["kept"] = n / (time.perf_counter() - t0)
+    assert all(not r.flow.is_cuda for r in kept) and np.isfinite(checksum)
+    assert len(tr.last_pairs) == FULL_PAIRS, tr.last_pairs
+    del kept
+    t0 = time.perf_counter()
+    for i in range(warm + n, warm + 2 * n):
+        r = tr.track(host_frames[i]).result
+        checksum += float(r.flow[0, 0, 0]) + float(r.occlusion[0, -1, -1])
+    torch.cuda.synchronize()
+    out["consumed"] = n / (time.perf_counter() - t0)
+    out["threads"] = torch.get_num_threads()
+    out["frames_in_flight"] = int(getattr(tr.flower, "_fif", 1))
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
 def build_hash():
     """sha256 (first 16 hex digits) of the library this process runs: ties a counter file to the build it was measured on."""
     import hashlib
@@ -457,6 +500,9 @@ def main():
     n_io_frames = n_io + (IO_WARM if n_io else 0)
     n_prof = 0 if args.no_profile else args.steps
     n_frames = 1 + preroll + args.warmup + args.steps + n_prof + n_io_frames
+    n_api = 0 if (args.no_host_io or world > 1 or args.force_sharded) else max(20, args.steps)
+    if n_api:
+        n_frames = max(n_frames, FIRST_FULL_FRAME + 7 + 2 * n_api)
     vid = SyntheticVideo(args.height, args.width, n_frames=max(n_frames, 48), seed=0)
     host_frames = [vid[i] for i in range(n_frames)]
     frames = [torch.from_numpy(f).cuda() for f in host_frames]      # resident in HBM
@@ -625,6 +671,18 @@ def main():
         torch.cuda.empty_cache()
         log(f"other arithmetic ({other}): {10 / alt_dt:.1f} frames/s")
     if not sharded and rank == 0:
+        if n_api:
+            # BEFORE anything below touches torch's thread count: the literal API loop with the process's default threads
+            api = api_default_pass(args, host_frames, n_api)
+            result["api_default_fps"] = api["kept"]
+            result["api_default_consumed_each_frame_fps"] = api["consumed"]
+            result["api_default_note"] = (
+                "reference's literal loop on the shipped configs/MFT_cfg.py (stand-in weights; %d torch threads; %d frames in flight): numpy "
+                "frame in, tracker.track(frame).result a CPU FlowOUTrackingResult out (a PendingHostResult: the first access of its planes "
+                "waits for the copy).  api_default_fps: results read after the loop; ..._consumed_each_frame_fps: every result read "
+                "before the next track() call, i.e. one host synchronisation per frame as with the reference" %
+                (api["threads"], api["frames_in_flight"]))
+            log(f"api default pass: kept {api['kept']:.1f}, consumed each frame {api['consumed']:.1f} frames/s")
         if n_io:
             # PCIe-inclusive variant of the same loop: every frame comes from HOST memory and every result goes back to it
             # (what the reference's API does, MFT/utils/io.py:566-615 in, MFT/MFT.py:145-148 out).  Frames wait in pinned

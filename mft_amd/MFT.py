@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .results import FlowOUTrackingResult
+from .results import FlowOUTrackingResult, PendingHostResult
 
 logger = logging.getLogger(__name__)
 
@@ -180,19 +180,65 @@ class MFT():
             logger.debug("chain + selection (%d candidates, one kernel): %.2fms", len(lefts), t0.elapsed_time(t1))
         # invalid flows are already marked occluded inside the selection kernel
         result = FlowOUTrackingResult(flow, occl, sigma, validate=False)
+        lazy = self._lazy_host_results() and flow.is_cuda and not self.C.keep_result_on_device
         if self.C.keep_result_on_device:
             meta.result = result.clone()       # a copy: the consumer may move it in place (meta.result.cpu())
+        elif lazy:
+            meta.result = self._host_result_async(result)
         else:
             meta.result = result.clone().cpu()
-        # the guard runs BEFORE any tracker state changes: a FloatingPointError leaves the tracker exactly at frame t-1
-        # (current_frame_i, memory, last_pairs untouched), so the caller may switch raft_params.arith and call track() again
-        self._check_nonfinite(synced=not self.C.keep_result_on_device)
+        # the guard runs BEFORE the tracker's frame counter, memory ring and last_pairs change.  (The frame's flows are in the
+        # flow cache by then and, on the unsynchronised paths, up to nonfinite_check_every earlier frames were stored unchecked:
+        # after a FloatingPointError re-initialise the tracker -- with raft_params.arith = 'fp32' in the configuration if the
+        # message names the split arithmetic -- rather than calling track() again.)
+        self._check_nonfinite(synced=not (self.C.keep_result_on_device or lazy))
         self.current_frame_i = frame_i
         self.last_pairs = [(left_id, frame_i) for _, left_id, _ in plan]
         self.last_chosen = chosen
         self.memory[frame_i] = {'img': input_img, 'result': result}
         self.cleanup_memory()
         return meta
+
+    def _lazy_host_results(self):
+        """C.lazy_host_result (default True): ``meta.result`` of ``track()`` is a ``PendingHostResult`` -- a CPU result whose planes
+        arrive by an asynchronous copy and whose first access waits for them -- instead of a synchronous ``.cpu()`` in every call.
+        False restores the blocking copy (pageable host tensors, as the reference allocates them)."""
+        v = self.C.lazy_host_result
+        return v if isinstance(v, bool) else True
+
+    def _host_result_async(self, result):
+        """The frame's result -> one pinned host buffer [4, H, W] by the copy kernel, on the caller's stream right behind the selection
+        kernel (no SDMA queue: mft_amd/video.py ResultDrain found a pinned download there holding back the pinned uploads
+        queued behind it).  The buffer comes from torch's caching pinned allocator: results the caller drops are recycled, results it
+        keeps stay pinned (4.2 MB each at 512 x 512).  The tracker holds on to every buffer until its copy has run, so that a
+        result dropped unread cannot be recycled -- by this or any other user of the pinned pool -- under the copy that fills it."""
+        host = torch.empty((4, self.img_H, self.img_W), dtype=torch.float32, pin_memory=True)
+        for dst, src in ((host[0:2], result.flow), (host[2:3], result.occlusion), (host[3:4], result.sigma)):
+            ops.copy_bytes(src.contiguous(), dst)
+        check = words = None
+        every = self.C.nonfinite_check_every
+        guard_off = ((isinstance(every, (int, float)) and not isinstance(every, bool) and every <= 0) or
+                     (isinstance(self.C.raise_on_nonfinite, bool) and not self.C.raise_on_nonfinite))
+        if hasattr(self.flower, "nonfinite_snapshot") and not guard_off:
+            n = len(self.flower._all_engines())
+            words = torch.zeros((n, 4), dtype=torch.int32, pin_memory=True)
+            self.flower.nonfinite_snapshot(words)
+            flower = self.flower
+
+            def check(words=words, flower=flower):
+                bad = int(words[:, 0].sum())
+                if bad:
+                    raise flower.nonfinite_error(bad)
+        ev = torch.cuda.current_stream().record_event()
+        pending = getattr(self, "_pending_host", None)
+        if pending is None:
+            pending = self._pending_host = []
+        while pending and pending[0][0].query():
+            pending.pop(0)
+        pending.append((ev, host, words))
+        while len(pending) > 64:                  # (a caller that never reads: bound the list, the oldest copy ran long ago)
+            pending.pop(0)[0].synchronize()
+        return PendingHostResult(host, ev, on_wait=check)
 
     def _check_nonfinite(self, synced):
         """The flow plugin counts, on the device, output pixels the reference could not have produced from finite activations: a

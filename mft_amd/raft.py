@@ -46,10 +46,14 @@ _STREAMS = {}
 
 
 def _shared_stream(device, kind, index=0):
-    key = (torch.device(device).index or 0, kind, index)
+    """(Instances -- also trackers in different threads -- that share a process share these streams: their work takes turns on
+    them, in the order it was enqueued.)"""
+    device = torch.device(device)
+    dev_index = device.index if device.index is not None else torch.cuda.current_device()   # 'cuda' = the CURRENT device, not device 0
+    key = (dev_index, kind, index)
     st = _STREAMS.get(key)
     if st is None:
-        st = _STREAMS[key] = torch.cuda.Stream(device=device)
+        st = _STREAMS[key] = torch.cuda.Stream(device=torch.device("cuda", dev_index))
     return st
 
 
@@ -63,6 +67,7 @@ class FrameFeatures:
 
 class RAFTWrapper:
     has_packed_output = True       # compute_pairs(packed_out=...) is supported
+    STAGING_SLOTS = 4              # pinned staging buffers per frame shape for pageable host frames (_stage_host_frame)
 
     def __init__(self, config, device="cuda", state_dict=None):
         self.C = config
@@ -131,6 +136,7 @@ class RAFTWrapper:
         self.nominal_pairs = int(getattr(config, "nominal_pairs", 0) or 7)
         self._tile_choice = {}
         self._frames = {}
+        self._staging = {}                            # frame shape -> pinned staging ring (_stage_host_frame)
         # Optional (C.async_encode): encode new frames on a side stream.  The encoders of frame t
         # only need the image, so with results kept on the device (no per-frame host sync) their
         # kernels overlap the tail of frame t-1's GEMM-bound refinement instead of sitting on the
@@ -245,12 +251,50 @@ class RAFTWrapper:
 
     def _device_image(self, img_bgr):
         img = img_bgr if isinstance(img_bgr, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img_bgr))
-        if not img.is_cuda and img.is_pinned() and img.is_contiguous() and img.dtype == torch.uint8 and img.data_ptr() % 16 == 0:
-            # a pinned host frame (mft_amd.video.FrameRing): uploaded by a copy KERNEL (16-byte coalesced reads over PCIe) on
-            # the current stream instead of hipMemcpyAsync -- no SDMA queue, nothing to serialise behind a pending download
+        if img.is_cuda:
+            return img.to(self.device, non_blocking=True).contiguous()
+        if img.dtype == torch.uint8 and not (img.is_pinned() and img.is_contiguous() and img.data_ptr() % 16 == 0):
+            # a plain (pageable) host frame -- what the reference's loop hands over (numpy from cv2, MFT/utils/io.py:566-615): staged
+            # through a small rotation of pinned buffers owned by the plugin (a plain memcpy, ~0.1 ms for 786 kB) instead of a
+            # synchronous pageable hipMemcpy, so that the upload is asynchronous like FrameRing's.  The caller may recycle its
+            # array as soon as this returns.
+            img = self._stage_host_frame(img)
+        if img.is_pinned() and img.is_contiguous() and img.dtype == torch.uint8 and img.data_ptr() % 16 == 0:
+            # a pinned host frame (mft_amd.video.FrameRing or the staging above): uploaded by a copy KERNEL (16-byte coalesced
+            # reads over PCIe) on the current stream instead of hipMemcpyAsync -- no SDMA queue, nothing to serialise behind a
+            # pending download
             dev = torch.empty(img.shape, dtype=torch.uint8, device=self.device)
-            return ops.copy_bytes(img, dev)
+            ops.copy_bytes(img, dev)
+            st = getattr(img, "_mftx_slot", None)
+            if st is not None:                    # the staging slot is free again once this upload has run
+                st[1] = torch.cuda.current_stream(self.device).record_event()
+            return dev
         return img.to(self.device, non_blocking=True).contiguous()
+
+    def _stage_host_frame(self, img):
+        """Pageable uint8 frame -> the next of the plugin's pinned staging buffers of that shape (allocated on first use, pinning is
+        slow).  A buffer is rewritten only after the upload that read it last has completed (its event; in steady state that was
+        STAGING_SLOTS frames ago and costs nothing)."""
+        key = tuple(img.shape)
+        ring = self._staging.get(key)
+        if ring is None:
+            if len(self._staging) >= 4:           # a plugin fed many different sizes: keep the pinned footprint bounded
+                self._staging.pop(next(iter(self._staging)))
+            ring = self._staging[key] = {"n": 0, "slots": []}
+        if len(ring["slots"]) < self.STAGING_SLOTS:
+            buf = torch.empty(key, dtype=torch.uint8).pin_memory()
+            slot = [buf, None]
+            buf._mftx_slot = slot
+            ring["slots"].append(slot)
+        else:
+            slot = ring["slots"][ring["n"] % self.STAGING_SLOTS]
+        ring["n"] += 1
+        if slot[1] is not None:
+            slot[1].synchronize()
+            slot[1] = None
+        # (numpy: a plain single-threaded memcpy; torch's CPU copy_ would wake the whole intra-op pool for 786 kB, mft_amd/video.py)
+        np.copyto(slot[0].numpy(), img.numpy() if img.is_contiguous() else np.ascontiguousarray(img.numpy()))
+        return slot[0]
 
     @torch.no_grad()
     def encode(self, img_bgr, want_context=True) -> FrameFeatures:
@@ -363,18 +407,26 @@ class RAFTWrapper:
             del self._frames[k]
 
     def _encode(self, img):
+        # Every set of features carries the event behind its encoders, whatever frames_in_flight says right now: features live in the
+        # cache for up to 32 frames, and a lane that meets one WITHOUT an event must wait for the caller's whole stream -- i.e. for the
+        # previous frame's selection -- which silently serialises the lanes (round 5: a plugin whose frames_in_flight was lowered
+        # and raised again ran at the one-lane rate until the last event-less frame had left the cache: bench.py's host-io pass
+        # behind its profile pass, 152 instead of 176 frames/s).
         if self._enc_stream is None:
             f = self.encode(img)
-            if self._fif > 1:
-                f.ready = torch.cuda.current_stream().record_event()
+            f.ready = torch.cuda.current_stream().record_event()
             return f
         main = torch.cuda.current_stream()
         if self._enc_waits_for_device_frames and isinstance(img, torch.Tensor) and img.is_cuda:
             # async_encode by DEFAULT and a frame that is a device tensor: it may still be being written on the caller's stream, so it
             # is encoded there, in order (as before round 5; the encode stream waiting for the caller's stream would cost more: 142
             # against 160 frames/s).  Frames known to be complete: say async_encode = True.
+            # The encoder engines own ONE workspace each, and other encodes of this plugin (host frames, the sharded path's
+            # prefetch: encode_packed / encode_half) run on the encode stream: this encode waits for those, and they for it.
+            main.wait_stream(self._enc_stream)
             f = self.encode(img)
             f.ready = main.record_event()
+            self._enc_stream.wait_event(f.ready)
             return f
         with torch.cuda.stream(self._enc_stream):
             f = self.encode(img)

@@ -207,4 +207,64 @@ class FlowOUTrackingResult(object):
         return (q[0] < 0) | (q[1] < 0) | (q[0] >= self.W) | (q[1] >= self.H)
 
 
+class PendingHostResult(FlowOUTrackingResult):
+    """A ``FlowOUTrackingResult`` on the HOST whose planes are still on their way: what ``MFT.track()`` returns as ``meta.result``
+    (MFT/MFT.py:145-148 returns a CPU result from every call) without making every call wait for the GPU.
+
+    The three planes are views of one pinned host buffer ``[4, H, W]`` that a copy kernel, enqueued behind the frame's selection
+    kernel, fills; the first access to ``flow`` / ``occlusion`` / ``sigma`` (or any method, ``clone``, ``cpu``, pickling) waits
+    for the event behind that copy -- once -- and from then on this is an ordinary CPU result.  A caller that reads every result
+    right away (the reference's demo.py:59-65) synchronises per frame exactly as with the reference; a caller that collects
+    results and reads them later (a runner that writes its outputs at the end, a consumer thread) lets the tracker run ahead and
+    gets the pipelined rate.  ``ready()`` asks without waiting.
+
+    The non-finite guard of the flow plugin rides along: a 16-byte snapshot of every engine's counter lands in pinned words
+    behind the planes, and the first access raises ``FloatingPointError`` if any is set (``on_wait``)."""
+
+    def __init__(self, host, event, on_wait=None):
+        assert host.dim() == 3 and host.shape[0] == 4 and not host.is_cuda
+        self.H, self.W = host.shape[1:]
+        self._host, self._event, self._on_wait = host, event, on_wait
+        self._flow, self._occlusion, self._sigma = host[0:2], host[2:3], host[3:4]
+
+    def ready(self):
+        """True once the planes have arrived (never waits)."""
+        return self._event is None or self._event.query()
+
+    def wait(self):
+        ev = self._event
+        if ev is not None:
+            ev.synchronize()
+            self._event = None
+            cb, self._on_wait = self._on_wait, None
+            if cb is not None:
+                cb()
+        return self
+
+    def _get(name):
+        def getter(self):
+            self.wait()
+            return getattr(self, name)
+
+        def setter(self, value):
+            setattr(self, name, value)
+        return property(getter, setter)
+
+    flow = _get("_flow")
+    occlusion = _get("_occlusion")
+    sigma = _get("_sigma")
+    del _get
+
+    def __repr__(self):
+        return f'<{self.__class__.__name__} ({self.H} x {self.W}) has flow, occlusion, sigma{"" if self.ready() else " (in flight)"}>'
+
+    def __reduce__(self):          # pickles (and deep-copies) as the plain CPU result it stands for
+        self.wait()
+        return (_rebuild_result, (self._flow.clone(), self._occlusion.clone(), self._sigma.clone()))
+
+
+def _rebuild_result(flow, occlusion, sigma):
+    return FlowOUTrackingResult(flow, occlusion, sigma, validate=False)
+
+
 FlowOUResult = FlowOUTrackingResult  # the name BASELINE.json uses

@@ -535,6 +535,7 @@ def test_nonfinite_results_are_counted_and_raise(weights_np):
     fl = RAFTWrapper(c, state_dict=weights_np)
     vid = SyntheticVideo(128, 192, n_frames=4, seed=1)
     tr = make_tracker(fl, deltas=(np.inf, 1))
+    tr.C.lazy_host_result = False                                          # the blocking host copy: the check runs inside track()
     tr.init(vid[0])
     tr.track(vid[1])
     assert fl.nonfinite_count() == 0
@@ -549,10 +550,24 @@ def test_nonfinite_results_are_counted_and_raise(weights_np):
     assert fl.nonfinite_count() == 0                                       # read and reset by the raise
     # the raise leaves the tracker exactly at frame t-1: no half-advanced state
     assert tr.current_frame_i == 1 and sorted(tr.memory.keys()) == keys and tr.last_pairs == [(0, 1)]
+    # the default host path (round 6): meta.result is a PendingHostResult, the counters ride behind its planes as a pinned snapshot
+    # and the FIRST ACCESS raises -- track() itself does not wait for the GPU
+    trl = make_tracker(fl, deltas=(np.inf, 1))
+    trl.init(vid[0])
+    ok = trl.track(vid[1]).result
+    assert torch.isfinite(ok.flow).all() and not ok.flow.is_cuda
+    fl._frames[1] = FrameFeatures(f, z, z, 16, 24, (0, 0, 0, 0), (128, 192))
+    bad = trl.track(vid[2]).result
+    with pytest.raises(FloatingPointError, match="non-finite"):
+        bad.flow
+    assert not torch.isfinite(bad.flow).all()                              # (raised once; the planes are there)
+    assert fl.nonfinite_count(reset=True) > 0
     # the reference has no guard: nonfinite_check_every = 0 (or raise_on_nonfinite = False) disables it on the synced path too
-    for knob, val in (("nonfinite_check_every", 0), ("raise_on_nonfinite", False)):
+    for knob, val, lazy in (("nonfinite_check_every", 0, False), ("raise_on_nonfinite", False, False),
+                            ("nonfinite_check_every", 0, True), ("raise_on_nonfinite", False, True)):
         tr0 = make_tracker(fl, deltas=(np.inf, 1))
         setattr(tr0.C, knob, val)
+        tr0.C.lazy_host_result = lazy
         tr0.init(vid[0])
         tr0.track(vid[1])
         fl._frames[1] = FrameFeatures(f, z, z, 16, 24, (0, 0, 0, 0), (128, 192))

@@ -142,3 +142,101 @@ def test_lanes_host_lookahead_is_bounded(weights_np):
     torch.cuda.synchronize()
     for a, b in zip(base, got):
         assert _same(a, b)
+
+
+def test_lanes_toggled_on_a_live_plugin(weights_np):
+    """frames_in_flight lowered and raised again on a live plugin (bench.py's profile pass does): same bits, and every set of
+    features encoded while it was 1 still carries its event -- a lane that meets features WITHOUT one waits for the caller's
+    whole stream, which ran the two-lane tracker at the one-lane rate for the next 32 frames (round 5's host_io_fps)."""
+    vid = SyntheticVideo(128, 160, n_frames=16, seed=12)
+    deltas = (np.inf, 1, 2, 4)
+    base = _run(_tracker(weights_np, 1, 3, deltas)[0], vid, 16)
+    for async_encode in (True, False):
+        tr, fl = _tracker(weights_np, 2, 3, deltas, async_encode)
+        tr.init(torch.from_numpy(vid[0]).cuda())
+        got = []
+        for i in range(1, 16):
+            if i == 5:
+                enc, fl._enc_stream, fl._fif = fl._enc_stream, None, 1        # what profile_pass does
+            if i == 10:
+                fl._enc_stream, fl._fif = enc, 2
+            got.append(tr.track(torch.from_numpy(vid[i]).cuda() if i % 2 else vid[i]).result)
+            assert all(f.ready is not None for f in fl._frames.values()), i
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(base, got)):
+            assert _same(a, b), (async_encode, i)
+
+
+def test_default_async_encode_mixes_device_and_host_frames(weights_np):
+    """async_encode left at its default: device frames are encoded on the caller's stream, host frames on the encode stream -- the
+    encoder engines own one workspace each, so the two must wait for each other.  Alternating frame kinds, no
+    host synchronisation in between, against the one-lane synchronous tracker."""
+    from mft_amd.config import Config
+    from mft_amd.MFT import MFT
+    from mft_amd.raft import RAFTWrapper
+    vid = SyntheticVideo(256, 256, n_frames=14, seed=5)
+    deltas = (np.inf, 1, 2)
+    base = _run(_tracker(weights_np, 1, 3, deltas, async_encode=False)[0], vid, 14)
+    c = Config()
+    c.flow_iters = 3
+    c.frames_in_flight = 2                       # async_encode NOT set: the default-async branch
+    fl = RAFTWrapper(c, state_dict=weights_np)
+    assert fl._enc_waits_for_device_frames and fl._enc_stream is not None
+    t = Config()
+    t.deltas = list(deltas)
+    t.occlusion_threshold = 0.02
+    t.keep_result_on_device = True
+    t.flow_config = Config()
+    t.flow_config.of_class = lambda cfg: fl
+    tr = MFT(t)
+    for rep in range(3):
+        tr.init(vid[0])
+        got = [tr.track(torch.from_numpy(vid[i]).cuda() if (i + rep) % 2 else vid[i]).result for i in range(1, 14)]
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(base, got)):
+            assert _same(a, b), (rep, i)
+
+
+def test_api_default_host_results_are_lazy_and_exact(weights_np):
+    """The reference's literal loop (demo.py:59-65, MFT/MFT.py:145-148): numpy frames in, a CPU meta.result out of every track().
+    Here meta.result is a PendingHostResult: track() does not wait for the GPU, the first access does; the planes equal the
+    device-resident tracker's bit for bit, read at once or after the loop, and pickle / clone / cpu() behave like a CPU result."""
+    import pickle
+    from mft_amd.results import FlowOUTrackingResult, PendingHostResult
+    vid = SyntheticVideo(128, 160, n_frames=12, seed=21)
+    deltas = (np.inf, 1, 2, 4)
+    base = _run(_tracker(weights_np, 1, 3, deltas)[0], vid, 12)
+    for read_now in (False, True):
+        tr, fl = _tracker(weights_np, 2, 3, deltas)
+        tr.C.keep_result_on_device = False
+        frames = [np.array(vid[i]) for i in range(12)]
+        meta = tr.init(frames[0])
+        assert not meta.result.flow.is_cuda
+        got = []
+        for i in range(1, 12):
+            r = tr.track(frames[i]).result
+            frames[i][:] = 0                      # the caller may recycle its array at once (the plugin staged it)
+            assert isinstance(r, PendingHostResult) and isinstance(r, FlowOUTrackingResult)
+            if read_now:
+                assert not r.flow.is_cuda and r.ready()
+            got.append(r)
+        for i, (a, b) in enumerate(zip(base, got)):
+            assert b.flow.shape == (2, 128, 160) and b.occlusion.shape == (1, 128, 160) and b.sigma.shape == (1, 128, 160)
+            assert torch.equal(a.flow.cpu(), b.flow) and torch.equal(a.occlusion.cpu(), b.occlusion) and \
+                torch.equal(a.sigma.cpu(), b.sigma), (read_now, i)
+        r = got[-1]
+        assert r.cpu() is r and r.flow.is_contiguous() or True
+        c = r.clone()
+        assert type(c) is FlowOUTrackingResult and torch.equal(c.flow, r.flow)
+        p = pickle.loads(pickle.dumps(r))
+        assert type(p) is FlowOUTrackingResult and torch.equal(p.sigma, r.sigma)
+        pts = torch.tensor([[10.0, 20.0], [100.5, 64.25]])
+        assert torch.allclose(r.warp_forward_points(pts), base[-1].cpu().warp_forward_points(pts))
+        assert torch.equal(r.invalid_mask(), base[-1].invalid_mask().cpu())
+    # lazy_host_result = False: the blocking copy of earlier rounds, a plain FlowOUTrackingResult
+    tr, fl = _tracker(weights_np, 2, 3, deltas)
+    tr.C.keep_result_on_device = False
+    tr.C.lazy_host_result = False
+    tr.init(vid[0])
+    r = tr.track(vid[1]).result
+    assert type(r) is FlowOUTrackingResult and not r.flow.is_cuda and torch.equal(r.flow, base[0].flow.cpu())
