@@ -87,3 +87,30 @@ def test_chain_select_and_tracker_are_deterministic_under_contention():
     for run in (a, b):
         assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-2000:]        # (non-zero: more than one distinct result overall)
         assert re.search(r"overall distinct 1$", run.stdout, re.M), run.stdout[-2000:]
+
+
+@pytest.mark.timeout(900)
+def test_masked_gather_kernels_are_deterministic_under_contention():
+    """Round 6: the kernels OUTSIDE chain.hip that gather behind bounds tests -- stand-alone lookup, on-demand lookup, convex
+    upsampler, both encoders, the cache codec -- at the benchmark's size, 1500 launches each on fixed inputs beside two load
+    generators: one distinct result each (tools/race_masked.py).  Their translation units carry no packed-fp32 instruction
+    (csrc/Makefile NOPK; tests/test_host_logic.py::test_masked_gather_units_carry_no_packed_fp32_code)."""
+    py = sys.executable
+    loads = [subprocess.Popen([py, str(REPO / "tools" / "race_kernels.py"), "--load-seconds", "110", "--tag", f"load{i}"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for i in range(2)]
+    try:
+        time.sleep(8)
+        m = subprocess.run([py, str(REPO / "tools" / "race_masked.py"), "1500"], capture_output=True, text=True, timeout=600)
+    finally:
+        outs = []
+        for p in loads:
+            try:
+                outs.append(p.communicate(timeout=180)[0])
+            except subprocess.TimeoutExpired:
+                p.kill()
+                outs.append("")
+    done = [int(x.group(1)) for o in outs for x in re.finditer(r"load: (\d+) refinements", o)]
+    assert len(done) == 2 and min(done) > 100, outs
+    kinds = re.findall(r"^(\S.*?)\s+distinct\s+(\d+) \[", m.stdout, re.M)
+    assert len(kinds) == 6 and all(int(n) == 1 for _, n in kinds), m.stdout + m.stderr[-2000:]
+    assert m.returncode == 0
