@@ -229,6 +229,41 @@ def api_default_pass(args, host_frames, n):
     return out
 
 
+def rank_diagnostics(tracker, window, H, W, world, rank, backend):
+    """What the first real multi-GPU run needs to be self-diagnosing: per rank the device, the hardware-queue setting and whether it
+    could take effect, the collective backend, and the time of the job's two all-gathers ALONE at this window's payload sizes (HIP
+    events on the current stream, 5 repeats behind 2 warm-ups) -- the wire time the emulation (--emulate-world) leaves out."""
+    import mft_amd
+    from mft_amd.dist import split_units
+    h, w = -(-H // 8), -(-W // 8)
+    slots_f = -(-window // world)
+    slots_u = max(c for _, c in split_units(FULL_PAIRS * window, world))
+    d = {"rank": rank, "device": torch.cuda.current_device(), "device_name": torch.cuda.get_device_name(),
+         "backend": backend, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "hw_queues": dict(mft_amd.HW_QUEUES),
+         "frames_in_flight": int(getattr(tracker.flower, "_fif", 1)),
+         "sharder": dict(getattr(tracker.sharder, "stats", {}))}
+    fake = not hasattr(dist, "get_backend")                       # --emulate-world replaced the collectives by local copies
+    for name, numel in (("features_all_gather", slots_f * h * w * 512), ("flowou_all_gather", slots_u * H * W * 4)):
+        send = torch.zeros(numel, dtype=torch.float32, device="cuda")
+        recv = torch.empty(world * numel, dtype=torch.float32, device="cuda")
+        if fake:
+            d[name] = {"bytes_sent_per_rank": 4 * numel, "bytes_gathered": 4 * numel * world, "us": None, "note": "emulated: no wire"}
+            continue
+        for _ in range(2):
+            dist.all_gather_into_tensor(recv, send)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            dist.all_gather_into_tensor(recv, send)
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / 5
+        d[name] = {"bytes_sent_per_rank": 4 * numel, "bytes_gathered": 4 * numel * world, "us": us,
+                   "bytes_per_us_received": 4 * numel * (world - 1) / us if us > 0 else None}
+    return d
+
+
 def build_hash():
     """sha256 (first 16 hex digits) of the library this process runs: ties a counter file to the build it was measured on."""
     import hashlib
@@ -280,18 +315,24 @@ def cpu_baseline(args, vid):
         tr.memory[i] = dict(img=vid[i], result=ident)
     tr.cur = 32
     first_meta = None
+    per_frame = []
     with torch.no_grad():
         t0 = time.perf_counter()
         for i in range(33, 33 + n):
+            t1 = time.perf_counter()
             meta = tr.track(vid[i])
+            per_frame.append(time.perf_counter() - t1)
             assert len(meta.pairs) == FULL_PAIRS
             first_meta = first_meta or meta
         dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": cores, "host_cores": host_cores(), "kind": "port",
             "sample": f"{n} steady-state frames (7 flow pairs x {args.iters} iters + chain + select each) of the same "
                       f"{H}x{W} synthetic video; oracle/mft_oracle.py on torch CPU ops, {cores} threads "
-                      f"(thread sweep: profiles/r2_cpu_thread_sweep.txt), {dt:.1f} s",
-            "s_per_frame": dt / n,
+                      f"(thread sweep: profiles/r2_cpu_thread_sweep.txt), {dt:.1f} s.  The sample is bounded to the ~10-30 s of CPU "
+                      f"work the bench contract allows (a frame takes ~3.5 s: 20 frames would be ~70 s; --cpu-frames 20 runs them, "
+                      f"profiles/r6*_cpu_baseline_20.json); every frame is a steady-state frame (memory ring pre-filled), frame_s "
+                      f"lists them",
+            "s_per_frame": dt / n, "frame_s": [round(x, 3) for x in per_frame],
             "stage_s_per_frame": {k: v / n for k, v in stages.items()}}, first_meta
 
 
@@ -436,7 +477,9 @@ def main():
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--window", type=int, default=0,
                     help="multi-GPU look-ahead window in frames (0 = one per GPU; 1 = per-frame delta sharding)")
-    ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--cpu-frames", type=int, default=6,
+                    help="steady-state frames the CPU oracle is timed on (~3.5 s each on 16 threads; the default keeps the leg within "
+                         "the ~10-30 s the bench contract allows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size EPE check against the CPU oracle")
@@ -559,11 +602,19 @@ def main():
 
     kernels, prof_pairs = {}, []
     ranks_seen = 1
+    rank_diag = None
     if sharded:
         # what the collectives themselves say about the job: every rank contributes a one
         ones = torch.ones(1, device="cuda", dtype=torch.float32)
         dist.all_reduce(ones)
         ranks_seen = int(round(float(ones.item())))
+        mine = rank_diagnostics(tracker, window, args.height, args.width, args.emulate_world or world, rank, backend)
+        print("[bench rank %d] %s" % (rank, json.dumps(mine)), file=sys.stderr, flush=True)
+        if world > 1:
+            rank_diag = [None] * world
+            dist.all_gather_object(rank_diag, mine)
+        else:
+            rank_diag = [mine]
     if n_prof and not sharded:
         kernels, prof_pairs = profile_pass(tracker, frames, first + args.steps, n_prof, args.arith)
         torch.cuda.synchronize()
@@ -605,6 +656,7 @@ def main():
             "emulated_world": (args.emulate_world or None),
             **({"invalid_ab": "encoders skipped (--ab-skip-encoders): an upper bound, not a measurement"} if args.ab_skip_encoders else {}),
             "ranks_seen": ranks_seen,          # sum over ranks of 1, by all-reduce (1 without a process group)
+            **({"ranks": rank_diag} if rank_diag is not None else {}),
             "host_enqueue_ms_per_step": (float(np.mean(host_ms)) if host_ms else None),
             "pairs_per_frame": {"warmup": warm_pairs, "timed_min": min(timed_pairs), "timed_max": max(timed_pairs),
                                 "timed_mean": float(np.mean(timed_pairs)), "profile_pass_min": min(prof_pairs, default=None)},

@@ -195,6 +195,23 @@ class RAFTWrapper:
         self._lane_next += 1
         return lane
 
+    def _lanes_fit(self, P, h, w):
+        """Every lane beyond the first owns a workspace of its own (1.1 GB at 7 pairs of 512 x 512, 43 GB at 7 pairs of 1080p): before
+        a lane allocates one, check that it fits into what the device has free NEXT TO what is already allocated (a flow cache's HBM
+        tier, the caller's own tensors) with a tenth of the device kept in reserve -- otherwise run with the lanes that exist
+        (frames_in_flight is lowered for this plugin, logged once) instead of failing in the middle of a sequence."""
+        while self._fif > max(1, len(self._lanes)):
+            k = max(1, len(self._lanes))              # the lane the next _lane() call would create first (lane 0 is the plugin's first
+            need = int(ops._lib.load().mftx_raft_workspace_bytes_for(self.engine._h, P, h, w))   # engine: needed whatever the setting)
+            free, total = torch.cuda.mem_get_info(self.device)
+            cached = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)   # (torch's pool can be re-used)
+            if need <= free + cached - total // 10:
+                return
+            logger.warning("frames_in_flight = %d needs %.1f GB more workspace (lane %d, %d pairs of %d x %d cells) but only %.1f GB of "
+                           "the device's %.1f GB are free: running with %d frame(s) in flight", self._fif, need / 1e9, k, P, h, w,
+                           (free + cached) / 1e9, total / 1e9, k)
+            self._fif = k
+
     def nonfinite_count(self, reset=False):
         """Non-finite output pixels counted on the device since the last reset, over all engines of this plugin."""
         return sum(e.nonfinite_count(reset=reset) for e in self._all_engines())
@@ -511,10 +528,11 @@ class RAFTWrapper:
         """One batch on the next lane of C.frames_in_flight (see __init__): the lane's stream waits for the frames' features
         only, the caller's stream for the lane -- whatever else is queued on the caller's stream (the previous frame's chaining
         and selection, result copies) does not hold the batch back."""
-        eng, st = self._lane()
-        main = torch.cuda.current_stream(self.device)
         P = len(fls)
         H0, W0 = geom.shape
+        self._lanes_fit(P, geom.h, geom.w)
+        eng, st = self._lane()
+        main = torch.cuda.current_stream(self.device)
         self._pin_kernels(geom.h, geom.w)
         if self._lanes_stale:                         # an engine ran on the caller's stream since the lanes last did: order them behind it
             for _, s_ in self._lanes:

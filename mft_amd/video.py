@@ -223,8 +223,11 @@ class ResultDrain:
                 h.copy_(t, non_blocking=True)
         words = None
         if self._nf_src is not None:
-            while len(self._nf_words) <= slot:
-                self._nf_words.append(torch.zeros(8, 4, dtype=torch.int32).pin_memory())
+            rows = len(self._nf_src._all_engines()) if hasattr(self._nf_src, "_all_engines") else 8     # one row per engine: the
+            while len(self._nf_words) <= slot:                       # plugin's split parts and lanes are user-configurable
+                self._nf_words.append(None)
+            if self._nf_words[slot] is None or self._nf_words[slot].shape[0] < rows:
+                self._nf_words[slot] = torch.zeros(max(8, rows), 4, dtype=torch.int32).pin_memory()
             words = self._nf_words[slot]
             self._nf_src.nonfinite_snapshot(words)
         ev = torch.cuda.Event()

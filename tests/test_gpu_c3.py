@@ -68,14 +68,15 @@ class OracleMFT:
     reference's cache protocol around its flow calls (MFT/MFT.py:99-102, 205-231: finite deltas read and write the cache, the
     delta = infinity candidate -- the one whose left frame is the start frame -- bypasses it)."""
 
-    def __init__(self, sd, log):
+    def __init__(self, sd, log, deltas=None, iters=ITERS):
         self.sd, self.log = sd, log
+        self.deltas, self.iters = list(deltas if deltas is not None else DELTAS), iters
         self.memo = {}                      # (hash of the video is implicit: one instance per sequence)
 
     def _raft(self, l, r, li, ri):
         if (l, r) not in self.memo:
             with torch.no_grad():
-                self.memo[(l, r)] = O.compute_flow(self.sd, li, ri, ITERS)
+                self.memo[(l, r)] = O.compute_flow(self.sd, li, ri, self.iters)
         return self.memo[(l, r)]
 
     def _flow(self, l, r, li, ri):
@@ -92,7 +93,7 @@ class OracleMFT:
 
     def init(self, img, start_frame_i=0, time_direction=1, flow_cache=None, **kw):
         self.cache = flow_cache
-        self.tr = O.Tracker(self._flow, deltas=DELTAS, occlusion_threshold=0.02)
+        self.tr = O.Tracker(self._flow, deltas=self.deltas, occlusion_threshold=0.02)
         m = self.tr.init(img, start_frame_i, time_direction)
         return SimpleNamespace(result=FlowOUTrackingResult(*m.result))
 
@@ -174,6 +175,54 @@ def test_c3_tapvid_protocol_vs_oracle(tmp_path):
         for k in ("average_jaccard", "average_pts_within_thresh", "occlusion_accuracy"):
             assert abs(a[k] - b[k]) <= 0.01, (mode, k, a[k], b[k])
     assert (tmp_path / "export" / conf.name / "eval" / "tapvid-eval-strided.pklz").exists()
+
+
+@pytest.mark.timeout(900)
+def test_c3_all_seven_deltas_strided_forward_and_backward_vs_oracle(tmp_path):
+    """The protocol with the reference's FULL delta set: a 128 x 128 sequence of 40 frames through the
+    reader's '256x256' scaling (tracked on the 256 raster), 'strided' queries, i.e. every start frame tracked forward AND
+    backward, all of {inf, 1, 2, 4, 8, 16, 32} live (delta 32 from the 33rd frame of a run on: forward from frame 0, backward
+    from frame 35), one flow cache shared by all runs -- the HIP tracker against the oracle tracker: the same (left, right) pairs
+    per tracked frame, the same cache reads / hits / writes, tracks and occlusion scores on the 256 raster.  The query frames
+    are chosen (0 and 35) instead of sampled every fifth frame: 74 tracked frames and ~430 distinct oracle pairs instead of
+    8 x 39 frames."""
+    torch.set_num_threads(16)
+    deltas = [np.inf, 1, 2, 4, 8, 16, 32]
+    vid = SyntheticVideo(128, 128, n_frames=40, seed=41)
+    tapvid.synthetic_pickle(tmp_path / "d.pkl", {"seq": vid}, n_tracks=10, seed=9)
+    (el,) = list(tapvid.create_tapvid_dataset(tmp_path / "d.pkl", ["strided"], "256x256"))
+    video = np.ascontiguousarray(el["data"]["strided"]["video"][0][..., ::-1])
+    assert video.shape == (40, 256, 256, 3)
+    rng = np.random.default_rng(3)
+    queries = np.concatenate([np.stack([np.full(6, t), rng.integers(8, 248, 6), rng.integers(8, 248, 6)], 1) for t in (0, 35)])
+    conf = load_config(REPO / "configs" / "MFT_cfg.py")
+    conf.flow_config.model, conf.flow_config.synthetic_weights_seed, conf.flow_config.flow_iters = None, 0, ITERS
+    assert list(conf.deltas) == deltas                                            # the shipped configuration IS the full set
+    conf.keep_result_on_device = True
+    tracker = conf.tracker_class(conf)
+    hip_pairs = []
+    orig_track = tracker.track
+
+    def track(img, **kw):
+        m = orig_track(img, **kw)
+        hip_pairs.append(sorted(tracker.last_pairs))
+        return m
+    tracker.track = track
+    cache = CountingCache(tmp_path / "cache", max_RAM_MB=512, max_GPU_RAM_MB=1024)
+    hip = tapvid.run_sequence(tracker, video, queries, "strided", flow_cache=cache, device="cuda")
+    sd = {k: torch.from_numpy(v) for k, v in make_weights(0).items()}
+    ora_pairs = []
+    ocache = OracleCache()
+    want = tapvid.run_sequence(OracleMFT(sd, ora_pairs, deltas=deltas), video, queries, "strided", flow_cache=ocache)
+    assert hip_pairs == ora_pairs and len(hip_pairs) == 39 + 4 + 35
+    assert max(len(p) for p in hip_pairs) == 7                                      # every delta live, in both directions
+    assert sum(len(p) == 7 for p in hip_pairs[:39]) == 7 and sum(len(p) == 7 for p in hip_pairs[43:]) == 3
+    assert cache.reads == ocache.reads and cache.writes == ocache.writes and cache.hits == ocache.hits
+    assert ocache.hits >= 3
+    d = np.abs(hip["tracks"] - want["tracks"]).max(-1)
+    assert (d <= 1e-3).mean() >= 0.99, (float((d <= 1e-3).mean()), float(d.max()))
+    do = np.abs(hip["occluded"] - want["occluded"])
+    assert (do <= 1e-4).mean() >= 0.99, (float((do <= 1e-4).mean()), float(do.max()))
 
 
 def test_c3_runner_cont_and_flow_export(tmp_path):

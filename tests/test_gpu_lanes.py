@@ -240,3 +240,23 @@ def test_api_default_host_results_are_lazy_and_exact(weights_np):
     tr.init(vid[0])
     r = tr.track(vid[1]).result
     assert type(r) is FlowOUTrackingResult and not r.flow.is_cuda and torch.equal(r.flow, base[0].flow.cpu())
+
+
+def test_extra_lane_is_refused_when_its_workspace_does_not_fit(weights_np, monkeypatch, caplog):
+    """Every lane beyond the first owns a workspace (43 GB at 7 pairs of 1080p): when the device has no room for it next to what is
+    already allocated, the plugin keeps running with the lanes it has -- logged -- instead of failing mid-sequence; same bits."""
+    import logging
+    vid = SyntheticVideo(128, 160, n_frames=8, seed=2)
+    deltas = (np.inf, 1, 2)
+    base = _run(_tracker(weights_np, 1, 3, deltas)[0], vid, 8)
+    tr, fl = _tracker(weights_np, 2, 3, deltas)
+    total = torch.cuda.mem_get_info()[1]
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda device=None: (total // 20, total))     # 5 % free: below the reserve
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda device=None: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda device=None: 0)
+    with caplog.at_level(logging.WARNING, logger="mft_amd.raft"):
+        got = _run(tr, vid, 8)
+    assert fl._fif == 1 and len(fl._lanes) == 1
+    assert any("frames_in_flight" in r.message for r in caplog.records)
+    for a, b in zip(base, got):
+        assert _same(a, b)

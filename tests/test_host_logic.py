@@ -462,3 +462,28 @@ def test_masked_gather_units_carry_no_packed_fp32_code(unit):
     assert out.returncode == 0, out.stderr[-2000:]
     assert "s_and_saveexec" in out.stdout
     assert not re.search(r"\bv_pk_\w+", out.stdout), re.findall(r"\bv_pk_\w+", out.stdout)[:5]
+
+
+def test_import_after_hip_initialisation_warns(monkeypatch):
+    """GPU_MAX_HW_QUEUES is read by the HIP runtime when it initialises: set at package import it is a silent no-op if a GPU call came
+    first (hygiene).  The package now says so -- and records what became of the setting in mft_amd.HW_QUEUES."""
+    import importlib
+    import warnings
+    import torch
+    import mft_amd
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        importlib.reload(mft_amd)
+    assert any("GPU_MAX_HW_QUEUES" in str(x.message) for x in w)
+    assert mft_amd.HW_QUEUES == {"explicit": False, "too_late": True, "value": "8"}
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "6")                 # an explicit setting wins and is not second-guessed
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        importlib.reload(mft_amd)
+    assert not w and mft_amd.HW_QUEUES == {"explicit": True, "too_late": False, "value": "6"}
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: False)
+    importlib.reload(mft_amd)
+    assert mft_amd.HW_QUEUES == {"explicit": False, "too_late": False, "value": "8"}
