@@ -1,5 +1,7 @@
 """Parity of every libmftx kernel (called through the C ABI) against the CPU
 oracle and the reference-generated golden vectors.  Needs an MI355X."""
+import re
+
 import numpy as np
 import pytest
 import torch
@@ -1470,3 +1472,27 @@ def test_round4_entry_points_argument_errors(ops_mod):
     assert lib.mftx_raft_set_nonfinite_counter(eng._h, z.data_ptr() + 2) == -2
     assert lib.mftx_raft_clear_graphs(None) == -4 and lib.mftx_raft_clear_graphs(eng._h) == 0
     assert lib.mftx_tile_conv_fills_chip(0, 64, 64) == 0 and lib.mftx_tile_conv_fills_chip(7, 64, 64) == 1
+
+
+@pytest.mark.timeout(600)
+def test_lookup_convc1_wide_variant():
+    """Round 6: the fused lookup that gathers in 16-byte pieces (csrc/lookup_convc1_wide.hip -> mft_amd/libmftx_lfwide.so, built by
+    __graft_entry__.build(); NOT the default: profiles/r6d_lookup_wide_gather.txt) stays parity-green: the fused-lookup tests -- vs the
+    two kernels it replaces and fp64 at odd grids / ragged tiles / wild coordinates (levels with a width that is not a multiple of 4
+    take its dword path), batch and tile invariance, stale LDS, the engine with it against the engine without, update-block goldens,
+    one compute_flow golden -- in a process that loads the variant library."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parents[1]
+    lib = repo / "mft_amd" / "libmftx_lfwide.so"
+    assert lib.exists(), "run __graft_entry__.build() (make -C mft_amd/csrc lfwide)"
+    env = dict(os.environ, MFTX_LIB=str(lib))
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                          str(repo / "tests" / "test_gpu_kernels.py"), str(repo / "tests" / "test_gpu_e2e.py"),
+                          "-k", "(lookup_convc1 and not wide_variant) or engine_fused_lookup or update_block_and_ou_heads or compute_flow_vs_golden"],
+                         capture_output=True, text=True, env=env, timeout=550)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1500:]
+    m = re.search(r"(\d+) passed", out.stdout)
+    assert m and int(m.group(1)) >= 12, out.stdout[-500:]

@@ -487,3 +487,16 @@ def test_import_after_hip_initialisation_warns(monkeypatch):
     monkeypatch.setattr(torch.cuda, "is_initialized", lambda: False)
     importlib.reload(mft_amd)
     assert mft_amd.HW_QUEUES == {"explicit": False, "too_late": False, "value": "8"}
+
+
+def test_variant_library_exports_the_same_symbols():
+    """mft_amd/libmftx_lfwide.so (the fused lookup with 16-byte gathers, `make lfwide`) is a drop-in for libmftx.so: every symbol of
+    include/mftx.h resolves in it too."""
+    import ctypes
+    lib = REPO / "mft_amd" / "libmftx_lfwide.so"
+    if not lib.exists():
+        pytest.skip("variant library not built (make -C mft_amd/csrc lfwide)")
+    names = re.findall(r"\b(mftx_\w+)\s*\(", (REPO / "include" / "mftx.h").read_text())
+    h = ctypes.CDLL(str(lib))
+    missing = [n for n in sorted(set(names)) if not hasattr(h, n)]
+    assert not missing, missing

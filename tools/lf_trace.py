@@ -12,7 +12,8 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from mft_amd import _lib, ops  # noqa: E402
 
-NAMES = {1: "start", 2: "coords0", 3: "gather>", 4: "waited", 5: "convert>", 6: "bar<", 7: "bar>", 8: "mfma>", 9: "epi>"}
+NAMES = {1: "start", 2: "coords0", 3: "gather>", 4: "waited", 5: "convert>", 6: "bar<", 7: "bar>", 8: "mfma>", 9: "epi>",
+         10: "table>", 11: "waited", 12: "taps>"}
 P, h, w = 7, 64, 64
 dev = "cuda"
 g = torch.Generator().manual_seed(0)
@@ -43,7 +44,8 @@ for wv in (0, 4):
     print(f"wave {wv} ({'consumer' if wv < 4 else 'producer'}), kilo-cycles:")
     print("   " + "  ".join(f"{NAMES.get(c, c)}@{(t - t0) / 1000:.1f}" for c, t in ev[wv]))
 prod = ev[4]
-for name, code in (("gather", 3), ("convert", 5), ("wait", 4)):
+for name, code in (("gather", 3), ("table (bar> .. table>)", 10), ("gather wait (table> .. waited)", 11), ("tap reads (waited .. taps>)", 12),
+                   ("DMA issue + conversion (taps> .. convert>)", 5)):
     d = [prod[i][1] - prod[i - 1][1] for i in range(1, len(prod)) if prod[i][0] == code]
     if d:
         print(f"producer {name}: median {sorted(d)[len(d) // 2]} cycles over {len(d)}")
