@@ -184,7 +184,11 @@ int mftx_conv2d_tile(const mftx_conv_desc *d, int tile, void *stream);
  * input of an output tile of 128 cells is loaded into LDS ONCE, the weights stream from L2 into registers; no LDS ring,
  * no barrier in the K loop.  Results agree with mftx_conv2d to fp32 rounding of the K sum (not bit for bit).
  * wtile: N * taps * cin * 4 bytes (16-byte aligned) filled by mftx_pack_tile_conv_weights from the layer's weight in the
- * mftx_conv2d packing wpk = [>= N rows][taps][cin_pad] fp32.  d->wpk is ignored. */
+ * mftx_conv2d packing wpk = [>= N rows][taps][cin_pad] fp32.  d->wpk is ignored.
+ * Round 6: 3 x 3 over 256 channels (c0 = 256, one segment; the motion encoder's convc2 and conv, core/update.py:152-160) -- the
+ * tile goes through LDS in TWO channel passes of 128 with the accumulators kept; N = 192, or an even N <= 128 (conv's 126:
+ * channels >= N of the 128-wide output rows are left untouched); relu, split-form output, bias required.  Pack with
+ * mftx_pack_tile_conv_weights(wpk, 192 | 128, 9, 256, cin_pad, ...). */
 int mftx_pack_tile_conv_weights(const float *wpk, int N, int taps, int cin, int cin_pad, void *wtile, void *stream);
 int mftx_tile_conv2d(const mftx_conv_desc *d, const void *wtile, void *stream);
 /* The occlusion and uncertainty heads (core/update.py:177-214, 17-75: per head conv3x3 712 -> 128, relu, conv3x3 128 -> 2 | 1; the
@@ -310,7 +314,10 @@ int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
  *   MFTX_RAFT_OPT_TILE_CELLS 0 default (cells per tile of the tile-resident kernels by how the tiles fill the chip: 128, else 64, else
  *                            32), or 128 / 64 / 32 forced.  Same bits whatever the value: a smaller tile is fewer MFMA row tiles per wave.
  *   MFTX_RAFT_OPT_FUSE_OU    1 default (where the tile-resident layers run and mftx_raft_set_ou_heads has been called: the occlusion and
- *                            uncertainty heads as mftx_ou_heads), 0 the 712 -> 256 GEMM on mftx_conv2d + the small-N kernel */
+ *                            uncertainty heads as mftx_ou_heads), 0 the 712 -> 256 GEMM on mftx_conv2d + the small-N kernel
+ *   MFTX_RAFT_OPT_TILE_CONV2P 1 default (where the tile-resident layers run and their streams are set: convc2 and conv of the motion
+ *                            encoder -- 3 x 3 over 256 channels -- tile-resident in two channel passes, csrc/tile_conv.hip
+ *                            tile_conv2p_kernel), 0 on mftx_conv2d's ring-buffered kernel.  fp32 rounding of the K sums apart. */
 #define MFTX_RAFT_OPT_FORK 0
 #define MFTX_RAFT_OPT_PRESPLIT 1
 #define MFTX_RAFT_OPT_GROUP 2
@@ -323,6 +330,7 @@ int mftx_raft_set_coords_trace(mftx_raft *r, float *trace);
 #define MFTX_RAFT_OPT_FUSE_GRU 9
 #define MFTX_RAFT_OPT_TILE_CELLS 10
 #define MFTX_RAFT_OPT_FUSE_OU 11
+#define MFTX_RAFT_OPT_TILE_CONV2P 12
 int mftx_raft_set_option(mftx_raft *r, int option, int value);
 /* A device-resident counter (4 bytes, zeroed by the caller) that the last kernel of every mftx_raft_refine* call increments
  * by the number of output pixels with a non-finite flow / occlusion / sigma; null switches it off.  The reference has no

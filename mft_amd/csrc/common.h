@@ -185,6 +185,10 @@ struct GruHalfLaunch {
 };
 int launch_gru_half(const GruHalfLaunch &d, hipStream_t s);
 int launch_pack_flow_head(const float *w2pk, void *out, hipStream_t s);
+// 3 x 3 over 256 split-form channels, tile-resident in two channel passes (tile_conv.hip: tile_conv2p_kernel): convc2 (N = 192), conv (126 of 128)
+int launch_pack_tile_conv2p(const float *wpk, int N, int cin_pad, void *out, hipStream_t s);
+int launch_tile_conv2p(const float *a, int lda, const void *wf, const float *bias, float *out, int ldo, int n_valid, int P, int h, int w, int cells,
+                       hipStream_t s);
 // the occlusion + uncertainty heads as one tile-resident kernel + a stencil sum (tile_conv.hip: ou_head_kernel)
 constexpr size_t OU_HEAD_WTILE_BYTES = 8ull * 5 * 9 * 9 * 128 * 16, OU_HEAD_WPROJ_BYTES = 32768;
 int launch_pack_ou_head(const float *w1pk, int cin_pad, const float *w2pk, void *wtile, void *wproj, hipStream_t s);

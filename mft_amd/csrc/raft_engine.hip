@@ -196,7 +196,7 @@ struct mftx_raft {
     const void *wproj;             // the flow head's last layer as the projection epilogue of its first (csrc/tile_conv.hip: TC_RELU_PROJ), or null
     const void *wt[W_COUNT];       // weight streams of the tile-resident conv kernel (csrc/tile_conv.hip) per slot, or null
     const void *wou, *wouproj;     // the occlusion + uncertainty heads as one tile-resident kernel (csrc/tile_conv.hip: ou_head_kernel), or null
-    int opt[12];                   // MFTX_RAFT_OPT_*
+    int opt[13];                   // MFTX_RAFT_OPT_*
     unsigned *nonfinite;           // device counter of non-finite output pixels (mftx_raft_set_nonfinite_counter), or null
 };
 // weights that go through the conv GEMM (the others feed VALU kernels and stay fp32)
@@ -225,7 +225,7 @@ extern "C" int mftx_raft_create(const float *const *weights, int n_weights, mftx
     r->coords_trace = nullptr;
     r->nonfinite = nullptr;
     r->graphs = new (std::nothrow) GraphCache;
-    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1; r->opt[MFTX_RAFT_OPT_FUSE_FLOW] = 1; r->opt[MFTX_RAFT_OPT_TILE_CONV] = 1; r->opt[MFTX_RAFT_OPT_FUSE_HEAD] = 1; r->opt[MFTX_RAFT_OPT_TILE_VOLUME] = 1; r->opt[MFTX_RAFT_OPT_FUSE_GRU] = 1; r->opt[MFTX_RAFT_OPT_TILE_CELLS] = 0; r->opt[MFTX_RAFT_OPT_FUSE_OU] = 1;
+    r->opt[MFTX_RAFT_OPT_FORK] = -1; r->opt[MFTX_RAFT_OPT_PRESPLIT] = 1; r->opt[MFTX_RAFT_OPT_GROUP] = 1; r->opt[MFTX_RAFT_OPT_FUSE_LOOKUP] = 1; r->opt[MFTX_RAFT_OPT_GRAPH] = 1; r->opt[MFTX_RAFT_OPT_FUSE_FLOW] = 1; r->opt[MFTX_RAFT_OPT_TILE_CONV] = 1; r->opt[MFTX_RAFT_OPT_FUSE_HEAD] = 1; r->opt[MFTX_RAFT_OPT_TILE_VOLUME] = 1; r->opt[MFTX_RAFT_OPT_FUSE_GRU] = 1; r->opt[MFTX_RAFT_OPT_TILE_CELLS] = 0; r->opt[MFTX_RAFT_OPT_FUSE_OU] = 1; r->opt[MFTX_RAFT_OPT_TILE_CONV2P] = 1;
     for (int i = 0; i < W_COUNT; ++i) r->w[i] = r->wg[i] = weights[i];
     *out = r;
     return 0;
@@ -348,7 +348,7 @@ extern "C" int mftx_raft_set_nonfinite_counter(mftx_raft *r, unsigned *counter) 
 
 extern "C" int mftx_raft_set_option(mftx_raft *r, int option, int value) {
     if (!r || r->magic != RAFT_MAGIC) return fail(MFTX_E_STATE, "raft_set_option: bad handle");
-    if (option < 0 || option > MFTX_RAFT_OPT_FUSE_OU) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
+    if (option < 0 || option > MFTX_RAFT_OPT_TILE_CONV2P) return fail(MFTX_E_ARG, "raft_set_option: unknown option %d", option);
     r->opt[option] = value;
     if (r->graphs) r->graphs->clear();
     return 0;
@@ -587,16 +587,23 @@ static int refine_impl(mftx_raft *r, int P, int h, int w, int iters, const float
         TRY(check_launch("lookup + convf1"));
         // motion encoder (core/update.py:152-160)
         if (!fuse_lookup) TRY(launch_conv(gemm(conv_desc(ws.corr, ws.ld_corr, ws.ld_corr, nullptr, 0, 0, G[W_CONVC1], W[B_CONVC1], ws.cor1, 256, P, h, w, 256, 1, 1, 1), false, true), s));
+        // convc2 and conv (3 x 3 over 256 channels): tile-resident in two channel passes where the tile-resident layers run (round 6)
+        const bool two_pass = tiles_on && r->opt[MFTX_RAFT_OPT_TILE_CONV2P] != 0 && r->wt[W_CONVC2] && r->wt[W_CONV];
+        auto run_c2 = [&]() -> int {
+            if (two_pass) return launch_tile_conv2p(ws.cor1, 256, r->wt[W_CONVC2], W[B_CONVC2], ws.corflo, 256, 192, P, h, w, r->opt[MFTX_RAFT_OPT_TILE_CELLS], s);
+            return launch_conv(c2, s);
+        };
         if (forked) {
-            TRY(launch_conv(c2, s));
+            TRY(run_c2());
             if (hipStreamWaitEvent(s, r->ev_join, 0) != hipSuccess) return fail(MFTX_E_STATE, "raft_refine: join failed");
         } else if (nopair || AR != MFTX_ARITH_F32) {
-            TRY(launch_conv(c2, s));
+            TRY(run_c2());
             if (!flow_first && !fuse_flow) TRY(launch_conv(f2, s));
         } else {
             TRY(launch_conv_pair(c2, f2, s));      // second layers of the two branches in one launch
         }
-        TRY(launch_conv(gemm(conv_desc(ws.corflo, 256, 256, nullptr, 0, 0, G[W_CONV], W[B_CONV], ws.hx + 256, 384, P, h, w, 126, 3, 3, 1), true, true), s));
+        if (two_pass) TRY(launch_tile_conv2p(ws.corflo, 256, r->wt[W_CONV], W[B_CONV], ws.hx + 256, 384, 126, P, h, w, r->opt[MFTX_RAFT_OPT_TILE_CELLS], s));
+        else TRY(launch_conv(gemm(conv_desc(ws.corflo, 256, 256, nullptr, 0, 0, G[W_CONV], W[B_CONV], ws.hx + 256, 384, P, h, w, 126, 3, 3, 1), true, true), s));
         // SepConvGRU (core/update.py:108-123): horizontal 1x5 then vertical 5x1
         // (decided ONCE for both passes: they hand h over through the ping-pong pair hx/hf <-> hb/hfb, so one fused and one
         // unfused pass would read a buffer the other never wrote -- a partial set of tile weights runs both passes unfused)
@@ -817,6 +824,7 @@ extern "C" int mftx_corr_lookup_convc1(const float *lvl0, const float *lvl1, con
 }
 
 extern "C" int mftx_pack_tile_conv_weights(const float *wpk, int N, int taps, int cin, int cin_pad, void *wtile, void *stream) {
+    if (taps == 9 && cin == 256) return launch_pack_tile_conv2p(wpk, N, cin_pad, wtile, (hipStream_t)stream);      // 3 x 3 over 256 channels: two channel passes
     return launch_pack_tile_conv(wpk, N, taps, cin, cin_pad, wtile, (hipStream_t)stream);
 }
 
@@ -826,6 +834,10 @@ extern "C" int mftx_tile_conv2d(const mftx_conv_desc *d, const void *wtile, void
     if (d->act != 0 && d->act != 1) return fail(MFTX_E_ARG, "tile_conv2d: activation none or relu");
     if (d->stride > 1 || d->residual_mode != 0 || d->out_scale != 1.f || (d->hin && d->hin != d->h) || (d->win && d->win != d->w) || d->pad_y != 0 || d->pad_x != 0)
         return fail(MFTX_E_ARG, "tile_conv2d: stride 1, same padding, no output scale");
+    if (d->kh == 3 && d->kw == 3 && d->c0 == 256 && d->c1 == 0) {       // two channel passes (tile_conv.hip: tile_conv2p_kernel)
+        if (d->act != 1 || !d->out_split || d->addend || !d->bias) return fail(MFTX_E_ARG, "tile_conv2d: 3 x 3 over 256 channels comes with bias, relu and a split-form output");
+        return launch_tile_conv2p(d->a0, d->lda0, wtile, d->bias, d->out, d->ldo, d->N, d->P, d->h, d->w, 0, (hipStream_t)stream);
+    }
     if (d->c0 != 128 || (d->c1 != 0 && d->c1 != 128)) return fail(MFTX_E_ARG, "tile_conv2d: channel segments of 128");
     TileConvLaunch t{};
     t.a0 = d->a0; t.lda0 = d->lda0; t.a1 = d->c1 ? d->a1 : nullptr; t.lda1 = d->lda1; t.cin = d->c0 + d->c1; t.wf = wtile; t.bias = d->bias;

@@ -1215,6 +1215,251 @@ int launch_tile_conv(const TileConvLaunch &d, hipStream_t s) {
 #undef TC_BY_CELLS
 }
 
+// ---- 3 x 3 over 256 channels, tile-resident in TWO channel passes (round 6): convc2 and conv of the motion encoder -----------------
+// (core/update.py:152-160: convc2 256 -> 192, conv [cor 192 | flo 64] -> 126.)  A 3 x 3 tile with its halo and 256 split-form
+// channels is 187 KB -- more than a CU's LDS -- so these two layers ran on the ring-buffered kernel, re-reading their input nine
+// times through L2 with a barrier per 32-wide K chunk (MFMA-busy 0.38 / 0.34, the lowest of the update block).  Here, as in
+// ou_head_kernel: the tile is loaded as two passes of 128 channels (95 KB each), the accumulators live across the passes, and the K
+// loop is tile_conv_kernel's -- eight ds_read_b128, two weight loads, twelve MFMAs per step, no barrier in it.
+//   waves     N = 128: wave = (column tile, K half), as tile_conv_kernel.
+//             N = 192: six column tiles on eight waves -- waves 0..3 own column tiles 0..3 with ALL of K, waves 4 / 5 the K halves
+//             of column tile 4, waves 6 / 7 those of column tile 5: every SIMD (waves w and w + 4) carries one and a half column
+//             tiles, a quarter less than the 256-wide layout would with two of its eight column tiles multiplying zeros.
+//   K order   pass (channels 0..127, then 128..255) > tap > channel group: one fixed sequence of products per output, whatever
+//             the batch or the tile; the halves of a K-split column tile meet in LDS and are added in a fixed order.
+//   output    relu(. + bias) in split form; channels >= n_valid are left untouched (conv writes 126 of its 128: the flow sits
+//             in channels 126, 127 of the motion features, core/update.py:160).
+struct TileConv2pArgs {
+    const float *a; int lda;            // 256 channels per cell, split form, at a + cell * lda floats
+    const void *wf;                     // launch_pack_tile_conv2p
+    const float *bias;                  // [n_valid]
+    float *out; int ldo; int n_valid;   // split-form rows at out + cell * ldo floats
+    int P, h, w, tiles_x, tiles_y;
+};
+
+// load passes + K loops + parking of one wave; G: its geometry (whole K or a K half).  A function of its own, called under the
+// wave-uniform role test, so that the 128 accumulator registers of the two roles never meet in a phi (spills otherwise)
+template <class G, int TH, int TW>
+__device__ __forceinline__ void tc2p_main(const TileConv2pArgs &p, unsigned char *lds, const uint4 *__restrict__ w2, int ks_off, int x0, int y0, long long img_base,
+                                          float *slab, int rowf, int col0) {
+    constexpr int RT = G::RT, PF = 3, PASSES = 2;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    tc_f32x16 acc[RT], accx[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; accx[i][r] = 0.f; }
+    const unsigned char *abase[RT];
+    {
+        const int r = lane & 31;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int m = 32 * i + r;
+            abase[i] = lds + ((m / TW) * G::HWD + (m % TW)) * G::CELLB + (lane >> 5) * 32 + ks_off;
+        }
+    }
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const uint4 *__restrict__ wp = w2 + (long long)pass * G::STEPS * 128;
+        uint4 bq[PF][2];
+#pragma unroll
+        for (int s = 0; s < PF; ++s) { bq[s][0] = wp[s * 128]; bq[s][1] = wp[s * 128 + 64]; }      // in flight while the tile loads
+        if (pass) tc_barrier();          // every wave is done with the first pass's channels
+        // ---- channels [128 pass, 128 pass + 128) of the tile (halo included) -> LDS, 16-byte pieces, zeros outside the image
+        {
+            constexpr int PPC = 32, TOTAL = G::HCELLS * PPC, ROUNDS = (TOTAL + 511) / 512, B = 8;
+#pragma unroll 1
+            for (int r0 = 0; r0 < ROUNDS; r0 += B) {
+                uint4 v[B];
+#pragma unroll
+                for (int k = 0; k < B; ++k) {
+                    const int q = (r0 + k) * 512 + tid;
+                    v[k] = make_uint4(0u, 0u, 0u, 0u);
+                    if (r0 + k < ROUNDS && q < TOTAL) {
+                        const int c = q / PPC, pc = q - c * PPC;
+                        const int cy = c / G::HWD, cx = c - cy * G::HWD;
+                        const int yy = y0 - 1 + cy, xx = x0 - 1 + cx;
+                        if (yy >= 0 && yy < p.h && xx >= 0 && xx < p.w)
+                            v[k] = *reinterpret_cast<const uint4 *>(p.a + (img_base + (long long)yy * p.w + xx) * p.lda + pass * 128 + pc * 4);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < B; ++k) {
+                    const int q = (r0 + k) * 512 + tid;
+                    if (r0 + k < ROUNDS && q < TOTAL) {
+                        const int c = q / PPC, pc = q - c * PPC;
+                        *reinterpret_cast<uint4 *>(lds + c * G::CELLB + pc * 16) = v[k];
+                    }
+                }
+            }
+        }
+        tc_barrier();
+        tc_kloop<G, 3>(abase, wp, bq, acc, accx);
+    }
+    tc_barrier();           // every wave is done with the input tile: its space takes the sums
+    const float inv2048 = 1.f / 2048.f;
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            tc_f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * b + e] + accx[i][4 * b + e] * inv2048;
+            *reinterpret_cast<tc_f32x4 *>(slab + (32 * i + (lane & 31)) * rowf + col0 + 8 * b + 4 * (lane >> 5)) = v;
+        }
+}
+
+template <int TH, int TW, int N>
+__global__ __launch_bounds__(512, 2) void tile_conv2p_kernel(TileConv2pArgs p) {
+    using GF = TcGeom<TH, TW, 3, 3, 128, 256>;      // a wave with all of K: 72 steps per pass
+    using GH = TcGeom<TH, TW, 3, 3, 128, 128>;      // a wave with a K half (channel groups of its parity): 36 steps per pass
+    static_assert(N == 128 || N == 192, "tile_conv2p: N");
+    constexpr int CELLS = GF::CELLS, PASSES = 2;
+    constexpr int RED0 = N + 4, RED1 = (N == 128 ? 128 : 64) + 4;          // floats per cell of the two slabs of parked sums
+    static_assert((CELLS * (RED0 + RED1)) * 4 <= 160 * 1024, "tile_conv2p: LDS");
+    extern __shared__ __attribute__((aligned(16))) unsigned char tc_lds[];
+    unsigned char *lds = tc_lds;
+    const int tid = (int)threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = (int)blockIdx.x;
+    const int tx_ = tile % p.tiles_x, ty_ = (tile / p.tiles_x) % p.tiles_y, img = tile / (p.tiles_x * p.tiles_y);
+    const int x0 = tx_ * TW, y0 = ty_ * TH;
+    const long long img_base = (long long)img * p.h * p.w;
+    const bool full = N == 192 && wv < 4;
+    const int nt = N == 128 ? (wv & 3) : (wv < 4 ? wv : 4 + ((wv - 4) >> 1));
+    const int ks = N == 128 ? (wv >> 2) : (wv < 4 ? 0 : ((wv - 4) & 1));
+    const int wstart = N == 128 ? wv * PASSES * GH::STEPS : (wv < 4 ? wv * PASSES * GF::STEPS : 4 * PASSES * GF::STEPS + (wv - 4) * PASSES * GH::STEPS);
+    const uint4 *__restrict__ w2 = reinterpret_cast<const uint4 *>(p.wf) + (long long)wstart * 128 + (tid & 63);
+    // sums -> LDS: slab 0 [cell][N] (whole-K waves and the first K halves), slab 1 (the second K halves: all columns at N = 128,
+    // columns 128..191 at N = 192)
+    float *red = reinterpret_cast<float *>(lds);
+    const bool second = !full && ks == 1;
+    float *slab = second ? red + CELLS * RED0 : red;
+    const int rowf = second ? RED1 : RED0;
+    const int col0 = second && N == 192 ? 32 * (nt - 4) : 32 * nt;
+    if (N == 192 && full) tc2p_main<GF, TH, TW>(p, lds, w2, 0, x0, y0, img_base, slab, rowf, col0);
+    else tc2p_main<GH, TH, TW>(p, lds, w2, ks * 64, x0, y0, img_base, slab, rowf, col0);
+    tc_barrier();
+
+    // ---- row-wise epilogue: 8 consecutive channels of a cell per lane
+    const float k2048 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(0x45000000));
+    constexpr int GPC = N / 8, ITEMS = CELLS * GPC;
+#pragma unroll
+    for (int it = 0; it < (ITEMS + 511) / 512; ++it) {
+        const int item = tid + 512 * it;
+        if (item >= ITEMS) break;
+        const int m = item / GPC, n0 = (item % GPC) * 8;
+        const int yy = y0 + m / TW, xx = x0 + m % TW;
+        const float *src = red + m * RED0 + n0;
+        tc_f32x4 u = *reinterpret_cast<const tc_f32x4 *>(src), v = *reinterpret_cast<const tc_f32x4 *>(src + 4);
+        if (N == 128 || n0 >= 128) {
+            const float *s1 = red + CELLS * RED0 + m * RED1 + (N == 128 ? n0 : n0 - 128);
+            u += *reinterpret_cast<const tc_f32x4 *>(s1);
+            v += *reinterpret_cast<const tc_f32x4 *>(s1 + 4);
+        }
+        if (yy >= p.h || xx >= p.w || n0 >= p.n_valid) continue;
+        const long long cell = img_base + (long long)yy * p.w + xx;
+        const int nv = p.n_valid - n0;                  // channels of this group that exist (>= 8: all)
+        if (nv >= 8) {
+            u += *reinterpret_cast<const tc_f32x4 *>(p.bias + n0);
+            v += *reinterpret_cast<const tc_f32x4 *>(p.bias + n0 + 4);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { if (e < nv) u[e] += p.bias[n0 + e]; if (4 + e < nv) v[e] += p.bias[n0 + 4 + e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { u[e] = relu_keep_nan(u[e]); v[e] = relu_keep_nan(v[e]); }
+        tc_u32x4 hi, lo;
+        tc_split8(u, v, k2048, hi, lo);
+        unsigned *dst = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(p.out + cell * p.ldo) + (n0 >> 3) * 32);
+        if (nv >= 8) {
+            reinterpret_cast<uint4 *>(dst)[0] = __builtin_bit_cast(uint4, hi);
+            reinterpret_cast<uint4 *>(dst)[1] = __builtin_bit_cast(uint4, lo);
+        } else {                                        // a ragged last group: whole pairs of channels only (n_valid is even)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (2 * e + 1 < nv) { dst[e] = hi[e]; dst[4 + e] = lo[e]; }
+        }
+    }
+}
+
+// the GEMM's packed form [>= N rows][9 taps][cin_pad >= 256] fp32 -> the kernel's streams: wave after wave, [pass][step][hi | lo][lane] x 16 bytes
+__global__ void pack_tile_conv2p_kernel(const float *__restrict__ wpk, int cin_pad, int N, uint4 *__restrict__ out, long long pieces) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= pieces) return;
+    constexpr int SF = 72, SH = 36;
+    const int lane = (int)(idx & 63), part = (int)((idx >> 6) & 1);
+    int t = (int)(idx >> 7), wv, r;
+    bool full = false;
+    if (N == 128) { wv = t / (2 * SH); r = t - wv * 2 * SH; }
+    else if (t < 4 * 2 * SF) { wv = t / (2 * SF); r = t - wv * 2 * SF; full = true; }
+    else { t -= 4 * 2 * SF; wv = 4 + t / (2 * SH); r = t - (wv - 4) * 2 * SH; }
+    const int nt = N == 128 ? (wv & 3) : (wv < 4 ? wv : 4 + ((wv - 4) >> 1));
+    const int ks = N == 128 ? (wv >> 2) : (wv < 4 ? 0 : ((wv - 4) & 1));
+    const int steps = full ? SF : SH, gpw = full ? 8 : 4, ksw = full ? 1 : 2;
+    const int pass = r / steps, step = r - pass * steps;
+    const int tap = step / gpw, g = 8 * pass + (step % gpw) * ksw + ks;
+    const int n = 32 * nt + (lane & 31);
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long long base = ((long long)n * 9 + tap) * cin_pad + 16 * g + 8 * (lane >> 5) + 2 * e;
+        const unsigned a = split_halves(wpk[base]), b = split_halves(wpk[base + 1]);
+        w[e] = part ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+    }
+    out[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+int launch_pack_tile_conv2p(const float *wpk, int N, int cin_pad, void *out, hipStream_t s) {
+    if (!wpk || !out) return fail(MFTX_E_ARG, "pack_tile_conv2p_weights: null pointer");
+    if ((N != 128 && N != 192) || cin_pad < 256) return fail(MFTX_E_ARG, "pack_tile_conv2p_weights: N in {128, 192}, 256 input channels");
+    if (!aligned16(out)) return fail(MFTX_E_ALIGN, "pack_tile_conv2p_weights: output not 16-byte aligned");
+    const long long pieces = (long long)N * 9 * 256 * 4 / 16;
+    hipLaunchKernelGGL(pack_tile_conv2p_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, wpk, cin_pad, N, reinterpret_cast<uint4 *>(out), pieces);
+    return check_launch("pack_tile_conv2p");
+}
+
+template <int TH, int TW, int N>
+static int tc2p_launch(TileConv2pArgs a, hipStream_t s) {
+    using GF = TcGeom<TH, TW, 3, 3, 128, 256>;
+    constexpr int red = GF::CELLS * ((N + 4) + ((N == 128 ? 128 : 64) + 4)) * 4;
+    constexpr int lds_bytes = GF::A_BYTES > red ? GF::A_BYTES : red;
+    static_assert(lds_bytes <= 160 * 1024, "tile_conv2p: LDS");
+    a.tiles_x = cdiv(a.w, TW); a.tiles_y = cdiv(a.h, TH);
+    const long long tiles = (long long)a.P * a.tiles_x * a.tiles_y;
+    if (tiles > 0x7fffffffLL) return fail(MFTX_E_ARG, "tile_conv2p: too many tiles");
+    auto kern = tile_conv2p_kernel<TH, TW, N>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+            return fail(MFTX_E_STATE, "tile_conv2p: cannot reserve %d bytes of LDS", lds_bytes);
+        attr_set = true;
+    }
+    ProfScope prof(PC_CONV_GEMM, s, 2.0 * a.P * a.h * a.w * ((double)a.n_valid * 9 * 256));
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds_bytes, s, a);
+    return check_launch("tile_conv2p");
+}
+
+// a [M][lda] split form, 256 channels; out [M][ldo] split form, channels [0, n_valid) written; N = 128 (n_valid <= 128, even) or 192
+int launch_tile_conv2p(const float *a, int lda, const void *wf, const float *bias, float *out, int ldo, int n_valid, int P, int h, int w, int cells,
+                       hipStream_t s) {
+    if (!a || !wf || !bias || !out) return fail(MFTX_E_ARG, "tile_conv2p: null pointer");
+    if (P <= 0 || h <= 0 || w <= 0) return fail(MFTX_E_ARG, "tile_conv2p: bad sizes");
+    const int N = n_valid > 128 ? 192 : 128;
+    if (n_valid < 8 || n_valid > 192 || (n_valid & 1) || (N == 192 && n_valid != 192)) return fail(MFTX_E_ARG, "tile_conv2p: 192 output channels, or an even number up to 128");
+    auto bad_split = [](const float *p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 31) != 0 || (ld % 8) != 0; };
+    if (bad_split(a, lda) || bad_split(out, ldo) || lda < 256 || ldo < N - (N - n_valid) / 8 * 8 || !aligned16(wf) || (reinterpret_cast<uintptr_t>(bias) & 3))
+        return fail(MFTX_E_ALIGN, "tile_conv2p: split-form rows are 32-byte aligned with strides in multiples of 8; weights 16-byte aligned");
+    TileConv2pArgs k{};
+    k.a = a; k.lda = lda; k.wf = wf; k.bias = bias; k.out = out; k.ldo = ldo; k.n_valid = n_valid; k.P = P; k.h = h; k.w = w;
+    if (!cells) cells = tile_conv_cells(P, h, w, 3);
+#define TC2P(TH) (N == 192 ? tc2p_launch<TH, 16, 192>(k, s) : tc2p_launch<TH, 16, 128>(k, s))
+    if (cells == 128) return TC2P(8);
+    if (cells == 64) return TC2P(4);
+    if (cells == 32) return TC2P(2);
+#undef TC2P
+    return fail(MFTX_E_ARG, "tile_conv2p: 128, 64 or 32 cells per tile");
+}
+
 // ---- the flow head's second layer, in two pieces (see TC_RELU_PROJ) -----------------------------------------------------
 // its filter in the GEMM's packed form [>= 2 rows][9 taps][256] fp32 -> MFMA A fragments of the [18 (+ 14 zero rows) x 256]
 // matrix W2'[j = 2 tap + o][k]: [k group 0..15][hi | lo][lane] x 16 bytes

@@ -722,11 +722,12 @@ class RaftEngine:
     # WeightSlot indices (csrc/raft_engine.hip) of the weights that feed GEMM layers
     GEMM_SLOTS = (0, 2, 6, 8, 10, 11, 13, 14, 16, 17, 19, 20, 22, 26, 28, 30)
 
-    OPTIONS = {"fork": 0, "presplit": 1, "group": 2, "fuse_lookup": 3, "graph": 4, "fuse_flow": 5, "tile_conv": 6, "fuse_head": 7, "tile_volume": 8, "fuse_gru": 9, "tile_cells": 10, "fuse_ou": 11}      # MFTX_RAFT_OPT_*
+    OPTIONS = {"fork": 0, "presplit": 1, "group": 2, "fuse_lookup": 3, "graph": 4, "fuse_flow": 5, "tile_conv": 6, "fuse_head": 7, "tile_volume": 8, "fuse_gru": 9, "tile_cells": 10, "fuse_ou": 11, "tile_conv2p": 12}      # MFTX_RAFT_OPT_*
     # WeightSlot -> (N, cin) of the layers with a tile-resident kernel (csrc/tile_conv.hip): GRU gates (per-iteration and
     # context parts, both passes), flow head and mask head first layers
-    TILE_SLOTS = {10: (256, 256), 11: (256, 128), 13: (128, 256), 14: (128, 128), 16: (256, 256), 17: (256, 128),
-                  19: (128, 256), 20: (128, 128), 22: (256, 128), 26: (256, 128)}
+    # ... and (round 6) the motion encoder's convc2 (N = 192) and conv (126 of 128), 3 x 3 over 256 channels: two channel passes
+    TILE_SLOTS = {2: (192, 256), 8: (128, 256), 10: (256, 256), 11: (256, 128), 13: (128, 256), 14: (128, 128), 16: (256, 256),
+                  17: (256, 128), 19: (128, 256), 20: (128, 128), 22: (256, 128), 26: (256, 128)}
 
     def __init__(self, state_dict: dict, device, ondemand_corr=False, arith=ARITH_SPLIT, options=None):
         """options: {"fork" | "presplit" | "group" | "fuse_lookup" | "graph" | "fuse_flow" | "tile_conv" | "fuse_head" | "tile_volume": int} scheduling options of this handle

@@ -1117,6 +1117,51 @@ def test_tile_conv_batch_invariance_and_argument_errors(ops_mod):
         ops_mod.pack_tile_conv_weights(torch.full((256, 9, 128), 1e5, device=DEV), 256, 128)
 
 
+@pytest.mark.parametrize("cout,P,h,w", [(192, 1, 24, 40), (126, 1, 24, 40), (192, 2, 33, 47), (126, 3, 9, 70), (192, 7, 64, 64), (126, 7, 64, 64)])
+def test_tile_conv_two_pass_vs_conv_gemm_and_fp64(ops_mod, cout, P, h, w):
+    """Round 6: 3 x 3 over 256 channels tile-resident in TWO channel passes (convc2 256 -> 192 and conv 256 -> 126 of the motion
+    encoder, core/update.py:152-160; csrc/tile_conv.hip: tile_conv2p_kernel) against the ring-buffered GEMM on the same split-form
+    operands and against fp64: whole and ragged tiles, images smaller than a tile, the K-split column tiles of N = 192, and conv's
+    ragged last channel group -- channels 126, 127 of its 128-wide output rows are NOT written (the flow lives there)."""
+    g = torch.Generator().manual_seed(cout + h)
+    M = P * h * w
+    x = torch.randn(M, 256, generator=g)
+    wt = torch.randn(cout, 256, 3, 3, generator=g) * 0.04
+    b = torch.randn(cout, generator=g)
+    wpk = ops_mod.pack_conv_weight(wt.cuda())
+    xs = ops_mod.split_activations(x.cuda())
+    N = 192 if cout == 192 else 128
+    wtile = ops_mod.pack_tile_conv_weights(wpk, N, 256)
+    sentinel = ops_mod.split_activations(torch.full((M, N), 7.25, device=DEV))
+    got_s = ops_mod.tile_conv2d(xs, wtile, b.cuda(), P, h, w, cout, 3, 3, act="relu", out_split=True, out=sentinel.clone())
+    got = ops_mod.unsplit_activations(got_s)
+    ref = ops_mod.unsplit_activations(ops_mod.conv2d(xs, ops_mod.split_weights(wpk), b.cuda(), P, h, w, cout, 3, 3, act="relu", arith=1, a_split=True,
+                                                     out_split=True, out=sentinel.clone()))
+    xi = x.double().reshape(P, h, w, 256).permute(0, 3, 1, 2)
+    r64 = torch.relu(torch.nn.functional.conv2d(xi, wt.double(), b.double(), padding=1)).permute(0, 2, 3, 1).reshape(M, cout)
+    scale = float(r64.abs().max())
+    e_tile = float((got[:, :cout].cpu().double() - r64).abs().max())
+    e_ring = float((ref[:, :cout].cpu().double() - r64).abs().max())
+    assert e_tile < 3e-6 * scale and e_tile < 2 * e_ring + 1e-6 * scale, (e_tile, e_ring, scale)
+    if cout < N:
+        assert torch.equal(got_s.view(torch.int32).reshape(M, -1, 8)[:, -1, 3::4], sentinel.view(torch.int32).reshape(M, -1, 8)[:, -1, 3::4])   # channels 126, 127: both halves untouched
+        assert bool((got[:, cout:] == 7.25).all())
+    # a pair's bits do not depend on the batch (nor, with it, on the cells per tile the launcher picks)
+    one = ops_mod.tile_conv2d(xs[:h * w].contiguous(), wtile, b.cuda(), 1, h, w, cout, 3, 3, act="relu", out_split=True, out=sentinel[:h * w].clone())
+    assert torch.equal(one, got_s[:h * w])
+
+
+def test_engine_two_pass_tile_conv_matches_ring_gemm():
+    """The engine with convc2 and conv on the two-pass tile-resident kernel (the default where the tile-resident layers run) against
+    the same engine with the two layers on the ring-buffered GEMM: fp32 rounding of their K sums."""
+    two, ring = _engine_outputs({"tile_conv": 2}), _engine_outputs({"tile_conv": 2, "tile_conv2p": 0})
+    assert np.isfinite(two).all() and not np.array_equal(two, ring)
+    n = 3 * 2 * 192 * 320
+    d = (two[:n] - ring[:n]).reshape(3, 2, -1)
+    assert np.sqrt((d ** 2).sum(1)).mean() < 1e-4
+    assert np.abs(two[n:] - ring[n:]).max() < 1e-3
+
+
 def test_engine_tile_conv_matches_ring_gemm():
     """The engine with the GRU gates, their context parts and the flow / mask heads' first layers on the tile-resident
     kernel (the default) against the same engine with every layer on the ring-buffered GEMM: fp32 rounding of the K sums."""

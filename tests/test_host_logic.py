@@ -432,7 +432,7 @@ def test_chain_kernels_are_built_without_packed_fp32_code():
     assert not re.search(r"\bv_pk_\w+", out.stdout), re.findall(r"\bv_pk_\w+", out.stdout)[:5]
 
 
-@pytest.mark.parametrize("unit", ["corr", "corr_ondemand", "upsample", "encoder", "codec"])
+@pytest.mark.parametrize("unit", ["corr", "corr_ondemand", "upsample", "encoder", "raft_engine", "codec"])
 def test_masked_gather_units_carry_no_packed_fp32_code(unit):
     """Round 6: the chain race needed packed-fp32 arithmetic AND EXEC-masked gathers in one instruction
     stream (profiles/r5q_chain_race.txt) and its exact hazard is not pinned down -- so every translation unit that gathers behind
@@ -450,7 +450,7 @@ def test_masked_gather_units_carry_no_packed_fp32_code(unit):
     if unit == "codec":
         rule = re.search(r"^codec\.o:.*\n\t\$\(HIPCC\) \$\(CXXFLAGS\) (.*?) -c \$< -o \$@", mk, re.M)
     else:
-        rule = re.search(r"^corr\.o corr_ondemand\.o upsample\.o encoder\.o:.*\n\t\$\(HIPCC\) \$\(CXXFLAGS\) (.*?) -c \$< -o \$@", mk, re.M)
+        rule = re.search(r"^corr\.o corr_ondemand\.o upsample\.o encoder\.o raft_engine\.o:.*\n\t\$\(HIPCC\) \$\(CXXFLAGS\) (.*?) -c \$< -o \$@", mk, re.M)
     assert rule and "$(NOPK)" in rule.group(1), "Makefile rule without NOPK"
     extra = [f for tok in rule.group(1).split() for f in (nopk if tok == "$(NOPK)" else [tok])]
     tune = (REPO / "tools" / "build_tuning.sh").read_text()
