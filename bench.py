@@ -264,6 +264,44 @@ def rank_diagnostics(tracker, window, H, W, world, rank, backend):
     return d
 
 
+def host_io_pass(tracker, host_frames, base, n_io, n_io_frames, IO_WARM):
+    """PCIe-inclusive variant of the timed loop on the SAME tracker, right behind the timed region: every frame comes from HOST memory
+    and every result goes back to it (what the reference's API does, MFT/utils/io.py:566-615 in, MFT/MFT.py:145-148 out).  Frames
+    wait in pinned buffers (mft_amd.video.FrameRing) and are uploaded by a copy kernel on the encoders' stream; results leave through
+    the same copy kernel into pinned buffers and are collected two frames late (ResultDrain) -- no SDMA copy on either side, so
+    nothing serialises (profiles/r2_io_paths.txt was the study of the hipMemcpyAsync paths)."""
+    from mft_amd.video import FrameRing, ResultDrain
+    enc = getattr(tracker.flower, "_enc_stream", None)
+    ring = FrameRing((host_frames[i] for i in range(base, base + n_io_frames)), keep=40,
+                     streams=[enc] if enc is not None else None).prepare(host_frames[0].shape)
+    drain = ResultDrain(depth=4, nonfinite_from=tracker).prepare(tracker.memory[tracker.current_frame_i]['result'])
+    got = 0
+    t0 = None
+    # (the loop issues no CPU tensor math; torch's intra-op pool -- 128 threads on this host -- only adds wake-up and
+    # spin noise to the host-side waits: tools/io_paths3.py, 101 vs 124 frames/s)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        for n, frame in enumerate(ring):
+            if n == IO_WARM:              # the first frames touch the pinned buffers for the first time (GPU-side address
+                torch.cuda.synchronize()  # translation of fresh pinned pages): steady state starts behind them
+                t0 = time.perf_counter()
+                got = -len(drain)
+            drain.submit(tracker.track(frame).result)
+            if len(drain) > 2:
+                out = drain.collect()
+                assert not out[0].is_cuda
+                got += 1
+        while len(drain):
+            drain.collect()
+            got += 1
+        torch.cuda.synchronize()
+        assert got == n_io, (got, n_io)
+        return n_io / (time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(threads)
+
+
 def build_hash():
     """sha256 (first 16 hex digits) of the library this process runs: ties a counter file to the build it was measured on."""
     import hashlib
@@ -600,6 +638,16 @@ def main():
     if min(timed_pairs + warm_pairs) != FULL_PAIRS or max(timed_pairs) != FULL_PAIRS:
         raise SystemExit(f"timed region is not the 7-pair steady state: warm-up {warm_pairs}, timed {timed_pairs}")
 
+    host_io_fps = None
+    if n_io and rank == 0:
+        host_io_fps = host_io_pass(tracker, host_frames, first + args.steps, n_io, n_io_frames, IO_WARM)
+        log(f"host-io pass done: {host_io_fps:.1f} frames/s")
+    api = None
+    if n_api and rank == 0:
+        # (before the per-kernel profile pass and before anything touches torch's thread count: the literal API loop with the process's
+        # default threads, on a fresh tracker of the shipped configuration)
+        api = api_default_pass(args, host_frames, n_api)
+        log(f"api default pass: kept {api['kept']:.1f}, consumed each frame {api['consumed']:.1f} frames/s")
     kernels, prof_pairs = {}, []
     ranks_seen = 1
     rank_diag = None
@@ -616,7 +664,7 @@ def main():
         else:
             rank_diag = [mine]
     if n_prof and not sharded:
-        kernels, prof_pairs = profile_pass(tracker, frames, first + args.steps, n_prof, args.arith)
+        kernels, prof_pairs = profile_pass(tracker, frames, first + args.steps + n_io_frames, n_prof, args.arith)
         torch.cuda.synchronize()
         if min(prof_pairs) != FULL_PAIRS:
             raise SystemExit(f"profile pass left the steady state: {prof_pairs}")
@@ -723,9 +771,7 @@ def main():
         torch.cuda.empty_cache()
         log(f"other arithmetic ({other}): {10 / alt_dt:.1f} frames/s")
     if not sharded and rank == 0:
-        if n_api:
-            # BEFORE anything below touches torch's thread count: the literal API loop with the process's default threads
-            api = api_default_pass(args, host_frames, n_api)
+        if api is not None:
             result["api_default_fps"] = api["kept"]
             result["api_default_consumed_each_frame_fps"] = api["consumed"]
             result["api_default_note"] = (
@@ -734,41 +780,10 @@ def main():
                 "waits for the copy).  api_default_fps: results read after the loop; ..._consumed_each_frame_fps: every result read "
                 "before the next track() call, i.e. one host synchronisation per frame as with the reference" %
                 (api["threads"], api["frames_in_flight"]))
-            log(f"api default pass: kept {api['kept']:.1f}, consumed each frame {api['consumed']:.1f} frames/s")
-        if n_io:
-            # PCIe-inclusive variant of the same loop: every frame comes from HOST memory and every result goes back to it
-            # (what the reference's API does, MFT/utils/io.py:566-615 in, MFT/MFT.py:145-148 out).  Frames wait in pinned
-            # buffers (mft_amd.video.FrameRing) and are uploaded by a copy kernel on the encoders' stream; results leave
-            # through the same copy kernel into pinned buffers and are collected two frames late (ResultDrain) -- no SDMA
-            # copy on either side, so nothing serialises (profiles/r2_io_paths.txt was the study of the hipMemcpyAsync paths).
-            from mft_amd.video import FrameRing, ResultDrain
-            base = first + args.steps + n_prof
-            enc = getattr(tracker.flower, "_enc_stream", None)
-            ring = FrameRing((host_frames[i] for i in range(base, base + n_io_frames)), keep=40,
-                             streams=[enc] if enc is not None else None).prepare(host_frames[0].shape)
-            drain = ResultDrain(depth=4, nonfinite_from=tracker).prepare(tracker.memory[tracker.current_frame_i]['result'])
-            got = 0
-            # (the loop issues no CPU tensor math; torch's intra-op pool -- 128 threads on this host -- only adds wake-up and
-            # spin noise to the host-side waits: tools/io_paths3.py, 101 vs 124 frames/s)
-            torch.set_num_threads(1)
-            for n, frame in enumerate(ring):
-                if n == IO_WARM:              # the first frames touch the pinned buffers for the first time (GPU-side address
-                    torch.cuda.synchronize()  # translation of fresh pinned pages): steady state starts behind them
-                    t0 = time.perf_counter()
-                    got = -len(drain)
-                drain.submit(tracker.track(frame).result)
-                if len(drain) > 2:
-                    out = drain.collect()
-                    assert not out[0].is_cuda
-                    got += 1
-            while len(drain):
-                drain.collect()
-                got += 1
-            torch.cuda.synchronize()
-            assert got == n_io, (got, n_io)
-            result["host_io_fps"] = n_io / (time.perf_counter() - t0)
-            result["host_io_path"] = "pinned frames in and pinned results out, both moved by a copy kernel (no SDMA queue)"
-            log("host-io pass done")
+        if host_io_fps is not None:
+            result["host_io_fps"] = host_io_fps
+            result["host_io_path"] = ("pinned frames in and pinned results out, both moved by a copy kernel (no SDMA queue); the same tracker, "
+                                      "right behind the timed region")
         torch.set_num_threads(oracle_threads())
         if not args.no_parity:
             result["parity"] = flow_epe_vs_oracle(args, tracker, vid)

@@ -315,7 +315,10 @@ class RAFTWrapper:
 
     @torch.no_grad()
     def encode(self, img_bgr, want_context=True) -> FrameFeatures:
-        """uint8 BGR (H,W,3) -> pixel-major features (MFT/raft.py:41-48, core/raft.py:122-149)."""
+        """uint8 BGR (H,W,3) -> pixel-major features (MFT/raft.py:41-48, core/raft.py:122-149).
+        (fnet and cnet are independent, and running cnet on a second stream beside fnet was measured in round 6: 183 -> 162
+        frames/s pipelined and 143 -> 117 with a host synchronisation per frame -- two chains of ~50 small launches side by side
+        cost more than they hide.  One after the other, on one stream.)"""
         H0, W0 = img_bgr.shape[:2]
         img = self._device_image(img_bgr)
         h, w, pads = self._geometry(H0, W0)
