@@ -68,7 +68,7 @@ FLOP_CATS = {0, 3, 4, 8, 11, 12, 13}
 GEMM_PARTS = ("conv_gemm", "gru_half_fused", "encoder_conv_gemm")    # every conv GEMM of the step: what `roofline` prices, as in earlier rounds
 # kernel symbols booked under GEMM_PARTS (profile.h: PC_CONV_GEMM / PC_GRU_HALF / PC_ENC_GEMM): the counter file is averaged over the
 # same set that `roofline.achieved` and `flops_per_launch` are
-GEMM_KERNEL_NAMES = ("conv_gemm", "tile_conv_kernel", "gru_half_kernel", "ou_head_kernel")
+GEMM_KERNEL_NAMES = ("conv_gemm", "tile_conv_kernel", "tile_conv2p_kernel", "gru_half_kernel", "ou_head_kernel")
 VALU_CATS = {4, 8}
 FULL_PAIRS = 7                  # flow pairs per frame once every delta is live
 FIRST_FULL_FRAME = 33           # first frame index with FULL_PAIRS pairs (forward tracking from frame 0)
@@ -242,13 +242,14 @@ def rank_diagnostics(tracker, window, H, W, world, rank, backend):
          "backend": backend, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "hw_queues": dict(mft_amd.HW_QUEUES),
          "frames_in_flight": int(getattr(tracker.flower, "_fif", 1)),
          "sharder": dict(getattr(tracker.sharder, "stats", {}))}
-    fake = not hasattr(dist, "get_backend")                       # --emulate-world replaced the collectives by local copies
+    real_world = dist.get_world_size()
+    fake = real_world != world                                    # --emulate-world: this process stands for rank 0 of `world`, there is no wire
     for name, numel in (("features_all_gather", slots_f * h * w * 512), ("flowou_all_gather", slots_u * H * W * 4)):
+        if fake:
+            d[name] = {"bytes_sent_per_rank": 4 * numel, "bytes_gathered": 4 * numel * world, "us": None, "note": "emulated world: no wire"}
+            continue
         send = torch.zeros(numel, dtype=torch.float32, device="cuda")
         recv = torch.empty(world * numel, dtype=torch.float32, device="cuda")
-        if fake:
-            d[name] = {"bytes_sent_per_rank": 4 * numel, "bytes_gathered": 4 * numel * world, "us": None, "note": "emulated: no wire"}
-            continue
         for _ in range(2):
             dist.all_gather_into_tensor(recv, send)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -716,7 +717,7 @@ def main():
         if dom:
             traffic, source = profiled_traffic()
             split = args.arith == "split"
-            result["roofline"] = {"kernel": "conv_gemm_kernel + tile_conv_kernel + gru_half_kernel (%s implicit GEMM, ring-buffered and tile-resident: update block, "
+            result["roofline"] = {"kernel": "conv_gemm_kernel + tile_conv_kernel + tile_conv2p_kernel + gru_half_kernel + ou_head_kernel (%s implicit GEMM, ring-buffered and tile-resident: update block, "
                                             "OU heads, encoders -- kernels.conv_gemm_all)" %
                                             ("split-fp16 MFMA" if split else "fp32 MFMA"),
                                   "bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"],

@@ -56,7 +56,7 @@ with open(out / "pmc_hbm_traffic.csv", "w") as f:
     for k, v in sorted(data.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", (0, 0))[1]):
         n, fe = v.get("FETCH_SIZE", (0, 0.0))
         _, wr = v.get("WRITE_SIZE", (0, 0.0))
-        f.write(f"{k},{n},{fe:.1f},{fe * 2 if ('conv_gemm' in k or 'tile_conv' in k or 'gru_half' in k) else fe:.1f},{wr:.1f}\n")
+        f.write(f"{k},{n},{fe:.1f},{fe * 2 if ('conv_gemm' in k or 'tile_conv' in k or 'gru_half' in k or 'ou_head' in k) else fe:.1f},{wr:.1f}\n")
 
 # ---- MFMA utilisation
 p = src / "pmc_MFMA" / "bench_counter_collection.csv"
@@ -105,7 +105,7 @@ if p.exists():
                 "kernel,dispatches_total,dispatches_steady,avg_us_steady,share_of_steady_gpu_time\n")
         for t, k, n, m, avg in sorted(rows, reverse=True):
             f.write(f'"{k}",{n},{m},{avg:.1f},{t / tot:.4f}\n')
-        gemm = [(t, m) for t, k, n, m, avg in rows if ("conv_gemm" in k and ", 4, 32" not in k) or "tile_conv_kernel" in k or "gru_half_kernel" in k]
+        gemm = [(t, m) for t, k, n, m, avg in rows if ("conv_gemm" in k and ", 4, 32" not in k) or "tile_conv_kernel" in k or "tile_conv2p_kernel" in k or "gru_half_kernel" in k or "ou_head_kernel" in k]
         if gemm:
             f.write(f"# all conv-GEMM launches (ring-buffered and tile-resident) except the volume GEMM: {sum(t for t, _ in gemm) / sum(m for _, m in gemm) / 1e3:.1f} us "
                     f"average -- the figure bench.py reports as kernels.conv_gemm.avg_us (HIP events, + ~1.5 us of bracket)\n")
