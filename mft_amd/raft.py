@@ -354,10 +354,16 @@ class RAFTWrapper:
             return buf
 
         if self._enc_stream is None or torch.cuda.current_stream(self.device) == self._enc_stream:
-            return run(), (h, w)
+            cur = torch.cuda.current_stream(self.device)
+            self._encode_begin(cur)
+            buf = run()
+            self._encode_end(cur.record_event(), cur)
+            return buf, (h, w)
         main = torch.cuda.current_stream(self.device)
+        self._encode_begin(self._enc_stream)
         with torch.cuda.stream(self._enc_stream):
             buf = run()
+            self._encode_end(self._enc_stream.record_event(), self._enc_stream)
         if wait:
             main.wait_stream(self._enc_stream)
             buf.record_stream(main)
@@ -383,10 +389,16 @@ class RAFTWrapper:
             return buf
 
         if self._enc_stream is None or torch.cuda.current_stream(self.device) == self._enc_stream:
-            return run(), (h, w)
+            cur = torch.cuda.current_stream(self.device)
+            self._encode_begin(cur)
+            buf = run()
+            self._encode_end(cur.record_event(), cur)
+            return buf, (h, w)
         main = torch.cuda.current_stream(self.device)
+        self._encode_begin(self._enc_stream)
         with torch.cuda.stream(self._enc_stream):
             buf = run()
+            self._encode_end(self._enc_stream.record_event(), self._enc_stream)
         if wait:
             main.wait_stream(self._enc_stream)
             buf.record_stream(main)
@@ -432,9 +444,15 @@ class RAFTWrapper:
         # previous frame's selection -- which silently serialises the lanes (round 5: a plugin whose frames_in_flight was lowered
         # and raised again ran at the one-lane rate until the last event-less frame had left the cache: bench.py's host-io pass
         # behind its profile pass, 152 instead of 176 frames/s).
+        #   The encoder engines own ONE workspace each: an encode that runs on another stream than the previous one waits for it
+        # (_encode_begin / _encode_end: the default-async branch below, a plugin whose encode stream is switched on a live tracker --
+        # bench.py's profile pass does --, the sharded path's prefetch beside caller-stream encodes).
         if self._enc_stream is None:
+            cur = torch.cuda.current_stream()
+            self._encode_begin(cur)
             f = self.encode(img)
-            f.ready = torch.cuda.current_stream().record_event()
+            f.ready = cur.record_event()
+            self._encode_end(f.ready, cur)
             return f
         main = torch.cuda.current_stream()
         if self._enc_waits_for_device_frames and isinstance(img, torch.Tensor) and img.is_cuda:
@@ -443,19 +461,29 @@ class RAFTWrapper:
             # against 160 frames/s).  Frames known to be complete: say async_encode = True.
             # The encoder engines own ONE workspace each, and other encodes of this plugin (host frames, the sharded path's
             # prefetch: encode_packed / encode_half) run on the encode stream: this encode waits for those, and they for it.
-            main.wait_stream(self._enc_stream)
+            self._encode_begin(main)
             f = self.encode(img)
             f.ready = main.record_event()
-            self._enc_stream.wait_event(f.ready)
+            self._encode_end(f.ready, main)
             return f
+        self._encode_begin(self._enc_stream)
         with torch.cuda.stream(self._enc_stream):
             f = self.encode(img)
             f.ready = self._enc_stream.record_event()
+        self._encode_end(f.ready, self._enc_stream)
         main.wait_stream(self._enc_stream)
         for t in (f.fmap, f.net, f.inp):          # allocated on the side stream, consumed on `main`
             if t is not None:
                 t.record_stream(main)
         return f
+
+    def _encode_begin(self, stream):
+        prev = getattr(self, "_last_encode", None)
+        if prev is not None and prev[1] != stream:
+            stream.wait_event(prev[0])
+
+    def _encode_end(self, event, stream):
+        self._last_encode = (event, stream)
 
     def _features(self, key, img):
         if key is None:
