@@ -122,6 +122,7 @@ struct LfProducer {
     int pw, lane, rpw, TR, my_tiles, U;
     int c16, q;
     unsigned tap_rc[7][4];       // table indices (row entry | column entry << 16) of this lane's tap in DMA 4 i + e of a unit
+    int ent[3];                  // (cell << 8 | j) of this lane's table entry in pass k (entries 64 k + lane of 16 x 10)
     unsigned char *patches;
     float *cslots;
     unsigned *tab;               // row / column offsets of the windows being gathered: [cell][row 0..15 | column 0..15]
@@ -160,14 +161,7 @@ struct LfProducer {
     // large value where the row / column lies outside the level (any sum with it is out of range = a zero, as
     // grid_sample pads), into a small LDS table; phase 2 adds one row and one column entry per tap.
     struct GatherCtx { __amdgpu_buffer_rsrc_t rs; unsigned char *pdst; const unsigned *tb; int nd; };
-    struct ConvCtx { float T[36]; float w00, w01, w10, w11; unsigned char *dst; bool live; };
-    // what a unit's address-table passes need: level geometry, this lane's (cell of a pass, row | column, j) and the
-    // coordinates of its six cells (read together: one LDS round trip)
-    struct TableCtx {
-        float inv; unsigned H, W, rowmul, stride4, lim; bool blocked; int cell0, cl, kind, j;
-        float2 cv[6]; unsigned *tb;
-    };
-
+    struct ConvCtx { float T[36]; float w00, w01, w10, w11; unsigned char *dst; const unsigned char *src; bool live; };
     __device__ __forceinline__ void level_geometry(int v, const float *&base, long long &stride, unsigned &H, unsigned &W, unsigned &wb) const {
         const int l = v & 3;
         base = l == 0 ? p.lvl[0] : l == 1 ? p.lvl[1] : l == 2 ? p.lvl[2] : p.lvl[3];
@@ -177,41 +171,43 @@ struct LfProducer {
         wb = (unsigned)(l == 0 ? p.wb0 : p.wb1);
     }
 
-    // The address table of unit v, three cells per pass.
-    __device__ __forceinline__ void table_begin(int v, TableCtx &t) {
-        const int k = v >> 2, l = v & 3;
-        const float *base; long long stride; unsigned wb;
-        level_geometry(v, base, stride, t.H, t.W, wb);
-        t.inv = l == 0 ? 1.f : l == 1 ? 0.5f : l == 2 ? 0.25f : 0.125f;     // (x / 2^l, exactly)
-        t.blocked = l < 2;
-        t.rowmul = t.blocked ? wb * 128u : t.W * 4u;
-        t.stride4 = (unsigned)stride * 4u;
-        t.cell0 = tile_of(k) * TR + pw * rpw;
-        // three cells per pass: lane = (cell of the pass, row | column, j < 10)
-        t.cl = lane / 20;
-        const int rem = lane - 20 * t.cl;
-        t.kind = rem >= 10 ? 1 : 0;
-        t.j = rem - 10 * t.kind;
-        t.lim = t.kind ? t.W : t.H;
-        t.tb = tab;
-        const float2 *cs = reinterpret_cast<const float2 *>(cslots + (k % 3) * 32);
-#pragma unroll
-        for (int pass = 0; pass < 6; ++pass) t.cv[pass] = cs[min(3 * pass + t.cl, LF_CPP - 1)];
-    }
-    // (all 16 cells, used or not: the last DMA of a short unit runs a few taps into the next cell's table entries, which must say
+    // The address table of unit v: 160 row entries and 160 column entries (16 cells x 10), as three passes of rows and three of
+    // columns -- entry 64 k + lane of a kind; the lane's (cell, j) of pass k were worked out once (ent[k]).  Every pass carries
+    // ONE kind of entry, so no lane computes both forms and selects, and the multiplications are 24-bit (round 6: the table was
+    // 2.1 k of the producer's 6.6 k cycles per step with three cells per pass and both kinds in every pass).
+    // (All 16 cells, used or not: the last DMA of a short unit runs a few taps into the next cell's table entries, which must say
     // "outside" -- a stale entry could be a misaligned offset, and a misaligned dword of finite floats can be a NaN that the
-    // next cell's zero-weight dummy samples would spread over a whole row)
-    __device__ __forceinline__ void table_pass(const TableCtx &t, int pass) {
-        const int ci = 3 * pass + t.cl;
-        const float sv = (t.kind ? t.cv[pass].x : t.cv[pass].y) * t.inv;
-        // clamp so that the int conversion is defined for wild coordinates
-        const unsigned vv = (unsigned)((int)fminf(fmaxf(floorf(sv), -1.0e6f), 1.0e6f) - 4 + t.j);
-        unsigned val;
-        if (t.blocked) val = t.kind ? (vv >> 3) * 128u + (vv & 7u) * 4u : (vv >> 2) * t.rowmul + (vv & 3u) * 32u;
-        else val = t.kind ? vv * 4u : vv * t.rowmul;
-        if (!t.kind) val += (unsigned)ci * t.stride4;        // this cell's slice inside the unit's buffer
-        const bool ok = (ci < rpw) & (t.cell0 + ci < p.cells) & (vv < t.lim);
-        if (lane < 60 && ci < LF_CPP) t.tb[ci * 32 + t.kind * 16 + t.j] = ok ? val : 0x40000000u;
+    // next cell's zero-weight dummy samples would spread over a whole row.)
+    __device__ __forceinline__ void table(int v) {
+        const int k = v >> 2, l = v & 3;
+        const float *base; long long stride; unsigned H, W, wb;
+        level_geometry(v, base, stride, H, W, wb);
+        const float inv = l == 0 ? 1.f : l == 1 ? 0.5f : l == 2 ? 0.25f : 0.125f;     // (x / 2^l, exactly)
+        const bool blocked = l < 2;
+        const unsigned rowmul = blocked ? wb * 128u : W * 4u;
+        const unsigned stride4 = (unsigned)stride * 4u;
+        const int cell0 = tile_of(k) * TR + pw * rpw;
+        const float *cs = cslots + (k % 3) * 32;
+        float cx[3], cy[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { cx[q] = cs[2 * (ent[q] >> 8)]; cy[q] = cs[2 * (ent[q] >> 8) + 1]; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {             // rows
+            const int ci = ent[q] >> 8, j = ent[q] & 15;
+            // clamp so that the int conversion is defined for wild coordinates
+            const unsigned yy = (unsigned)((int)fminf(fmaxf(floorf(cy[q] * inv), -1.0e6f), 1.0e6f) - 4 + j);
+            const unsigned val = (blocked ? __umul24(yy >> 2, rowmul) + (yy & 3u) * 32u : __umul24(yy, rowmul)) + __umul24((unsigned)ci, stride4);
+            const bool ok = (ci < rpw) & (cell0 + ci < p.cells) & (yy < H);
+            if (q < 2 || lane < 32) tab[ci * 32 + j] = ok ? val : 0x40000000u;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {             // columns
+            const int ci = ent[q] >> 8, j = ent[q] & 15;
+            const unsigned xx = (unsigned)((int)fminf(fmaxf(floorf(cx[q] * inv), -1.0e6f), 1.0e6f) - 4 + j);
+            const unsigned val = blocked ? (xx >> 3) * 128u + (xx & 7u) * 4u : xx * 4u;
+            const bool ok = (ci < rpw) & (cell0 + ci < p.cells) & (xx < W);
+            if (q < 2 || lane < 32) tab[ci * 32 + 16 + j] = ok ? val : 0x40000000u;
+        }
     }
 
     // what unit v's DMA groups need
@@ -246,19 +242,24 @@ struct LfProducer {
     // conversion of unit v: lane (cell c16, quarter q) blends samples k'' = 24 q .. 24 q + 23 of its cell and stores
     // their halves into the A slot v & 1 -- in three chunks of eight samples, so that the DMAs of the next gather can be issued
     // between them (a DMA holds the wave that issues the NEXT one; VALU work slotted in between is free)
-    __device__ __forceinline__ void conv_load(int v, ConvCtx &C) {
+    // what the conversion of unit v needs apart from the taps -- bilinear weights, source, destination: worked out BEFORE the wait for
+    // the unit's gather (it depends on the coordinates only; round 6: one LDS round trip less in the step's chain)
+    __device__ __forceinline__ void conv_prepare(int v, ConvCtx &C) {
         float sx, sy;
         level_coords(v, sx, sy);
         const float fx = sx - floorf(sx), fy = sy - floorf(sy);
         C.w00 = (1.f - fx) * (1.f - fy); C.w01 = fx * (1.f - fy); C.w10 = (1.f - fx) * fy; C.w11 = fx * fy;
-        const lf_f32x4 *src = reinterpret_cast<const lf_f32x4 *>(patches + (v % 3) * LF_PSLOT + c16 * LF_PATCH + q * 96);
+        C.src = patches + (v % 3) * LF_PSLOT + c16 * LF_PATCH + q * 96;
+        C.dst = lds + (v & 1) * LF_AUNIT + (pw * rpw + c16) * LF_AROW + q * 96;
+        C.live = c16 < rpw;
+    }
+    __device__ __forceinline__ void conv_load(ConvCtx &C) {
+        const lf_f32x4 *src = reinterpret_cast<const lf_f32x4 *>(C.src);
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const lf_f32x4 t = src[i];
             C.T[4 * i] = t[0]; C.T[4 * i + 1] = t[1]; C.T[4 * i + 2] = t[2]; C.T[4 * i + 3] = t[3];
         }
-        C.dst = lds + (v & 1) * LF_AUNIT + (pw * rpw + c16) * LF_AROW + q * 96;
-        C.live = c16 < rpw;
     }
     __device__ __forceinline__ void conv_chunk(const ConvCtx &C, int g8) {
         const float k2048 = 2048.f;
@@ -285,10 +286,7 @@ struct LfProducer {
         GatherCtx G{};
         ConvCtx C;
         if (vg >= 0) {
-            TableCtx t;
-            table_begin(vg, t);
-#pragma unroll
-            for (int pass = 0; pass < 6; ++pass) table_pass(t, pass);
+            table(vg);
             G = gather_begin(vg);
         }
 #ifdef MFTX_TUNING
@@ -296,8 +294,9 @@ struct LfProducer {
         if (p.ablate & 4) vc = -1;
 #endif
         if (vc >= 0) {
+            conv_prepare(vc, C);
             lf_wait_vmcnt(younger(vc, 1));
-            conv_load(vc, C);
+            conv_load(C);
         }
 #pragma unroll
         for (int i = 0; i < 7; ++i) {            // (unrolled: tap_rc stays in registers)
@@ -333,6 +332,11 @@ struct LfProducer {
                 const int cell = g / 100, t = g - 100 * cell, r = t / 10;
                 tap_rc[i][e] = cell < LF_CPP ? (unsigned)(cell * 32 + r) | ((unsigned)(cell * 32 + 16 + (t - 10 * r)) << 16) : 0u;
             }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int idx = min(64 * q + lane, 159);
+            ent[q] = ((idx / 10) << 8) | (idx % 10);
+        }
         coords_issue(0);
         lf_wait_vmcnt(0);
         LF_T(2);
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(512, 2) void lookup_convc1_kernel(LookupConvArgs p)
     if (wid >= 4) {
         const int pw = wid - 4;
         LfProducer P{p, lf_lds, pw, lane, p.rpw, TR, my_tiles, U,
-                     lane & 15, lane >> 4, {},
+                     lane & 15, lane >> 4, {}, {},
                      lf_lds + LF_OFF_PATCH + pw * (LF_NP * LF_PSLOT),
                      reinterpret_cast<float *>(lf_lds + LF_OFF_COORD + pw * (3 * 128)),
                      reinterpret_cast<unsigned *>(lf_lds + LF_OFF_TAB + pw * (LF_CPP * 32 * 4))};
