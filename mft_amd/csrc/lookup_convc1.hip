@@ -32,6 +32,7 @@ typedef float lf_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned lf_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned lf_u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 lf_f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) const unsigned lf_lds_u32;
 
 constexpr int LF_GROUPS = 24;                       // 16-wide k groups: 4 levels x 6
 constexpr int LF_AROW = 400;                        // bytes per A row of a unit: 96 x 4 + 16 (rows r, r + 1 start 25 sixteen-byte slots apart: conflict-free ds_read_b128)
@@ -121,7 +122,9 @@ struct LfProducer {
     unsigned char *lds;
     int pw, lane, rpw, TR, my_tiles, U;
     int c16, q;
-    unsigned tap_rc[7][4];       // table indices (row entry | column entry << 16) of this lane's tap in DMA 4 i + e of a unit
+    // this lane's tap in DMA 4 i + e of a unit: the LDS addresses of its row entry and of its column entry in the table (round 6:
+    // addresses, not packed indices -- the unpacking was 4 VALU instructions per DMA and lane, 100 per unit)
+    lf_lds_u32 *tap_r[7][4], *tap_c[7][4];
     int ent[3];                  // (cell << 8 | j) of this lane's table entry in pass k (entries 64 k + lane of 16 x 10)
     unsigned char *patches;
     float *cslots;
@@ -224,7 +227,7 @@ struct LfProducer {
         G.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base + (long long)c0 * stride), 0, (unsigned)rpw * (unsigned)stride * 4u, 0x00020000);
         // The unit's taps form ONE array -- cell after cell, 100 each -- and a DMA instruction fetches 64 consecutive ones:
         // 25 full instructions for 16 cells.  A lane's (cell, row, column) in DMA d never changes: their table addresses were
-        // worked out once (tap_rc).  (Taps past the last cell: table entries that say "outside" -- zeros into a patch nobody reads.)
+        // worked out once (tap_r / tap_c).  (Taps past the last cell: table entries that say "outside" -- zeros into a patch nobody reads.)
         G.nd = n_gather(v);
         return G;
     }
@@ -233,7 +236,7 @@ struct LfProducer {
     __device__ __forceinline__ void dma_group(const GatherCtx &G, int i) {
         unsigned o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = G.tb[tap_rc[i][e] & 0xffffu] + G.tb[tap_rc[i][e] >> 16];
+        for (int e = 0; e < 4; ++e) o[e] = *tap_r[i][e] + *tap_c[i][e];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (4 * i + e < G.nd) lf_dma4(G.rs, G.pdst + (4 * i + e) * 256, o[e]);
@@ -299,7 +302,7 @@ struct LfProducer {
             conv_load(C);
         }
 #pragma unroll
-        for (int i = 0; i < 7; ++i) {            // (unrolled: tap_rc stays in registers)
+        for (int i = 0; i < 7; ++i) {            // (unrolled: tap_r / tap_c stay in registers)
             if (vg >= 0 && 4 * i < G.nd) dma_group(G, i);
             __builtin_amdgcn_sched_barrier(0);
             if (vc >= 0 && i < 3) conv_chunk(C, i);
@@ -330,7 +333,9 @@ struct LfProducer {
             for (int e = 0; e < 4; ++e) {
                 const int g = 64 * (4 * i + e) + lane;                    // this lane's tap in the unit's array
                 const int cell = g / 100, t = g - 100 * cell, r = t / 10;
-                tap_rc[i][e] = cell < LF_CPP ? (unsigned)(cell * 32 + r) | ((unsigned)(cell * 32 + 16 + (t - 10 * r)) << 16) : 0u;
+                lf_lds_u32 *tb3 = (lf_lds_u32 *)tab;
+                tap_r[i][e] = tb3 + (cell < LF_CPP ? cell * 32 + r : 0);
+                tap_c[i][e] = tb3 + (cell < LF_CPP ? cell * 32 + 16 + (t - 10 * r) : 0);
             }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(512, 2) void lookup_convc1_kernel(LookupConvArgs p)
     if (wid >= 4) {
         const int pw = wid - 4;
         LfProducer P{p, lf_lds, pw, lane, p.rpw, TR, my_tiles, U,
-                     lane & 15, lane >> 4, {}, {},
+                     lane & 15, lane >> 4, {}, {}, {},
                      lf_lds + LF_OFF_PATCH + pw * (LF_NP * LF_PSLOT),
                      reinterpret_cast<float *>(lf_lds + LF_OFF_COORD + pw * (3 * 128)),
                      reinterpret_cast<unsigned *>(lf_lds + LF_OFF_TAB + pw * (LF_CPP * 32 * 4))};
