@@ -16,10 +16,14 @@ $BENCH > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 # A/B of the round's structural changes, same box, same run (results do not depend on any of them beyond fp32 rounding)
 $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-graphs > $OUT/bench_no_graphs.json 2>/dev/null; echo "bench no-graphs rc=$?"
 $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-fused-lookup > $OUT/bench_no_fused_lookup.json 2>/dev/null; echo "bench no-fused-lookup rc=$?"
-(for o in "" "fuse_gru=0" "fuse_ou=0" "gather=0" "fuse_head=2" "fuse_head=0" "tile_volume=0" "tile_conv=0" "fuse_flow=0" "fuse_lookup=0" "fuse_head=0 tile_conv=0 fuse_flow=0" "gather=0 tile_volume=0 fuse_head=0 tile_conv=0 fuse_flow=0 fuse_lookup=0 fuse_gru=0 fuse_ou=0 graph=0"; do
+(for o in "" "tile_conv2p=0" "fuse_gru=0" "fuse_ou=0" "gather=0" "fuse_head=2" "fuse_head=0" "tile_volume=0" "tile_conv=0" "fuse_flow=0" "fuse_lookup=0" "fuse_head=0 tile_conv=0 fuse_flow=0" "gather=0 tile_volume=0 fuse_head=0 tile_conv=0 fuse_flow=0 fuse_lookup=0 fuse_gru=0 fuse_ou=0 graph=0"; do
    args=""; for kv in $o; do args="$args --engine-opt $kv"; done
    for rep in 1 2; do $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-host-io $args 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('engine options [$o]:', round(d['value'],1), 'frames/s, host', round(d['host_enqueue_ms_per_step'],2), 'ms per frame, conv GEMM', round(d['roofline']['frac'],3), 'of the fp16 MFMA peak')"; done
  done) > $OUT/engine_options_ab.txt
+# the fused lookup's 16-byte-gather variant (csrc/lookup_convc1_wide.hip -> mft_amd/libmftx_lfwide.so) against the default, alternating (round 6)
+if [ -f mft_amd/libmftx_lfwide.so ]; then
+  (for rep in 1 2 3; do for lib in "" "MFTX_LIB=$PWD/mft_amd/libmftx_lfwide.so"; do env $lib $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-host-io 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); k=d['kernels']['lookup_convc1_fused']; print('${lib:+16-byte gather (lfwide)}' or 'dword gather (default)  ', round(d['value'],1), 'frames/s; lookup_convc1_fused', round(k['avg_us'],1), 'us, frac', round(k['frac'],3))"; done; done) > $OUT/lookup_gather_ab.txt
+fi
 # frames in flight (flow_config.frames_in_flight): 1 / 2 / 3 lanes, same box, twice
 (for rep in 1 2; do for f in 1 2 3; do $BENCH --no-cpu-baseline --no-parity --no-alt-arith --no-profile --frames-in-flight $f 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('frames in flight $f:', round(d['value'],1), 'frames/s,', round(d['ms_per_step'],3), 'ms per frame, with PCIe', round(d['host_io_fps'],1))"; done; done
  for f in 1 2; do python bench.py --steps 20 --warmup 5 --height 256 --width 256 --no-cpu-baseline --no-parity --no-alt-arith --no-profile --no-host-io --frames-in-flight $f 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('256 x 256, frames in flight $f:', round(d['value'],1), 'frames/s')"; done
