@@ -121,7 +121,6 @@ class RAFTWrapper:
         # split arithmetic (the fp32 path batches through _refine_split instead), 1 otherwise.
         self._fif = self._frames_in_flight_setting(config)
         self._lanes, self._lane_next = [], 0          # [(engine, stream)]
-        self._split_frame = os.environ.get("MFTX_SPLIT_FRAME", "") == "1"
         self._lanes_stale = False
         # ... and the host may not run ahead of the GPU without bound (every queued batch holds its outputs, allocated when it is
         # enqueued: 29 MB per 512 x 512 frame of 7 pairs): at most C.max_batches_ahead (default 16) lane batches are pending, the
@@ -529,12 +528,8 @@ class RAFTWrapper:
         want_planar = planar or packed_out is None or packed_out is False
         if (self._fif > 1 and gather and flow_init is None and not self._check_finite
                 and (packed_out is None or isinstance(packed_out, bool))):
-            if self._split_frame and P >= 4:
-                # EXPERIMENT (MFTX_SPLIT_FRAME=1): the frame's batch as two halves on two consecutive lanes
-                k = (P + 1) // 2
-                a = self._refine_on_lane(fls[:k], frs[:k], fmap1[:k], fmap2[:k], net[:k], inp[:k], ref, iters, bool(packed_out), want_planar)
-                b = self._refine_on_lane(fls[k:], frs[k:], fmap1[k:], fmap2[k:], net[k:], inp[k:], ref, iters, bool(packed_out), want_planar)
-                return a + b
+            # (one frame's batch as two halves on the two lanes -- for the caller that synchronises per frame -- was measured in
+            # round 6: the pipelined rate falls 188 -> 171 frames/s and the per-frame-synchronised rate does not move, 150 -> 150.)
             return self._refine_on_lane(fls, frs, fmap1, fmap2, net, inp, ref, iters, bool(packed_out), want_planar)
         if packed_out is not None and packed_out is not False:
             packed = packed_out if isinstance(packed_out, torch.Tensor) else \
