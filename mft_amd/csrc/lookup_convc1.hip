@@ -102,6 +102,14 @@ __device__ __forceinline__ void lf_dma4(__amdgpu_buffer_rsrc_t r, void *dst, uns
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)dst, 4, voff, 0, 0, 0);
 }
 
+// the bilinear blend of four taps, spelled out: one multiply and three fused multiply-adds in THIS order.  Left to the compiler's
+// contraction, the copies of the conversion that inlining makes (the prologue's and the loop's) may contract differently -- round 6
+// saw exactly that after a code motion: 1-ulp differences between a cell converted as a workgroup's first tile and as its second,
+// i.e. a pair's bits depending on its batch (tests/test_gpu_e2e.py::test_pair_bits_independent_of_batch_512, tools/lf_invariance.py).
+__device__ __forceinline__ float lf_blend4(float t00, float t01, float t10, float t11, float w00, float w01, float w10, float w11) {
+    return __builtin_fmaf(t11, w11, __builtin_fmaf(t10, w10, __builtin_fmaf(t01, w01, __fmul_rn(t00, w00))));
+}
+
 // (hi, lo) halves of two values: 5 instructions (conv_gemm.hip: split_pair)
 __device__ __forceinline__ void lf_split_pair(float x0, float x1, float k2048, unsigned &h, unsigned &l) {
     float r0, r1;
@@ -250,8 +258,9 @@ struct LfProducer {
     __device__ __forceinline__ void conv_prepare(int v, ConvCtx &C) {
         float sx, sy;
         level_coords(v, sx, sy);
-        const float fx = sx - floorf(sx), fy = sy - floorf(sy);
-        C.w00 = (1.f - fx) * (1.f - fy); C.w01 = fx * (1.f - fy); C.w10 = (1.f - fx) * fy; C.w11 = fx * fy;
+        const float fx = __fsub_rn(sx, floorf(sx)), fy = __fsub_rn(sy, floorf(sy));
+        const float gx = __fsub_rn(1.f, fx), gy = __fsub_rn(1.f, fy);
+        C.w00 = __fmul_rn(gx, gy); C.w01 = __fmul_rn(fx, gy); C.w10 = __fmul_rn(gx, fy); C.w11 = __fmul_rn(fx, fy);
         C.src = patches + (v % 3) * LF_PSLOT + c16 * LF_PATCH + q * 96;
         C.dst = lds + (v & 1) * LF_AUNIT + (pw * rpw + c16) * LF_AROW + q * 96;
         C.live = c16 < rpw;
@@ -270,8 +279,8 @@ struct LfProducer {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int j = 8 * g8 + 2 * e;
-            const float v0 = C.T[j] * C.w00 + C.T[j + 1] * C.w01 + C.T[j + 10] * C.w10 + C.T[j + 11] * C.w11;
-            const float v1 = C.T[j + 1] * C.w00 + C.T[j + 2] * C.w01 + C.T[j + 11] * C.w10 + C.T[j + 12] * C.w11;
+            const float v0 = lf_blend4(C.T[j], C.T[j + 1], C.T[j + 10], C.T[j + 11], C.w00, C.w01, C.w10, C.w11);
+            const float v1 = lf_blend4(C.T[j + 1], C.T[j + 2], C.T[j + 11], C.T[j + 12], C.w00, C.w01, C.w10, C.w11);
             lf_split_pair(v0, v1, k2048, h[e], l[e]);
         }
         if (C.live) {

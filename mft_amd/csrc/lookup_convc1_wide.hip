@@ -119,6 +119,14 @@ __device__ __forceinline__ void lf_dma16(__amdgpu_buffer_rsrc_t r, void *dst, un
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void *)dst, 16, voff, 0, 0, 0);
 }
 
+// the bilinear blend of four taps, spelled out: one multiply and three fused multiply-adds in THIS order.  Left to the compiler's
+// contraction, the copies of the conversion that inlining makes (the prologue's and the loop's) may contract differently -- round 6
+// saw exactly that after a code motion: 1-ulp differences between a cell converted as a workgroup's first tile and as its second,
+// i.e. a pair's bits depending on its batch (tests/test_gpu_e2e.py::test_pair_bits_independent_of_batch_512, tools/lf_invariance.py).
+__device__ __forceinline__ float lf_blend4(float t00, float t01, float t10, float t11, float w00, float w01, float w10, float w11) {
+    return __builtin_fmaf(t11, w11, __builtin_fmaf(t10, w10, __builtin_fmaf(t01, w01, __fmul_rn(t00, w00))));
+}
+
 // (hi, lo) halves of two values: 5 instructions (conv_gemm.hip: split_pair)
 __device__ __forceinline__ void lf_split_pair(float x0, float x1, float k2048, unsigned &h, unsigned &l) {
     float r0, r1;
@@ -322,8 +330,9 @@ struct LfProducer {
     __device__ __forceinline__ void conv_prepare(int v, ConvCtx &C) {
         float sx, sy;
         level_coords(v, sx, sy);
-        const float fx = sx - floorf(sx), fy = sy - floorf(sy);
-        C.w00 = (1.f - fx) * (1.f - fy); C.w01 = fx * (1.f - fy); C.w10 = (1.f - fx) * fy; C.w11 = fx * fy;
+        const float fx = __fsub_rn(sx, floorf(sx)), fy = __fsub_rn(sy, floorf(sy));
+        const float gx = __fsub_rn(1.f, fx), gy = __fsub_rn(1.f, fy);
+        C.w00 = __fmul_rn(gx, gy); C.w01 = __fmul_rn(fx, gy); C.w10 = __fmul_rn(gx, fy); C.w11 = __fmul_rn(fx, fy);
         const bool wide = is_wide(v);
         const int s = wide ? window_origin(sx) & 3 : 0;
         const unsigned char *cellp = patches + (v & 1) * LF_PSLOT + c16 * (wide ? LF_WCELL : LF_NCELL);
@@ -341,10 +350,10 @@ struct LfProducer {
     static __device__ __forceinline__ float sample(const ConvCtx &C) {
         if constexpr (I < 18) {
             constexpr int r = I / 9, a = I - 9 * r;
-            return C.T1[10 * r + a] * C.w00 + C.T1[10 * r + a + 1] * C.w01 + C.T1[10 * r + 10 + a] * C.w10 + C.T1[10 * r + 11 + a] * C.w11;
+            return lf_blend4(C.T1[10 * r + a], C.T1[10 * r + a + 1], C.T1[10 * r + 10 + a], C.T1[10 * r + 11 + a], C.w00, C.w01, C.w10, C.w11);
         } else if constexpr (I < 21) {
             constexpr int a = I - 18;
-            return C.T2[a] * C.w00 + C.T2[a + 1] * C.w01 + C.T2[4 + a] * C.w10 + C.T2[5 + a] * C.w11;
+            return lf_blend4(C.T2[a], C.T2[a + 1], C.T2[4 + a], C.T2[5 + a], C.w00, C.w01, C.w10, C.w11);
         } else {
             return 0.f;
         }
