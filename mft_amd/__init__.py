@@ -42,7 +42,9 @@ from .results import FlowOUTrackingResult, FlowOUResult  # noqa: F401,E402
 
 def __getattr__(name):  # lazy: these import torch-heavy modules
     if name in ("MFT", "chain_results", "get_flowou_with_cache"):
-        from . import MFT as _m
+        import importlib
+        _m = importlib.import_module(__name__ + ".MFT")       # (`from . import MFT` would ask this very function for "MFT": recursion)
+        globals()["MFT"] = _m.MFT                             # the CLASS, as the docstring promises (importing the submodule bound its own name here)
         return getattr(_m, name)
     if name == "RAFTWrapper":
         from .raft import RAFTWrapper

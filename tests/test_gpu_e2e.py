@@ -574,20 +574,24 @@ def test_nonfinite_results_are_counted_and_raise(weights_np):
         out = tr0.track(vid[2]).result                                     # NaN flows through, as in the reference
         assert not torch.isfinite(out.flow).all() and tr0.current_frame_i == 2
         assert fl.nonfinite_count(reset=True) > 0
-    # results kept on the device: no sync per frame, the check comes every C.nonfinite_check_every frames / on demand
+    # results kept on the device: no sync per frame -- every frame sends a 16-byte snapshot of the counters to pinned memory and the
+    # tracker looks at the snapshots that have arrived (round 6: no pipeline drain); on demand: check_nonfinite()
+    vid8 = SyntheticVideo(128, 192, n_frames=9, seed=1)
     tr2 = make_tracker(fl, deltas=(np.inf, 1))
     tr2.C.keep_result_on_device = True
     tr2.C.nonfinite_check_every = 3
-    tr2.init(vid[0])
-    tr2.track(vid[1])
+    tr2.init(vid8[0])
+    tr2.track(vid8[1])
     fl._frames[1] = FrameFeatures(f, z, z, 16, 24, (0, 0, 0, 0), (128, 192))
-    tr2.track(vid[2])                                                      # poisoned, not yet noticed
+    tr2.track(vid8[2])                                                     # poisoned, not yet noticed
     assert fl.nonfinite_count() > 0
     with pytest.raises(FloatingPointError):
         tr2.check_nonfinite()
     fl._frames[2] = FrameFeatures(f, z, z, 16, 24, (0, 0, 0, 0), (128, 192))
     with pytest.raises(FloatingPointError):
-        tr2.track(vid[3])                                                  # third unchecked frame: the periodic check fires
+        for i in range(3, 8):                                              # a snapshot arrives within a frame or two; after
+            tr2.track(vid8[i])                                             # `nonfinite_check_every` frames at the latest it is waited for
+    assert tr2.current_frame_i <= 6
 
 
 def test_infinite_sigma_is_not_an_error_and_drain_checks_without_sync(weights_np):

@@ -500,3 +500,14 @@ def test_variant_library_exports_the_same_symbols():
     h = ctypes.CDLL(str(lib))
     missing = [n for n in sorted(set(names)) if not hasattr(h, n)]
     assert not missing, missing
+
+
+def test_package_level_names_resolve():
+    """`from mft_amd import MFT` gives the tracker CLASS (round 6: the lazy attribute hook recursed for it), and the submodule path of the
+    reference-style import keeps working."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, "-c", "from mft_amd import MFT, chain_results, get_flowou_with_cache, RAFTWrapper, FlowOUResult\n"
+                          "from mft_amd.MFT import MFT as M2\nimport inspect\nassert inspect.isclass(MFT) and M2 is MFT and inspect.isclass(RAFTWrapper)\nprint('ok')"],
+                         capture_output=True, text=True, cwd=str(REPO), timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-1500:]
