@@ -22,3 +22,5 @@ pr.disable()
 st = pstats.Stats(pr, stream=sys.stderr)
 st.sort_stats("cumulative").print_stats("mft_amd|bench.py:4", 40)
 st.sort_stats("tottime").print_stats("mft_amd|torch/cuda|built-in|method", 40)
+for fn in ("_refine_on_lane", "_start_window", "_finish_frame", "_start_feature_exchange", "compute_pairs"):
+    st.sort_stats("cumulative").print_callees(fn)
